@@ -1,0 +1,53 @@
+"""Builds libimplicit_hip.so (hipcc, gfx950) in-tree next to this file.
+
+`python -m implicit_amd._build [--force]`.  Each .hip translation unit is compiled to an object in
+parallel and linked into implicit_amd/libimplicit_hip.so, which links librccl (multi-GPU exchange)
+and the HIP runtime only -- no PyTorch, no BLAS/solver/rand vendor libraries.
+"""
+import concurrent.futures
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJDIR = os.path.join(HERE, "csrc", "_obj")
+LIB = os.path.join(HERE, "libimplicit_hip.so")
+SOURCES = ["containers.hip", "als_cg.hip", "als_cholesky.hip", "gramian.hip", "solver.hip", "topk.hip",
+           "random.hip", "comm.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-Wno-unused-result", "-ffp-contract=off"]
+
+
+def _deps():
+    hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
+    hdrs.append(os.path.join(HERE, "..", "include", "implicit_hip.h"))
+    return max(os.path.getmtime(h) for h in hdrs)
+
+
+def _compile(src, force, hdr_mtime):
+    obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+    path = os.path.join(CSRC, src)
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), hdr_mtime):
+        return obj, False
+    subprocess.check_call([HIPCC, *FLAGS, "-c", path, "-o", obj])
+    return obj, True
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJDIR, exist_ok=True)
+    hdr_mtime = _deps()
+    with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
+        results = list(ex.map(lambda s: _compile(s, force, hdr_mtime), SOURCES))
+    objs = [o for o, _ in results]
+    if force or any(c for _, c in results) or not os.path.exists(LIB):
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB,
+                               "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"])
+        if verbose:
+            print(f"[implicit_amd] built {LIB}")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,162 @@
+// K2: Cholesky half sweep  X[u] = (YtY + reg I + Y_u^T (C_u - I) Y_u)^-1  Y_u^T C_u p_u
+//
+// NEW on the GPU side (the reference's CUDA path is CG-only, implicit/gpu/als.cu); restates the CPU
+// oracle implicit/cpu/_als.pyx:75-142: A = YtY + reg*I, b = sum_{c>0} c*y,
+// A += (|c|-1) y y^T, posv, cold solve (previous X ignored), empty rows -> 0, a non-positive pivot
+// reports the row (the oracle raises ValueError there, _als.pyx:131-138).
+//
+// One workgroup per row.  The (f+1) x (f+1) AUGMENTED lower triangle [A b; b^T .] lives in LDS with an
+// odd leading dimension (bank-conflict-free column walks); factoring its first f columns leaves
+// z = L^-1 b in the last row for free, and the back substitution L^T x = z is done by one wavefront
+// with readlane broadcasts (no block barriers).  Gathered factor rows are staged through LDS in
+// tiles of TILE rows, each a fully coalesced read.
+#include "common.h"
+
+namespace imp {
+
+constexpr int kCholTile = 8;
+
+__device__ __forceinline__ float bcast_lane(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+__global__ __launch_bounds__(256) void als_cholesky_kernel(const int32_t *__restrict__ order, int first, int count,
+                                                           const int32_t *__restrict__ indptr,
+                                                           const int32_t *__restrict__ indices,
+                                                           const float *__restrict__ data, float *__restrict__ X,
+                                                           const float *__restrict__ Y, const float *__restrict__ YtY,
+                                                           int f, float reg, int lda, unsigned long long *failed_row) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *A = smem;                              // [(f+1)][lda] lower triangle used, row f = b^T -> z^T
+  float *yt = A + (size_t)(f + 1) * lda;        // [TILE][f]   gathered rows
+  float *ut = yt + (size_t)kCholTile * f;       // [TILE][f+1] (|c|-1) * y, last = c+
+  const int tid = threadIdx.x;
+  const int ti = tid >> 4, tj = tid & 15;
+
+  for (int ri = blockIdx.x; ri < count; ri += gridDim.x) {
+    const int u = order[first + ri];
+    const int row_begin = indptr[u], row_end = indptr[u + 1];
+
+    // A = YtY + reg I (lower triangle), b = 0
+    for (int i = ti; i <= f; i += 16)
+      for (int j = tj; j <= i && j < f; j += 16)
+        A[i * lda + j] = i < f ? YtY[(size_t)i * f + j] + (i == j ? reg : 0.f) : 0.f;
+    __syncthreads();
+
+    for (int k0 = row_begin; k0 < row_end; k0 += kCholTile) {
+      const int cnt = min(kCholTile, row_end - k0);
+      // stage the tile: one wave per gathered row -> coalesced
+      for (int e = tid; e < kCholTile * f; e += 256) {
+        int t = e / f, c = e - t * f;
+        float yv = 0.f, uv = 0.f;
+        if (t < cnt) {
+          float conf = data[k0 + t];
+          float a = conf > 0.f ? conf : -conf;
+          yv = Y[(size_t)indices[k0 + t] * f + c];
+          uv = (a - 1.f) * yv;
+        }
+        yt[t * f + c] = yv;
+        ut[t * (f + 1) + c] = uv;
+      }
+      if (tid < kCholTile) {
+        float conf = tid < cnt ? data[k0 + tid] : 0.f;
+        ut[tid * (f + 1) + f] = conf > 0.f ? conf : 0.f;
+      }
+      __syncthreads();
+      for (int i = ti; i <= f; i += 16)
+        for (int j = tj; j <= i && j < f; j += 16) {
+          float s = A[i * lda + j];
+#pragma unroll
+          for (int t = 0; t < kCholTile; ++t) s = fmaf(ut[t * (f + 1) + i], yt[t * f + j], s);
+          A[i * lda + j] = s;
+        }
+      __syncthreads();
+    }
+
+    // right-looking Cholesky of the first f columns of the augmented triangle
+    bool ok = true;
+    for (int k = 0; k < f; ++k) {
+      float d = A[k * lda + k];
+      if (!(d > 0.f)) {  // uniform: every thread reads the same LDS word
+        ok = false;
+        break;
+      }
+      float inv = 1.0f / sqrtf(d);
+      __syncthreads();  // everyone has read the pivot
+      for (int i = k + tid; i <= f; i += 256) A[i * lda + k] = i == k ? sqrtf(d) : A[i * lda + k] * inv;
+      __syncthreads();
+      for (int i = k + 1 + ti; i <= f; i += 16) {
+        float lik = A[i * lda + k];
+        for (int j = k + 1 + tj; j <= i && j < f; j += 16) A[i * lda + j] = fmaf(-lik, A[j * lda + k], A[i * lda + j]);
+      }
+      __syncthreads();
+    }
+    if (!ok) {
+      if (tid == 0) atomicMin(failed_row, (unsigned long long)u);
+      __syncthreads();
+      continue;
+    }
+    // back substitution L^T x = z with one wavefront; lane l owns z[l + 64 m]
+    if (tid < 64) {
+      constexpr int MAXV = 4;  // f <= 256
+      float z[MAXV];
+#pragma unroll
+      for (int m = 0; m < MAXV; ++m) {
+        int i = tid + 64 * m;
+        z[m] = i < f ? A[f * lda + i] : 0.f;
+      }
+      for (int k = f - 1; k >= 0; --k) {
+        float zk = 0.f;
+#pragma unroll
+        for (int m = 0; m < MAXV; ++m)
+          if ((k >> 6) == m) zk = bcast_lane(z[m], k & 63);
+        float xk = zk / A[k * lda + k];
+#pragma unroll
+        for (int m = 0; m < MAXV; ++m) {
+          int i = tid + 64 * m;
+          if (i < k) z[m] = fmaf(-A[k * lda + i], xk, z[m]);
+          if (i == k) z[m] = xk;
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < MAXV; ++m) {
+        int i = tid + 64 * m;
+        if (i < f) X[(size_t)u * f + i] = z[m];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+void zero_rows(const int32_t *order, int first, int count, float *X, int f);  // als_cg.hip
+
+static unsigned long long *g_failed = nullptr;
+
+// returns -1, or the smallest failing row
+int64_t least_squares_cholesky(const imp_csr *C, imp_matrix *X, const imp_matrix *YtY, const imp_matrix *Y, double reg) {
+  const int f = (int)X->cols;
+  if (f > 160) throw std::invalid_argument("least_squares_cholesky: factors must be <= 160 in this build");
+  int lda = (f + 1) | 1;  // odd
+  size_t lds = ((size_t)(f + 1) * lda + (size_t)kCholTile * f + (size_t)kCholTile * (f + 1)) * sizeof(float);
+  if (!g_failed) IMP_CHECK_HIP(hipMalloc(&g_failed, sizeof(unsigned long long)));
+  IMP_CHECK_HIP(hipMemsetAsync(g_failed, 0xFF, sizeof(unsigned long long), stream()));
+  int nonempty = C->bin_start[2];
+  if (nonempty > 0) {
+    IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(als_cholesky_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
+    int grid = std::min(nonempty, ctx().num_cus * per_cu);
+    IMP_PROF("als_cholesky_rows");
+    als_cholesky_kernel<<<grid, 256, lds, stream()>>>(C->order.data(), 0, nonempty, C->indptr.data(), C->indices.data(),
+                                                      C->data.data(), X->f32(), Y->f32(), YtY->f32(), f, (float)reg, lda,
+                                                      g_failed);
+    IMP_CHECK_HIP(hipGetLastError());
+  }
+  zero_rows(C->order.data(), C->bin_start[2], C->bin_start[3] - C->bin_start[2], X->f32(), f);
+  unsigned long long failed = 0;
+  IMP_CHECK_HIP(hipMemcpyAsync(&failed, g_failed, sizeof(failed), hipMemcpyDeviceToHost, stream()));
+  sync();
+  return failed == ~0ULL ? -1 : (int64_t)failed;
+}
+
+}  // namespace imp

@@ -1,0 +1,98 @@
+// Multi-GPU exchange: one process per GPU, RCCL over xGMI.  No counterpart in the reference
+// ("TODO: multi-gpu support", implicit/gpu/als.cu:169).  Only two collectives exist on the ALS data
+// path (multi-GPU section): the f x f gramian all-reduce and the all-gather of the freshly
+// solved factor-row shards; both run on the library stream, in place on replicated buffers.
+#include <rccl/rccl.h>
+
+#include <cstring>
+
+#include "common.h"
+
+#define IMP_CHECK_NCCL(expr)                                                                        \
+  do {                                                                                              \
+    ncclResult_t _r = (expr);                                                                       \
+    if (_r != ncclSuccess) {                                                                        \
+      throw std::runtime_error(std::string("RCCL error: ") + ncclGetErrorString(_r) + " (" +       \
+                               __FILE__ + ":" + std::to_string(__LINE__) + ")");                  \
+    }                                                                                               \
+  } while (0)
+
+struct imp_comm {
+  ncclComm_t comm = nullptr;
+  int nranks = 1, rank = 0;
+};
+
+using namespace imp;
+
+extern "C" {
+
+static_assert(sizeof(ncclUniqueId) <= IMP_COMM_UNIQUE_ID_BYTES, "unique id does not fit");
+
+int imp_comm_unique_id(void *id_out) {
+  return guarded([&] {
+    ncclUniqueId id;
+    IMP_CHECK_NCCL(ncclGetUniqueId(&id));
+    std::memset(id_out, 0, IMP_COMM_UNIQUE_ID_BYTES);
+    std::memcpy(id_out, &id, sizeof(id));
+  });
+}
+
+int imp_comm_init_rank(const void *id_bytes, int nranks, int rank, imp_comm **out) {
+  return guarded([&] {
+    if (nranks < 1 || rank < 0 || rank >= nranks) throw std::invalid_argument("invalid rank / nranks for imp_comm_init_rank");
+    (void)ctx();
+    auto c = std::make_unique<imp_comm>();
+    c->nranks = nranks;
+    c->rank = rank;
+    ncclUniqueId id;
+    std::memcpy(&id, id_bytes, sizeof(id));
+    IMP_CHECK_NCCL(ncclCommInitRank(&c->comm, nranks, id, rank));
+    *out = c.release();
+  });
+}
+
+int imp_comm_destroy(imp_comm *c) {
+  return guarded([&] {
+    if (c && c->comm) (void)ncclCommDestroy(c->comm);
+    delete c;
+  });
+}
+
+int imp_comm_allreduce_sum(imp_comm *c, imp_matrix *m) {
+  return guarded([&] {
+    if (m->itemsize != 4) throw std::invalid_argument("allreduce_sum needs a float32 matrix");
+    IMP_PROF("rccl_allreduce");
+    IMP_CHECK_NCCL(ncclAllReduce(m->data, m->data, m->rows * m->cols, ncclFloat, ncclSum, c->comm, stream()));
+    sync();
+  });
+}
+
+int imp_comm_allgather_rows(imp_comm *c, imp_matrix *full, const int64_t *row_offsets) {
+  return guarded([&] {
+    if (row_offsets[0] != 0 || (size_t)row_offsets[c->nranks] != full->rows)
+      throw std::invalid_argument("row_offsets must span [0, rows] for allgather_rows");
+    IMP_PROF("rccl_allgather_rows");
+    // shards may be ragged: grouped broadcasts, one per owning rank (RCCL fuses the group)
+    const size_t row_bytes = full->cols * full->itemsize;
+    IMP_CHECK_NCCL(ncclGroupStart());
+    for (int r = 0; r < c->nranks; ++r) {
+      size_t bytes = (size_t)(row_offsets[r + 1] - row_offsets[r]) * row_bytes;
+      if (!bytes) continue;
+      char *p = reinterpret_cast<char *>(full->data) + (size_t)row_offsets[r] * row_bytes;
+      IMP_CHECK_NCCL(ncclBroadcast(p, p, bytes, ncclChar, r, c->comm, stream()));
+    }
+    IMP_CHECK_NCCL(ncclGroupEnd());
+    sync();
+  });
+}
+
+int imp_comm_barrier(imp_comm *c) {
+  return guarded([&] {
+    static float *dummy = nullptr;
+    if (!dummy) IMP_CHECK_HIP(hipMalloc(&dummy, sizeof(float)));
+    IMP_CHECK_NCCL(ncclAllReduce(dummy, dummy, 1, ncclFloat, ncclSum, c->comm, stream()));
+    sync();
+  });
+}
+
+}  // extern "C"

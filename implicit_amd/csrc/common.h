@@ -1,0 +1,140 @@
+// Internal shared declarations for libimplicit_hip.so (not part of the C-ABI).
+#ifndef IMPLICIT_AMD_CSRC_COMMON_H_
+#define IMPLICIT_AMD_CSRC_COMMON_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/implicit_hip.h"
+
+namespace imp {
+
+// ---- error plumbing: C++ exceptions inside, status codes at the extern "C" edge -------------
+struct out_of_range_error : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+void set_last_error(const std::string &msg);
+
+#define IMP_CHECK_HIP(expr)                                                                    \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) {                                                                    \
+      throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e) + " (" +    \
+                               __FILE__ + ":" + std::to_string(__LINE__) + ")");             \
+    }                                                                                          \
+  } while (0)
+
+// wraps the body of every extern "C" function
+template <typename F> int guarded(F &&body) {
+  try {
+    body();
+    return IMP_OK;
+  } catch (const std::invalid_argument &e) {
+    set_last_error(e.what());
+    return IMP_INVALID_ARGUMENT;
+  } catch (const out_of_range_error &e) {
+    set_last_error(e.what());
+    return IMP_OUT_OF_RANGE;
+  } catch (const std::exception &e) {
+    set_last_error(e.what());
+    return IMP_RUNTIME_ERROR;
+  } catch (...) {
+    set_last_error("unknown error");
+    return IMP_RUNTIME_ERROR;
+  }
+}
+
+// ---- per-device context: one stream, lazily created --------------------------------------------
+struct Context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int num_cus = 256;
+};
+Context &ctx();  // context of the current device
+inline hipStream_t stream() { return ctx().stream; }
+void sync();  // hipStreamSynchronize on the library stream
+
+// ---- launch-time profiler (HIP events on the library stream) ------------------------------------
+struct ProfScope {
+  explicit ProfScope(const char *name);
+  ~ProfScope();
+  const char *name;
+  hipEvent_t start = nullptr, stop = nullptr;
+};
+bool prof_enabled();
+#define IMP_PROF(name) ::imp::ProfScope _prof_scope_(name)
+
+// ---- device storage ---------------------------------------------------------------------------
+struct Storage {
+  void *ptr = nullptr;
+  size_t bytes = 0;
+  bool owned = true;
+  Storage(size_t bytes_, bool zero);
+  Storage(void *foreign) : ptr(foreign), owned(false) {}
+  ~Storage();
+  Storage(const Storage &) = delete;
+  Storage &operator=(const Storage &) = delete;
+};
+
+template <typename T> struct DeviceArray {
+  std::shared_ptr<Storage> storage;
+  size_t size = 0;
+  T *data() const { return storage ? reinterpret_cast<T *>(storage->ptr) : nullptr; }
+  void alloc(size_t n, bool zero = false) {
+    storage = std::make_shared<Storage>(n * sizeof(T), zero);
+    size = n;
+  }
+  void upload(const T *host, size_t n) {
+    alloc(n);
+    if (n) IMP_CHECK_HIP(hipMemcpyAsync(data(), host, n * sizeof(T), hipMemcpyHostToDevice, stream()));
+  }
+};
+
+}  // namespace imp
+
+// ---- handle definitions (opaque in the public header) -------------------------------------------
+struct imp_matrix {
+  size_t rows = 0, cols = 0, itemsize = 4;
+  void *data = nullptr;  // may point inside storage (views)
+  std::shared_ptr<imp::Storage> storage;
+  size_t bytes() const { return rows * cols * itemsize; }
+  float *f32() const {
+    if (itemsize != 4) throw std::runtime_error("can't cast Matrix to float*");
+    return reinterpret_cast<float *>(data);
+  }
+};
+
+struct imp_intvector {
+  imp::DeviceArray<int32_t> v;
+  size_t size = 0;
+};
+
+// Rows are scheduled in length classes so that a wavefront, a workgroup or several workgroups
+// cooperate on one row depending on its nnz (SURVEY section 7 "load imbalance").
+struct imp_csr {
+  int32_t rows = 0, cols = 0;
+  int64_t nnz = 0;
+  imp::DeviceArray<int32_t> indptr, indices;
+  imp::DeviceArray<float> data;
+  // row ids sorted by descending length; bin b covers order[bin_start[b] .. bin_start[b+1])
+  imp::DeviceArray<int32_t> order;
+  static constexpr int kBins = 3;  // 0: empty rows, 1: wave-per-row, 2: workgroup-per-row
+  int32_t bin_start[kBins + 1] = {0, 0, 0, 0};
+  int32_t max_row = 0;
+};
+
+struct imp_coo {
+  int32_t rows = 0, cols = 0;
+  int64_t nnz = 0;
+  imp::DeviceArray<int32_t> row, col;
+  imp::DeviceArray<float> data;
+};
+
+#endif  // IMPLICIT_AMD_CSRC_COMMON_H_

@@ -1,0 +1,515 @@
+// Device containers behind the C-ABI: Matrix / Vector<int> / CSRMatrix / COOMatrix, the library
+// context (one HIP stream per device), error state and the launch profiler.
+//
+// Replaces implicit/gpu/matrix.cu (reference) -- plain hipMalloc-backed storage instead of RMM
+// buffers and managed memory; the Thrust lambdas (copy_rowids, assign_rows, convert_array) and
+// calculate_norms_kernel become the small wave64 kernels below.
+#include <hip/hip_fp16.h>
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <mutex>
+
+#include "common.h"
+
+namespace imp {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string &msg) { g_last_error = msg; }
+
+static std::mutex g_ctx_mutex;
+static std::map<int, Context> g_contexts;
+
+Context &ctx() {
+  int dev = 0;
+  IMP_CHECK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_ctx_mutex);
+  auto it = g_contexts.find(dev);
+  if (it == g_contexts.end()) {
+    Context c;
+    c.device = dev;
+    IMP_CHECK_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    hipDeviceProp_t prop;
+    IMP_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+    c.num_cus = prop.multiProcessorCount;
+    it = g_contexts.emplace(dev, c).first;
+  }
+  return it->second;
+}
+
+void sync() { IMP_CHECK_HIP(hipStreamSynchronize(stream())); }
+
+// ---- profiler -----------------------------------------------------------------------------------
+struct ProfEntry {
+  double total_ms = 0;
+  int64_t launches = 0;
+};
+struct ProfPending {
+  const char *name;
+  hipEvent_t start, stop;
+};
+static bool g_prof_on = false;
+static std::map<std::string, ProfEntry> g_prof;
+static std::vector<ProfPending> g_prof_pending;
+static std::vector<hipEvent_t> g_event_pool;
+
+bool prof_enabled() { return g_prof_on; }
+
+static hipEvent_t get_event() {
+  if (!g_event_pool.empty()) {
+    hipEvent_t e = g_event_pool.back();
+    g_event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  IMP_CHECK_HIP(hipEventCreate(&e));
+  return e;
+}
+
+ProfScope::ProfScope(const char *n) : name(n) {
+  if (!g_prof_on) return;
+  start = get_event();
+  stop = get_event();
+  IMP_CHECK_HIP(hipEventRecord(start, stream()));
+}
+
+ProfScope::~ProfScope() {
+  if (!start) return;
+  (void)hipEventRecord(stop, stream());
+  g_prof_pending.push_back({name, start, stop});
+}
+
+static void prof_flush() {
+  if (g_prof_pending.empty()) return;
+  sync();
+  for (auto &p : g_prof_pending) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
+      auto &e = g_prof[p.name];
+      e.total_ms += ms;
+      e.launches += 1;
+    }
+    g_event_pool.push_back(p.start);
+    g_event_pool.push_back(p.stop);
+  }
+  g_prof_pending.clear();
+}
+
+// ---- storage ------------------------------------------------------------------------------------
+Storage::Storage(size_t bytes_, bool zero) : bytes(bytes_) {
+  if (bytes) {
+    IMP_CHECK_HIP(hipMalloc(&ptr, bytes));
+    if (zero) IMP_CHECK_HIP(hipMemsetAsync(ptr, 0, bytes, stream()));
+  }
+}
+Storage::~Storage() {
+  if (owned && ptr) (void)hipFree(ptr);
+}
+
+// ---- small kernels ------------------------------------------------------------------------------
+template <typename T>
+__global__ void gather_rows_kernel(const T *__restrict__ src, const int32_t *__restrict__ rowids,
+                                   T *__restrict__ dst, size_t nrows, size_t cols) {
+  size_t total = nrows * cols;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    size_t r = i / cols, c = i - r * cols;
+    dst[i] = src[(size_t)rowids[r] * cols + c];
+  }
+}
+
+__global__ void scatter_rows_kernel(float *__restrict__ dst, const int32_t *__restrict__ rowids,
+                                    const float *__restrict__ src, size_t nrows, size_t cols) {
+  size_t total = nrows * cols;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    size_t r = i / cols, c = i - r * cols;
+    dst[(size_t)rowids[r] * cols + c] = src[i];
+  }
+}
+
+__global__ void cast_f32_f16_kernel(const float *__restrict__ src, __half *__restrict__ dst, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = __float2half(src[i]);
+}
+__global__ void cast_f16_f32_kernel(const __half *__restrict__ src, float *__restrict__ dst, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = __half2float(src[i]);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// one wavefront per row: coalesced strided read, butterfly sum, zero norms -> 1e-10
+// (matrix.cu:173-188; CPU semantics cpu/matrix_factorization_base.py:233-247)
+template <typename T>
+__global__ void row_norms_kernel(const T *__restrict__ data, float *__restrict__ out, size_t rows, size_t cols) {
+  size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+  size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+  int lane = threadIdx.x & 63;
+  for (size_t r = wave; r < rows; r += nwaves) {
+    float s = 0.f;
+    for (size_t c = lane; c < cols; c += 64) {
+      float v = (float)data[r * cols + c];
+      s += v * v;
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+      float n = sqrtf(s);
+      out[r] = n == 0.f ? 1e-10f : n;
+    }
+  }
+}
+
+static int grid_for(size_t work_items, int block = 256) {
+  size_t blocks = (work_items + block - 1) / block;
+  size_t cap = (size_t)ctx().num_cus * 8;
+  return (int)std::max<size_t>(1, std::min(blocks, cap));
+}
+
+static imp_matrix *new_matrix(size_t rows, size_t cols, size_t itemsize, bool zero) {
+  if (itemsize != 4 && itemsize != 2) throw std::invalid_argument("invalid itemsize for Matrix (must be 2 or 4)");
+  auto m = std::make_unique<imp_matrix>();
+  m->rows = rows;
+  m->cols = cols;
+  m->itemsize = itemsize;
+  m->storage = std::make_shared<Storage>(rows * cols * itemsize, zero);
+  m->data = m->storage->ptr;
+  return m.release();
+}
+
+}  // namespace imp
+
+using namespace imp;
+
+// make the helper visible to the other translation units
+imp_matrix *imp_internal_new_matrix(size_t rows, size_t cols, size_t itemsize, bool zero) {
+  return new_matrix(rows, cols, itemsize, zero);
+}
+
+extern "C" {
+
+const char *imp_last_error(void) { return g_last_error.c_str(); }
+
+const char *imp_version(void) { return "implicit_hip 0.1 (gfx950)"; }
+
+int imp_get_device_count(int *count) {
+  return guarded([&] {
+    int c = 0;
+    IMP_CHECK_HIP(hipGetDeviceCount(&c));
+    if (c <= 0) throw std::runtime_error("no HIP device available");
+    *count = c;
+  });
+}
+
+int imp_set_device(int device) {
+  return guarded([&] { IMP_CHECK_HIP(hipSetDevice(device)); });
+}
+int imp_get_device(int *device) {
+  return guarded([&] { IMP_CHECK_HIP(hipGetDevice(device)); });
+}
+int imp_device_synchronize(void) {
+  return guarded([&] {
+    sync();
+    IMP_CHECK_HIP(hipDeviceSynchronize());
+  });
+}
+int imp_mem_get_info(size_t *free_bytes, size_t *total_bytes) {
+  return guarded([&] { IMP_CHECK_HIP(hipMemGetInfo(free_bytes, total_bytes)); });
+}
+
+// ---- Matrix -------------------------------------------------------------------------------------
+int imp_matrix_create(size_t rows, size_t cols, const void *host_data, size_t itemsize, imp_matrix **out) {
+  return guarded([&] {
+    imp_matrix *m = new_matrix(rows, cols, itemsize, host_data == nullptr);
+    std::unique_ptr<imp_matrix> guard(m);
+    if (host_data && m->bytes()) {
+      IMP_CHECK_HIP(hipMemcpyAsync(m->data, host_data, m->bytes(), hipMemcpyHostToDevice, stream()));
+    }
+    sync();
+    *out = guard.release();
+  });
+}
+
+int imp_matrix_wrap_device(size_t rows, size_t cols, void *device_ptr, size_t itemsize, imp_matrix **out) {
+  return guarded([&] {
+    if (itemsize != 4 && itemsize != 2) throw std::invalid_argument("invalid itemsize for Matrix (must be 2 or 4)");
+    auto m = std::make_unique<imp_matrix>();
+    m->rows = rows;
+    m->cols = cols;
+    m->itemsize = itemsize;
+    m->storage = std::make_shared<Storage>(device_ptr);
+    m->data = device_ptr;
+    *out = m.release();
+  });
+}
+
+int imp_matrix_row(const imp_matrix *src, size_t rowid, imp_matrix **out) {
+  return guarded([&] {
+    if (rowid >= src->rows) throw std::invalid_argument("row index out of bounds for matrix");
+    auto m = std::make_unique<imp_matrix>(*src);
+    m->rows = 1;
+    m->data = reinterpret_cast<char *>(src->data) + rowid * src->cols * src->itemsize;
+    *out = m.release();
+  });
+}
+
+int imp_matrix_slice(const imp_matrix *src, size_t start, size_t end, imp_matrix **out) {
+  return guarded([&] {
+    if (end < start) throw std::invalid_argument("end_rowid < start_rowid for matrix slice");
+    if (end > src->rows) throw std::invalid_argument("row index out of bounds for matrix");
+    auto m = std::make_unique<imp_matrix>(*src);
+    m->rows = end - start;
+    m->data = reinterpret_cast<char *>(src->data) + start * src->cols * src->itemsize;
+    *out = m.release();
+  });
+}
+
+int imp_matrix_gather(const imp_matrix *src, const imp_intvector *rowids, imp_matrix **out) {
+  return guarded([&] {
+    std::unique_ptr<imp_matrix> m(new_matrix(rowids->size, src->cols, src->itemsize, false));
+    size_t total = m->rows * m->cols;
+    if (total) {
+      IMP_PROF("gather_rows");
+      if (src->itemsize == 4)
+        gather_rows_kernel<float><<<grid_for(total), 256, 0, stream()>>>(
+            (const float *)src->data, rowids->v.data(), (float *)m->data, m->rows, m->cols);
+      else
+        gather_rows_kernel<__half><<<grid_for(total), 256, 0, stream()>>>(
+            (const __half *)src->data, rowids->v.data(), (__half *)m->data, m->rows, m->cols);
+      IMP_CHECK_HIP(hipGetLastError());
+    }
+    sync();
+    *out = m.release();
+  });
+}
+
+int imp_matrix_resize(imp_matrix *m, size_t rows, size_t cols) {
+  return guarded([&] {
+    if (cols != m->cols) throw std::logic_error("changing number of columns in Matrix::resize is not implemented yet");
+    if (rows < m->rows) throw std::logic_error("reducing number of rows in Matrix::resize is not implemented yet");
+    auto storage = std::make_shared<Storage>(rows * cols * m->itemsize, true);
+    if (m->bytes()) IMP_CHECK_HIP(hipMemcpyAsync(storage->ptr, m->data, m->bytes(), hipMemcpyDeviceToDevice, stream()));
+    sync();
+    m->storage = storage;
+    m->data = storage->ptr;
+    m->rows = rows;
+  });
+}
+
+int imp_matrix_assign_rows(imp_matrix *m, const imp_intvector *rowids, const imp_matrix *other) {
+  return guarded([&] {
+    if (other->cols != m->cols) throw std::invalid_argument("column dimension mismatch for Matrix::assign_rows");
+    if (other->rows != rowids->size) throw std::invalid_argument("row dimension mismatch for Matrix::assign_rows");
+    float *dst = m->f32();
+    const float *src = other->f32();
+    size_t total = other->rows * other->cols;
+    if (total) {
+      IMP_PROF("scatter_rows");
+      scatter_rows_kernel<<<grid_for(total), 256, 0, stream()>>>(dst, rowids->v.data(), src, other->rows, other->cols);
+      IMP_CHECK_HIP(hipGetLastError());
+    }
+    sync();
+  });
+}
+
+int imp_matrix_astype(const imp_matrix *src, size_t itemsize, imp_matrix **out) {
+  return guarded([&] {
+    std::unique_ptr<imp_matrix> m(new_matrix(src->rows, src->cols, itemsize, false));
+    size_t n = src->rows * src->cols;
+    if (n) {
+      if (itemsize == src->itemsize) {
+        IMP_CHECK_HIP(hipMemcpyAsync(m->data, src->data, src->bytes(), hipMemcpyDeviceToDevice, stream()));
+      } else if (itemsize == 2) {
+        IMP_PROF("cast_f32_f16");
+        cast_f32_f16_kernel<<<grid_for(n), 256, 0, stream()>>>((const float *)src->data, (__half *)m->data, n);
+      } else {
+        IMP_PROF("cast_f16_f32");
+        cast_f16_f32_kernel<<<grid_for(n), 256, 0, stream()>>>((const __half *)src->data, (float *)m->data, n);
+      }
+      IMP_CHECK_HIP(hipGetLastError());
+    }
+    sync();
+    *out = m.release();
+  });
+}
+
+int imp_matrix_calculate_norms(const imp_matrix *src, imp_matrix **out) {
+  return guarded([&] {
+    std::unique_ptr<imp_matrix> m(new_matrix(1, src->rows, 4, false));
+    if (src->rows) {
+      IMP_PROF("row_norms");
+      int grid = grid_for(src->rows * 64);
+      if (src->itemsize == 4)
+        row_norms_kernel<float><<<grid, 256, 0, stream()>>>((const float *)src->data, (float *)m->data, src->rows, src->cols);
+      else
+        row_norms_kernel<__half><<<grid, 256, 0, stream()>>>((const __half *)src->data, (float *)m->data, src->rows, src->cols);
+      IMP_CHECK_HIP(hipGetLastError());
+    }
+    sync();
+    *out = m.release();
+  });
+}
+
+int imp_matrix_to_host(const imp_matrix *m, void *host_out) {
+  return guarded([&] {
+    if (m->bytes()) IMP_CHECK_HIP(hipMemcpyAsync(host_out, m->data, m->bytes(), hipMemcpyDeviceToHost, stream()));
+    sync();
+  });
+}
+
+int imp_matrix_from_host(imp_matrix *m, const void *host_in) {
+  return guarded([&] {
+    if (m->bytes()) IMP_CHECK_HIP(hipMemcpyAsync(m->data, host_in, m->bytes(), hipMemcpyHostToDevice, stream()));
+    sync();
+  });
+}
+
+int imp_matrix_shape(const imp_matrix *m, size_t *rows, size_t *cols, size_t *itemsize) {
+  return guarded([&] {
+    if (rows) *rows = m->rows;
+    if (cols) *cols = m->cols;
+    if (itemsize) *itemsize = m->itemsize;
+  });
+}
+
+int imp_matrix_device_ptr(const imp_matrix *m, void **ptr) {
+  return guarded([&] { *ptr = m->data; });
+}
+
+int imp_matrix_destroy(imp_matrix *m) {
+  return guarded([&] { delete m; });
+}
+
+// ---- Vector<int> --------------------------------------------------------------------------------
+int imp_intvector_create(const int32_t *host_data, size_t size, imp_intvector **out) {
+  return guarded([&] {
+    auto v = std::make_unique<imp_intvector>();
+    v->size = size;
+    v->v.upload(host_data, size);
+    sync();
+    *out = v.release();
+  });
+}
+int imp_intvector_destroy(imp_intvector *v) {
+  return guarded([&] { delete v; });
+}
+
+// ---- CSR / COO -----------------------------------------------------------------------------------
+int imp_csr_create(int32_t rows, int32_t cols, int64_t nnz, const int32_t *indptr, const int32_t *indices,
+                   const float *data, imp_csr **out) {
+  return guarded([&] {
+    if (rows < 0 || cols < 0 || nnz < 0) throw std::invalid_argument("negative dimension for CSRMatrix");
+    if (nnz > INT32_MAX) throw std::invalid_argument("CSRMatrix with more than 2^31-1 nonzeros is not supported");
+    if (rows && indptr[rows] != nnz) throw std::invalid_argument("indptr[rows] != nonzeros for CSRMatrix");
+    auto m = std::make_unique<imp_csr>();
+    m->rows = rows;
+    m->cols = cols;
+    m->nnz = nnz;
+    m->indptr.upload(indptr, (size_t)rows + 1);
+    m->indices.upload(indices, (size_t)nnz);
+    m->data.upload(data, (size_t)nnz);
+
+    // Row schedule: counting sort of row ids by descending length, cut into length classes.
+    int32_t wave_max = 256;
+    if (const char *e = getenv("IMP_WAVE_ROW_MAX")) wave_max = std::max(1, atoi(e));
+    int32_t max_len = 0;
+    for (int32_t r = 0; r < rows; ++r) max_len = std::max(max_len, indptr[r + 1] - indptr[r]);
+    m->max_row = max_len;
+    std::vector<int32_t> count((size_t)max_len + 2, 0);
+    for (int32_t r = 0; r < rows; ++r) count[indptr[r + 1] - indptr[r]]++;
+    // start offset of each length in descending order
+    std::vector<int32_t> start((size_t)max_len + 2, 0);
+    int32_t acc = 0, n_long = 0, n_wave = 0;
+    for (int32_t len = max_len; len >= 0; --len) {
+      start[len] = acc;
+      acc += count[len];
+      if (len > wave_max) n_long += count[len];
+      else if (len > 0) n_wave += count[len];
+    }
+    std::vector<int32_t> order((size_t)rows);
+    for (int32_t r = 0; r < rows; ++r) order[start[indptr[r + 1] - indptr[r]]++] = r;
+    m->order.upload(order.data(), order.size());
+    m->bin_start[0] = 0;               // [0, n_long): workgroup-per-row
+    m->bin_start[1] = n_long;          // [n_long, n_long + n_wave): wave-per-row
+    m->bin_start[2] = n_long + n_wave; // [.., rows): empty rows
+    m->bin_start[3] = rows;
+    sync();
+    *out = m.release();
+  });
+}
+
+int imp_csr_shape(const imp_csr *m, int32_t *rows, int32_t *cols, int64_t *nonzeros) {
+  return guarded([&] {
+    if (rows) *rows = m->rows;
+    if (cols) *cols = m->cols;
+    if (nonzeros) *nonzeros = m->nnz;
+  });
+}
+
+int imp_csr_destroy(imp_csr *m) {
+  return guarded([&] { delete m; });
+}
+
+int imp_coo_create(int32_t rows, int32_t cols, int64_t nnz, const int32_t *row, const int32_t *col,
+                   const float *data, imp_coo **out) {
+  return guarded([&] {
+    if (rows < 0 || cols < 0 || nnz < 0) throw std::invalid_argument("negative dimension for COOMatrix");
+    auto m = std::make_unique<imp_coo>();
+    m->rows = rows;
+    m->cols = cols;
+    m->nnz = nnz;
+    m->row.upload(row, (size_t)nnz);
+    m->col.upload(col, (size_t)nnz);
+    if (data) m->data.upload(data, (size_t)nnz);
+    sync();
+    *out = m.release();
+  });
+}
+
+int imp_coo_destroy(imp_coo *m) {
+  return guarded([&] { delete m; });
+}
+
+// ---- profiler -------------------------------------------------------------------------------------
+int imp_prof_enable(int on) {
+  return guarded([&] {
+    prof_flush();
+    g_prof_on = on != 0;
+  });
+}
+int imp_prof_reset(void) {
+  return guarded([&] {
+    prof_flush();
+    g_prof.clear();
+  });
+}
+int imp_prof_get(const char *kernel, double *total_ms, int64_t *launches) {
+  return guarded([&] {
+    prof_flush();
+    auto it = g_prof.find(kernel);
+    if (total_ms) *total_ms = it == g_prof.end() ? 0.0 : it->second.total_ms;
+    if (launches) *launches = it == g_prof.end() ? 0 : it->second.launches;
+  });
+}
+int imp_prof_names(char *buf, size_t buflen) {
+  return guarded([&] {
+    prof_flush();
+    std::string s;
+    for (auto &kv : g_prof) {
+      if (!s.empty()) s += "\n";
+      s += kv.first;
+    }
+    if (buflen) {
+      size_t n = std::min(buflen - 1, s.size());
+      memcpy(buf, s.data(), n);
+      buf[n] = 0;
+    }
+  });
+}
+
+}  // extern "C"

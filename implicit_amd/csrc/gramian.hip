@@ -1,0 +1,123 @@
+// K3: gramian  YtY = Y^T Y + reg * I   (f x f fp32, Y is N x f row-major fp32)
+//
+// Replaces LeastSquaresSolver::calculate_yty (implicit/gpu/als.cu:122-152: cublasSgemm + the
+// l2_regularize_kernel); oracle: np.dot(Y.T, Y) at implicit/cpu/_als.pyx:70,164.
+//
+// MFMA-bound (2 N f^2 flop over 4 N f bytes).  Uses the exact-fp32 matrix instruction
+// v_mfma_f32_32x32x2_f32: for a pair of rows (k = 2) lane l feeds A[i][k] = Y[r0+k][32 ti + i] and
+// B[k][j] = Y[r0+k][32 tj + j] straight from global memory (both operands are 128-byte coalesced
+// segments of the same two rows -- no LDS staging needed), accumulating a 32x32 tile of Y^T Y.
+// The row range is split over grid.x (split-K); partial tiles go to a workspace and a second
+// kernel sums them in a FIXED order and adds reg on the diagonal, so the result is deterministic.
+#include "common.h"
+
+namespace imp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// TJ = number of 32-wide column tiles this block covers (<= 8); tile rows: one per wave.
+template <int TJ>
+__global__ __launch_bounds__(256) void gramian_partial_kernel(const float *__restrict__ Y, long n_rows, int f,
+                                                              long rows_per_chunk, float *__restrict__ ws) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int ti = blockIdx.y * 4 + wave;       // tile row of this wave
+  const int tj0 = blockIdx.z * 8;             // first tile column of this block
+  const int n_tiles = (f + 31) / 32;
+  const int i_col = 32 * ti + (lane & 31);
+  const int khalf = lane >> 5;
+  const long r_begin = (long)blockIdx.x * rows_per_chunk;
+  const long r_end = min(n_rows, r_begin + rows_per_chunk);
+
+  f32x16 acc[TJ];
+#pragma unroll
+  for (int t = 0; t < TJ; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  if (ti < n_tiles) {
+    const bool a_ok = i_col < f;
+    for (long r0 = r_begin; r0 < r_end; r0 += 8) {
+      // 4 k-steps (8 rows) per trip so that 4*(1+TJ) loads are in flight
+      float a[4], b[4][TJ];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        long r = r0 + 2 * s + khalf;
+        bool r_ok = r < r_end;
+        const float *row = Y + r * (long)f;
+        a[s] = (r_ok && a_ok) ? row[i_col] : 0.f;
+#pragma unroll
+        for (int t = 0; t < TJ; ++t) {
+          int c = 32 * (tj0 + t) + (lane & 31);
+          b[s][t] = (r_ok && c < f) ? row[c] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int t = 0; t < TJ; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s][t], acc[t], 0, 0, 0);
+    }
+    // C/D layout of the 32x32 tile: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+    float *out = ws + (size_t)blockIdx.x * f * f;
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) {
+      int c = 32 * (tj0 + t) + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        int rr = 32 * ti + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (rr < f && c < f) out[(size_t)rr * f + c] = acc[t][e];
+      }
+    }
+  }
+}
+
+__global__ void gramian_reduce_kernel(const float *__restrict__ ws, int chunks, int f, float reg, float *__restrict__ out) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= f * f) return;
+  float s = 0.f;
+  for (int c = 0; c < chunks; ++c) s += ws[(size_t)c * f * f + idx];
+  int r = idx / f, col = idx - r * f;
+  if (r == col) s += reg;
+  out[idx] = s;
+}
+
+struct GramWorkspace {
+  DeviceArray<float> ws;
+};
+static GramWorkspace &g_ws = *new GramWorkspace;  // leaked on purpose: no hipFree after runtime teardown
+
+// out (f x f) = Y^T Y + reg I over rows [0, n_rows) of Y
+void gramian(const float *Y, long n_rows, int f, float reg, float *out) {
+  const int n_tiles = (f + 31) / 32;
+  const int gy = (n_tiles + 3) / 4, gz = (n_tiles + 7) / 8;
+  long target_chunks = std::max(1, ctx().num_cus * 2 / (gy * gz));
+  long rows_per_chunk = std::max<long>(256, (n_rows + target_chunks - 1) / target_chunks);
+  rows_per_chunk = (rows_per_chunk + 7) / 8 * 8;
+  int chunks = (int)std::max<long>(1, (n_rows + rows_per_chunk - 1) / rows_per_chunk);
+  size_t need = (size_t)chunks * f * f;
+  if (g_ws.ws.size < need) g_ws.ws.alloc(need);
+  dim3 grid(chunks, gy, gz);
+  {
+    IMP_PROF("gramian_partial");
+    int tj = std::min(n_tiles, 8);
+    float *ws = g_ws.ws.data();
+    switch (tj) {
+      case 1: gramian_partial_kernel<1><<<grid, 256, 0, stream()>>>(Y, n_rows, f, rows_per_chunk, ws); break;
+      case 2: gramian_partial_kernel<2><<<grid, 256, 0, stream()>>>(Y, n_rows, f, rows_per_chunk, ws); break;
+      case 3: gramian_partial_kernel<3><<<grid, 256, 0, stream()>>>(Y, n_rows, f, rows_per_chunk, ws); break;
+      case 4: gramian_partial_kernel<4><<<grid, 256, 0, stream()>>>(Y, n_rows, f, rows_per_chunk, ws); break;
+      case 5: gramian_partial_kernel<5><<<grid, 256, 0, stream()>>>(Y, n_rows, f, rows_per_chunk, ws); break;
+      case 6: gramian_partial_kernel<6><<<grid, 256, 0, stream()>>>(Y, n_rows, f, rows_per_chunk, ws); break;
+      case 7: gramian_partial_kernel<7><<<grid, 256, 0, stream()>>>(Y, n_rows, f, rows_per_chunk, ws); break;
+      default: gramian_partial_kernel<8><<<grid, 256, 0, stream()>>>(Y, n_rows, f, rows_per_chunk, ws); break;
+    }
+    IMP_CHECK_HIP(hipGetLastError());
+  }
+  {
+    IMP_PROF("gramian_reduce");
+    gramian_reduce_kernel<<<(f * f + 255) / 256, 256, 0, stream()>>>(g_ws.ws.data(), chunks, f, reg, out);
+    IMP_CHECK_HIP(hipGetLastError());
+  }
+}
+
+}  // namespace imp

@@ -1,0 +1,327 @@
+// K4: top-k dot-product scorer behind recommend() / similar_items() / similar_users().
+//
+// Replaces KnnQuery::topk (implicit/gpu/knn.cu:77-265: cuBLAS GEMM + three Thrust passes + RAFT
+// select_k).  Semantics follow the CPU oracle implicit/cpu/topk.pyx:15-67 + select.h:12-40:
+//   scores = query . items^T (exact fp32), optional divide by item_norms, per-query (COO) and global
+//   item filters set to -FLT_MAX, then the k best per row, written best-first.
+// Tie rule: total order (score desc, column desc) -- identical to the oracle's output order and to
+// its retained set whenever there is no exact tie straddling the k-th score.
+//
+// Stage 1  score_gemm_kernel : fp32 MFMA (v_mfma_f32_32x32x2_f32), LDS-staged K-tiles of both operands
+//          with odd row stride (conflict-free fragment reads), norm divide fused in the epilogue.
+// Stage 2  filters (tiny scatter kernels).
+// Stage 3  select_kernel : one workgroup per query row, MSB-first 8-bit radix select on the 64-bit key
+//          (ordered(score) << 32 | column) with early exit once the boundary bucket is taken whole,
+//          then a gather of the k winners and an in-LDS bitonic sort.
+#include <cfloat>
+
+#include "common.h"
+
+namespace imp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kBM = 64;   // queries per block tile
+constexpr int kBN = 128;  // items per block tile
+constexpr int kBK = 64;   // factors per K step
+constexpr int kLd = kBK + 1;
+
+// scores[q][i] = sum_k Q[q][k] * I[i][k]   (optionally / norms[i])
+__global__ __launch_bounds__(256) void score_gemm_kernel(const float *__restrict__ Q, int nq, const float *__restrict__ I,
+                                                         int ni, int f, const float *__restrict__ norms,
+                                                         float *__restrict__ S) {
+  __shared__ float Qs[kBM * kLd];
+  __shared__ float Is[kBN * kLd];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q0 = blockIdx.y * kBM, i0 = blockIdx.x * kBN;
+  f32x16 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  for (int k0 = 0; k0 < f; k0 += kBK) {
+    // stage: consecutive threads walk the factor dimension -> coalesced global reads
+    for (int e = tid; e < kBM * kBK; e += 256) {
+      int r = e / kBK, c = e - r * kBK;
+      int q = q0 + r, k = k0 + c;
+      Qs[r * kLd + c] = (q < nq && k < f) ? Q[(size_t)q * f + k] : 0.f;
+    }
+    for (int e = tid; e < kBN * kBK; e += 256) {
+      int r = e / kBK, c = e - r * kBK;
+      int i = i0 + r, k = k0 + c;
+      Is[r * kLd + c] = (i < ni && k < f) ? I[(size_t)i * f + k] : 0.f;
+    }
+    __syncthreads();
+    // wave w: queries [0,64) x items [32w, 32w+32): two 32x32 tiles
+    const int kh = lane >> 5, l31 = lane & 31;
+#pragma unroll 8
+    for (int kk = 0; kk < kBK; kk += 2) {
+      float b = Is[(32 * wave + l31) * kLd + kk + kh];
+      float a0 = Qs[l31 * kLd + kk + kh];
+      float a1 = Qs[(32 + l31) * kLd + kk + kh];
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int item = i0 + 32 * wave + (lane & 31);
+  if (item < ni) {
+    float inv_valid = norms ? norms[item] : 1.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        int q = q0 + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (q < nq) {
+          float s = acc[t][e];
+          if (norms) s = s / inv_valid;
+          S[(size_t)q * ni + item] = s;
+        }
+      }
+  }
+}
+
+__global__ void item_filter_kernel(float *__restrict__ S, int rows, int ni, const int32_t *__restrict__ items, int n_items) {
+  size_t total = (size_t)rows * n_items;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int col = items[i % n_items];
+    size_t row = i / n_items;
+    if (col >= 0 && col < ni) S[row * ni + col] = -FLT_MAX;
+  }
+}
+
+__global__ void coo_filter_kernel(float *__restrict__ S, int start, int end, int ni, const int32_t *__restrict__ row,
+                                  const int32_t *__restrict__ col, size_t nnz) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nnz; i += (size_t)gridDim.x * blockDim.x) {
+    int r = row[i], c = col[i];
+    if (r >= start && r < end && c >= 0 && c < ni) S[(size_t)(r - start) * ni + c] = -FLT_MAX;
+  }
+}
+
+__device__ __forceinline__ uint32_t ordered(float s) {
+  uint32_t u = __float_as_uint(s);
+  return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float unordered(uint32_t u) {
+  return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+__device__ __forceinline__ uint64_t make_key(float s, int col) { return ((uint64_t)ordered(s) << 32) | (uint32_t)col; }
+
+// One workgroup per query row.  `cand` = k 64-bit slots (LDS when it fits, else global scratch).
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void select_kernel(const float *__restrict__ S, int ni, int k, int kpad,
+                                                       int32_t *__restrict__ out_ids, float *__restrict__ out_dist,
+                                                       int out_stride, uint64_t *__restrict__ global_cand, int use_lds) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __shared__ unsigned int hist[256];
+  __shared__ unsigned int sh_bucket, sh_remaining, sh_count;
+  uint64_t *cand = use_lds ? reinterpret_cast<uint64_t *>(smem_raw) : global_cand + (size_t)blockIdx.x * kpad;
+  const float *row = S + (size_t)blockIdx.x * ni;
+  const int tid = threadIdx.x;
+
+  uint64_t prefix = 0, mask = 0;
+  unsigned int remaining = k;  // k <= ni guaranteed by the host
+  for (int digit = 7; digit >= 0; --digit) {
+    const int shift = digit * 8;
+    for (int i = tid; i < 256; i += BLOCK) hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < ni; i += BLOCK) {
+      uint64_t key = make_key(row[i], i);
+      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 0xFF], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned int acc = 0;
+      int b = 255;
+      for (; b > 0; --b) {
+        if (acc + hist[b] >= remaining) break;
+        acc += hist[b];
+      }
+      sh_bucket = b;
+      sh_remaining = remaining - acc;
+      sh_count = hist[b];
+    }
+    __syncthreads();
+    prefix |= (uint64_t)sh_bucket << shift;
+    mask |= (uint64_t)0xFF << shift;
+    remaining = sh_remaining;
+    bool whole = sh_count == remaining;
+    __syncthreads();
+    if (whole) break;  // boundary bucket taken entirely: no finer digits needed
+  }
+
+  // gather the winners: (key & mask) >= prefix selects exactly k keys
+  if (tid == 0) sh_count = 0;
+  for (int i = tid; i < kpad; i += BLOCK) cand[i] = 0;  // pads sort last
+  __syncthreads();
+  for (int i = tid; i < ni; i += BLOCK) {
+    uint64_t key = make_key(row[i], i);
+    if ((key & mask) >= prefix) {
+      unsigned int slot = atomicAdd(&sh_count, 1u);
+      if (slot < (unsigned)kpad) cand[slot] = key;
+    }
+  }
+  __syncthreads();
+  // bitonic sort, descending
+  for (int size = 2; size <= kpad; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (kpad >> 1); t += BLOCK) {
+        int lo = 2 * t - (t & (stride - 1));
+        int hi = lo + stride;
+        bool desc = ((lo & size) == 0);
+        uint64_t a = cand[lo], b = cand[hi];
+        if ((a < b) == desc) {
+          cand[lo] = b;
+          cand[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < k; i += BLOCK) {
+    uint64_t key = cand[i];
+    out_ids[(size_t)blockIdx.x * out_stride + i] = (int32_t)(uint32_t)key;
+    out_dist[(size_t)blockIdx.x * out_stride + i] = unordered((uint32_t)(key >> 32));
+  }
+}
+
+static bool is_host_pointer(const void *p) {
+  hipPointerAttribute_t attr;
+  hipError_t err = hipPointerGetAttributes(&attr, p);
+  if (err != hipSuccess) {
+    (void)hipGetLastError();  // clear
+    return true;
+  }
+  return attr.type == hipMemoryTypeHost || attr.type == hipMemoryTypeUnregistered;
+}
+
+}  // namespace imp
+
+using namespace imp;
+
+extern "C" int imp_matrix_astype(const imp_matrix *src, size_t itemsize, imp_matrix **out);
+
+struct imp_knn {
+  size_t max_temp_memory = 0;
+};
+
+extern "C" {
+
+int imp_knn_create(size_t max_temp_memory, imp_knn **out) {
+  return guarded([&] {
+    (void)ctx();
+    if (!max_temp_memory) {
+      size_t free_b = 0, total_b = 0;
+      IMP_CHECK_HIP(hipMemGetInfo(&free_b, &total_b));
+      max_temp_memory = std::min<size_t>(free_b / 2, (size_t)4 << 30);
+    }
+    auto k = new imp_knn();
+    k->max_temp_memory = max_temp_memory;
+    *out = k;
+  });
+}
+
+int imp_knn_destroy(imp_knn *k) {
+  return guarded([&] { delete k; });
+}
+
+int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *query_in, int k, int32_t *indices, float *distances,
+                 const imp_matrix *item_norms, const imp_coo *query_filter, const imp_intvector *item_filter) {
+  return guarded([&] {
+    if (query_in->cols != items_in->cols) throw std::invalid_argument("Must have same number of columns in each matrix for topk");
+    if (query_in->itemsize != items_in->itemsize) throw std::invalid_argument("Must have same dtype in each matrix for topk");
+    if (k < 0) throw std::invalid_argument("k must be >= 0 for topk");
+    if (item_norms && (item_norms->itemsize != 4 || item_norms->rows * item_norms->cols != items_in->rows))
+      throw std::invalid_argument("item_norms must be a float32 matrix with one entry per item");
+    const size_t nq = query_in->rows, ni = items_in->rows;
+    const int f = (int)items_in->cols;
+    if (nq == 0 || k == 0) return;
+    if (ni > (size_t)INT32_MAX) throw std::invalid_argument("too many items for topk");
+
+    // fp16 factors: score in fp32 (reference: SgemmEx with fp32 accumulate, knn.cu:117-128)
+    std::unique_ptr<imp_matrix> items_conv, query_conv;
+    const imp_matrix *items = items_in, *query = query_in;
+    if (items_in->itemsize == 2) {
+      imp_matrix *t = nullptr;
+      if (imp_matrix_astype(items_in, 4, &t) != IMP_OK) throw std::runtime_error(imp_last_error());
+      items_conv.reset(t);
+      if (imp_matrix_astype(query_in, 4, &t) != IMP_OK) throw std::runtime_error(imp_last_error());
+      query_conv.reset(t);
+      items = items_conv.get();
+      query = query_conv.get();
+    }
+
+    const int k_eff = (int)std::min<size_t>((size_t)k, ni);
+    int kpad = 1;
+    while (kpad < k_eff) kpad <<= 1;
+    if (kpad < 2) kpad = 2;
+
+    const bool host_ids = is_host_pointer(indices), host_dist = is_host_pointer(distances);
+    DeviceArray<int32_t> dev_ids;
+    DeviceArray<float> dev_dist;
+    int32_t *d_ids = indices;
+    float *d_dist = distances;
+    if (host_ids) {
+      dev_ids.alloc(nq * (size_t)k);
+      d_ids = dev_ids.data();
+    }
+    if (host_dist) {
+      dev_dist.alloc(nq * (size_t)k);
+      d_dist = dev_dist.data();
+    }
+    if (k_eff < k) {
+      // entries past k_eff keep the caller's initial values (topk.pyx:20-21 zero-fills them)
+      if (host_ids) IMP_CHECK_HIP(hipMemcpyAsync(d_ids, indices, nq * (size_t)k * 4, hipMemcpyHostToDevice, stream()));
+      if (host_dist) IMP_CHECK_HIP(hipMemcpyAsync(d_dist, distances, nq * (size_t)k * 4, hipMemcpyHostToDevice, stream()));
+    }
+
+    size_t temp = std::min<size_t>(knn->max_temp_memory, (size_t)4 << 30);
+    size_t batch = std::max<size_t>(1, std::min<size_t>(nq, temp / (sizeof(float) * ni)));
+    DeviceArray<float> scores;
+    scores.alloc(batch * ni);
+    const bool use_lds = (size_t)kpad * 8 <= 96 * 1024;
+    DeviceArray<uint64_t> gcand;
+    if (!use_lds) gcand.alloc(batch * (size_t)kpad);
+
+    for (size_t start = 0; start < nq; start += batch) {
+      size_t end = std::min(nq, start + batch), rows = end - start;
+      {
+        IMP_PROF("score_gemm");
+        dim3 grid((unsigned)((ni + kBN - 1) / kBN), (unsigned)((rows + kBM - 1) / kBM));
+        score_gemm_kernel<<<grid, 256, 0, stream()>>>(query->f32() + start * f, (int)rows, items->f32(), (int)ni, f,
+                                                      item_norms ? item_norms->f32() : nullptr, scores.data());
+        IMP_CHECK_HIP(hipGetLastError());
+      }
+      if (item_filter && item_filter->size) {
+        IMP_PROF("item_filter");
+        size_t total = rows * item_filter->size;
+        int grid = (int)std::min<size_t>((total + 255) / 256, (size_t)ctx().num_cus * 8);
+        item_filter_kernel<<<grid, 256, 0, stream()>>>(scores.data(), (int)rows, (int)ni, item_filter->v.data(), (int)item_filter->size);
+        IMP_CHECK_HIP(hipGetLastError());
+      }
+      if (query_filter && query_filter->nnz) {
+        IMP_PROF("coo_filter");
+        int grid = (int)std::min<size_t>(((size_t)query_filter->nnz + 255) / 256, (size_t)ctx().num_cus * 8);
+        coo_filter_kernel<<<grid, 256, 0, stream()>>>(scores.data(), (int)start, (int)end, (int)ni, query_filter->row.data(),
+                                                      query_filter->col.data(), (size_t)query_filter->nnz);
+        IMP_CHECK_HIP(hipGetLastError());
+      }
+      {
+        IMP_PROF("topk_select");
+        size_t lds = use_lds ? (size_t)kpad * 8 : 0;
+        auto kern = select_kernel<512>;
+        IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)std::max<size_t>(lds, 1)));
+        kern<<<(unsigned)rows, 512, lds, stream()>>>(scores.data(), (int)ni, k_eff, kpad, d_ids + start * k, d_dist + start * k, k,
+                                                     gcand.data(), use_lds ? 1 : 0);
+        IMP_CHECK_HIP(hipGetLastError());
+      }
+    }
+    if (host_ids) IMP_CHECK_HIP(hipMemcpyAsync(indices, d_ids, nq * (size_t)k * 4, hipMemcpyDeviceToHost, stream()));
+    if (host_dist) IMP_CHECK_HIP(hipMemcpyAsync(distances, d_dist, nq * (size_t)k * 4, hipMemcpyDeviceToHost, stream()));
+    sync();
+  });
+}
+
+}  // extern "C"

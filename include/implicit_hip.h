@@ -1,0 +1,168 @@
+/*
+ * implicit_hip.h -- C-ABI of libimplicit_hip.so, the MI355X (gfx950) replacement for the
+ * native half of benfred/implicit's `implicit.gpu` plug-in.
+ *
+ * Every entry point below is what a binding for this path binds instead of the reference's C++
+ * classes (which Cython reaches through implicit/gpu/{matrix,als,knn,random,utils}.pxd).  The
+ * reference interface each one replaces is cited as file:line relative to the reference tree.
+ * Plain pointers, sizes and opaque handles only: no C++ types, no torch types.
+ *
+ * Conventions
+ *   - every function returns an imp_status; on failure imp_last_error() (thread-local) holds the
+ *     message.  The mapping to the reference's exceptions (implicit/gpu/utils.h:15-73 and the
+ *     Cython `except +` translation) is: IMP_INVALID_ARGUMENT -> std::invalid_argument ->
+ *     ValueError; IMP_OUT_OF_RANGE -> IndexError; IMP_RUNTIME_ERROR -> std::runtime_error /
+ *     std::logic_error -> RuntimeError.  No C++ exception ever crosses this boundary.
+ *   - all calls are synchronous on return, like the reference's (cudaDeviceSynchronize after each
+ *     kernel, implicit/gpu/als.cu:147,151,196,276; sync_stream, knn.cu:254).  Work is issued on
+ *     one library-owned HIP stream per device.
+ *   - matrices are row-major; itemsize 4 = fp32, 2 = fp16 storage (implicit/gpu/matrix.h:23-90).
+ *   - handles own device memory; row/slice views share their parent's storage by reference count
+ *     (reference: shared_ptr<rmm::device_buffer>, matrix.h:90).
+ */
+#ifndef IMPLICIT_HIP_H_
+#define IMPLICIT_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  IMP_OK = 0,
+  IMP_INVALID_ARGUMENT = 1, /* ValueError   */
+  IMP_OUT_OF_RANGE = 2,     /* IndexError   */
+  IMP_RUNTIME_ERROR = 3     /* RuntimeError */
+} imp_status;
+
+typedef struct imp_matrix imp_matrix;       /* implicit::gpu::Matrix       matrix.h:23-90  */
+typedef struct imp_intvector imp_intvector; /* implicit::gpu::Vector<int>  matrix.h:12-21  */
+typedef struct imp_csr imp_csr;             /* implicit::gpu::CSRMatrix    matrix.h:92-99  */
+typedef struct imp_coo imp_coo;             /* implicit::gpu::COOMatrix    matrix.h:101-108 */
+typedef struct imp_solver imp_solver;       /* implicit::gpu::LeastSquaresSolver  als.h:11-24 */
+typedef struct imp_knn imp_knn;             /* implicit::gpu::KnnQuery     knn.h:15-35     */
+typedef struct imp_random imp_random;       /* implicit::gpu::RandomState  random.h:10-21  */
+typedef struct imp_comm imp_comm;           /* NEW: RCCL communicator (reference: "TODO: multi-gpu", als.cu:169) */
+
+/* ---- library / device ------------------------------------------------------------------- */
+const char *imp_last_error(void);
+/* get_device_count(), utils.h:75-79: fails with IMP_RUNTIME_ERROR when no device is usable. */
+int imp_get_device_count(int *count);
+int imp_set_device(int device);
+int imp_get_device(int *device);
+int imp_device_synchronize(void);
+int imp_mem_get_info(size_t *free_bytes, size_t *total_bytes);
+const char *imp_version(void);
+
+/* ---- Matrix (matrix.h:23-90, matrix.cu:34-220) -------------------------------------------- */
+/* Matrix(rows, cols, data, allocate=true, itemsize): allocates; copies rows*cols*itemsize bytes
+ * from host_data when non-NULL, zero-fills otherwise (matrix.cu:80-96). */
+int imp_matrix_create(size_t rows, size_t cols, const void *host_data, size_t itemsize, imp_matrix **out);
+/* Matrix(rows, cols, device_ptr, allocate=false, itemsize): wraps foreign device memory, never
+ * frees it (matrix.cu:93-95; __cuda_array_interface__ path of _cuda.pyx:99-104). */
+int imp_matrix_wrap_device(size_t rows, size_t cols, void *device_ptr, size_t itemsize, imp_matrix **out);
+/* Matrix(other, rowid): one-row view sharing storage (matrix.cu:34-40). */
+int imp_matrix_row(const imp_matrix *m, size_t rowid, imp_matrix **out);
+/* Matrix(other, start, end): row-range view sharing storage (matrix.cu:42-53). */
+int imp_matrix_slice(const imp_matrix *m, size_t start, size_t end, imp_matrix **out);
+/* Matrix(other, rowids): gather-copy of the selected rows (matrix.cu:55-78). */
+int imp_matrix_gather(const imp_matrix *m, const imp_intvector *rowids, imp_matrix **out);
+/* Matrix::resize: grows rows only, zero-fills the new rows (matrix.cu:98-120). */
+int imp_matrix_resize(imp_matrix *m, size_t rows, size_t cols);
+/* Matrix::assign_rows(rowids, other): scatter rows of `other` (fp32 only, matrix.cu:122-143). */
+int imp_matrix_assign_rows(imp_matrix *m, const imp_intvector *rowids, const imp_matrix *other);
+/* Matrix::astype(itemsize): fp32 <-> fp16 copy (matrix.cu:153-171). */
+int imp_matrix_astype(const imp_matrix *m, size_t itemsize, imp_matrix **out);
+/* Matrix::calculate_norms(): 1 x rows fp32 L2 norms, zeros replaced by 1e-10 (matrix.cu:173-215). */
+int imp_matrix_calculate_norms(const imp_matrix *m, imp_matrix **out);
+/* Matrix::to_host (matrix.cu:217-220). */
+int imp_matrix_to_host(const imp_matrix *m, void *host_out);
+/* NEW: overwrite the matrix from host memory (same shape/itemsize); used to re-seed parity runs. */
+int imp_matrix_from_host(imp_matrix *m, const void *host_in);
+int imp_matrix_shape(const imp_matrix *m, size_t *rows, size_t *cols, size_t *itemsize);
+int imp_matrix_device_ptr(const imp_matrix *m, void **ptr);
+int imp_matrix_destroy(imp_matrix *m);
+
+/* ---- Vector<int> / CSRMatrix / COOMatrix (matrix.cu:13-32, 222-280) ------------------------- */
+int imp_intvector_create(const int32_t *host_data, size_t size, imp_intvector **out);
+int imp_intvector_destroy(imp_intvector *v);
+/* CSRMatrix(rows, cols, nonzeros, indptr, indices, data): H2D copy into plain device memory (the
+ * reference uses managed memory + ReadMostly advise, matrix.cu:222-251).  Also builds the
+ * row-length bins the solver kernels schedule from (device-side metadata, not visible here). */
+int imp_csr_create(int32_t rows, int32_t cols, int64_t nonzeros, const int32_t *indptr,
+                   const int32_t *indices, const float *data, imp_csr **out);
+int imp_csr_shape(const imp_csr *m, int32_t *rows, int32_t *cols, int64_t *nonzeros);
+int imp_csr_destroy(imp_csr *m);
+int imp_coo_create(int32_t rows, int32_t cols, int64_t nonzeros, const int32_t *row,
+                   const int32_t *col, const float *data, imp_coo **out);
+int imp_coo_destroy(imp_coo *m);
+
+/* ---- LeastSquaresSolver (als.h:11-24, als.cu:118-281) ---------------------------------------- */
+int imp_solver_create(imp_solver **out);
+int imp_solver_destroy(imp_solver *s);
+/* calculate_yty(Y, &YtY, regularization): YtY(f x f fp32) = Y^T Y + reg*I  (als.cu:122-152).
+ * MFMA (v_mfma_f32_32x32x2_f32) split over row blocks with a fixed-order second stage. */
+int imp_solver_calculate_yty(imp_solver *s, const imp_matrix *Y, imp_matrix *YtY, float regularization);
+/* least_squares(Cui, &X, YtY, Y, cg_steps): warm-started CG half sweep, X in place; YtY is the
+ * regularised gramian (als.cu:154-197; numerics follow the CPU oracle _als.pyx:152-248). */
+int imp_solver_least_squares(imp_solver *s, const imp_csr *cui, imp_matrix *X, const imp_matrix *YtY,
+                             const imp_matrix *Y, int cg_steps);
+/* NEW (the reference GPU path has no Cholesky solver; mirrors the CPU _als._least_squares,
+ * _als.pyx:75-142): YtY is UNregularised, `regularization` (double) is added to the diagonal,
+ * the previous X is ignored.  On a non-positive-definite row returns IMP_INVALID_ARGUMENT
+ * (ValueError, as _als.pyx:136-138) and *failed_row = that row (else -1). */
+int imp_solver_least_squares_cholesky(imp_solver *s, const imp_csr *cui, imp_matrix *X,
+                                      const imp_matrix *YtY, const imp_matrix *Y,
+                                      double regularization, int64_t *failed_row);
+/* calculate_loss(Cui, X, Y, regularization) (als.cu:253-281; oracle _als.pyx:257-308). */
+int imp_solver_calculate_loss(imp_solver *s, const imp_csr *cui, const imp_matrix *X,
+                              const imp_matrix *Y, float regularization, float *loss_out);
+
+/* ---- KnnQuery (knn.h:15-35, knn.cu:56-265) ---------------------------------------------------- */
+/* KnnQuery(max_temp_memory): 0 = min(free/2, 4 GiB) (knn.cu:56-75). */
+int imp_knn_create(size_t max_temp_memory, imp_knn **out);
+int imp_knn_destroy(imp_knn *k);
+/* topk(items, query, k, indices, distances, item_norms, query_filter, item_filter) (knn.cu:77-265).
+ * indices/distances are caller-allocated [query.rows x k] HOST or DEVICE buffers (auto-detected,
+ * knn.cu:40-54,147-164).  Rows are written best-first in the total order (score desc, column
+ * desc); when k > items.rows only the first items.rows entries of each row are written
+ * (knn.cu:239).  Filtered entries score -FLT_MAX (topk.pyx:51). */
+int imp_knn_topk(imp_knn *k, const imp_matrix *items, const imp_matrix *query, int topk,
+                 int32_t *indices, float *distances, const imp_matrix *item_norms,
+                 const imp_coo *query_filter, const imp_intvector *item_filter);
+
+/* ---- RandomState (random.h:10-21, random.cu:14-40) ------------------------------------------- */
+int imp_random_create(int64_t seed, imp_random **out);
+int imp_random_destroy(imp_random *r);
+int imp_random_uniform(imp_random *r, size_t rows, size_t cols, float low, float high, imp_matrix **out);
+int imp_random_randn(imp_random *r, size_t rows, size_t cols, float mean, float stddev, imp_matrix **out);
+
+/* ---- NEW: multi-GPU exchange over RCCL / xGMI (no reference counterpart) ------------------------ */
+/* One process per GPU.  Rank 0 calls imp_comm_unique_id, the host side broadcasts the 128 bytes by
+ * any means (torch.distributed store, MPI, a file) and every rank calls imp_comm_init_rank. */
+#define IMP_COMM_UNIQUE_ID_BYTES 128
+int imp_comm_unique_id(void *id_out);
+int imp_comm_init_rank(const void *id, int nranks, int rank, imp_comm **out);
+int imp_comm_destroy(imp_comm *c);
+/* in-place sum all-reduce of an fp32 matrix (the f x f gramian). */
+int imp_comm_allreduce_sum(imp_comm *c, imp_matrix *m);
+/* all-gather of row shards: rank r contributes rows [row_offsets[r], row_offsets[r+1]) of `full`
+ * (already in place in its own copy); afterwards every rank holds all rows. */
+int imp_comm_allgather_rows(imp_comm *c, imp_matrix *full, const int64_t *row_offsets);
+int imp_comm_barrier(imp_comm *c);
+
+/* ---- NEW: measurement hooks (bench.py's roofline leg) -------------------------------------------- */
+/* When enabled every kernel launch is bracketed by HIP events on the library stream; totals are
+ * accumulated per kernel name.  imp_prof_get returns 0 launches for unknown names. */
+int imp_prof_enable(int on);
+int imp_prof_reset(void);
+int imp_prof_get(const char *kernel, double *total_ms, int64_t *launches);
+/* '\n'-separated list of kernel names seen so far, copied into buf (truncated to buflen). */
+int imp_prof_names(char *buf, size_t buflen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMPLICIT_HIP_H_ */

@@ -1,0 +1,111 @@
+"""Container semantics of the implicit.gpu surface (implicit/gpu/_cuda.pyx:85-247, matrix.cu)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+from numpy.testing import assert_array_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def test_matrix_roundtrip_views_and_gather(gpu):
+    a = np.arange(60, dtype=np.float32).reshape(12, 5)
+    m = gpu.Matrix(a)
+    assert m.shape == (12, 5) and bool(m)
+    assert_array_equal(m.to_numpy(), a)
+    assert_array_equal(m[3].to_numpy(), a[3:4])          # int -> one-row view, shape (1, cols)
+    assert m[3].shape == (1, 5)
+    assert_array_equal(m[2:7].to_numpy(), a[2:7])        # slice -> shared-storage view
+    assert_array_equal(m[:].to_numpy(), a)
+    assert_array_equal(m[[5, 1, 1, 11]].to_numpy(), a[[5, 1, 1, 11]])  # gather copy
+    assert_array_equal(m[np.int64(4)].to_numpy(), a[4:5])  # numpy scalar -> array path (_cuda.pyx:138-158)
+    with pytest.raises(IndexError):
+        m[[0, 12]]
+    with pytest.raises(IndexError):
+        m[[-1]]
+    with pytest.raises(ValueError):
+        m[0:10:2]
+    with pytest.raises(ValueError):
+        gpu.Matrix(np.zeros((2, 2), dtype=np.float64))
+    with pytest.raises(ValueError):
+        m[1:30]
+    assert gpu.Matrix(None) is not None
+
+
+def test_view_shares_storage_with_solver_writes(gpu):
+    """Row-range views alias their parent (matrix.cu:42-53): astype/assign on the parent is visible."""
+    a = np.zeros((6, 4), dtype=np.float32)
+    m = gpu.Matrix(a)
+    view = m[2:4]
+    m.assign_rows([2, 3], gpu.Matrix(np.ones((2, 4), dtype=np.float32)))
+    assert_array_equal(view.to_numpy(), np.ones((2, 4), dtype=np.float32))
+
+
+def test_astype_resize_assign(gpu):
+    a = np.random.default_rng(0).random((7, 6), dtype=np.float32)
+    m = gpu.Matrix(a)
+    h = m.astype(np.float16)
+    assert h.to_numpy().dtype == np.float16
+    assert_array_equal(h.to_numpy(), a.astype(np.float16))
+    assert_array_equal(h.astype(np.float32).to_numpy(), a.astype(np.float16).astype(np.float32))
+    with pytest.raises(ValueError):
+        m.astype(np.float64)
+    m.resize(10, 6)
+    got = m.to_numpy()
+    assert got.shape == (10, 6)
+    assert_array_equal(got[:7], a)
+    assert not got[7:].any()
+    with pytest.raises(RuntimeError):
+        m.resize(4, 6)
+    with pytest.raises(RuntimeError):
+        m.resize(12, 3)
+    rows = gpu.Matrix(np.full((2, 6), 3.0, dtype=np.float32))
+    m.assign_rows([9, 0], rows)
+    got = m.to_numpy()
+    assert (got[9] == 3).all() and (got[0] == 3).all() and not got[8].any()
+    with pytest.raises(ValueError):
+        m.assign_rows([1], rows)
+    z = gpu.Matrix.zeros(3, 4)
+    assert not z.to_numpy().any()
+    f16 = gpu.Matrix(np.ones((2, 2), dtype=np.float16))
+    assert f16.to_numpy().dtype == np.float16
+
+
+def test_cuda_array_interface_wrap(gpu):
+    m = gpu.Matrix(np.arange(12, dtype=np.float32).reshape(3, 4))
+
+    class Foreign:
+        __cuda_array_interface__ = {"shape": (3, 4), "typestr": "<f4", "data": (m.device_ptr, False), "version": 2}
+
+    w = gpu.Matrix(Foreign())
+    assert_array_equal(w.to_numpy(), m.to_numpy())
+
+
+def test_csr_requires_int32_and_converts_non_csr(gpu):
+    from implicit_amd.utils import ParameterWarning
+
+    C = sp.random(10, 8, density=0.3, format="csr", dtype=np.float32, random_state=0)
+    gpu.CSRMatrix(C)
+    with pytest.warns(ParameterWarning):
+        gpu.CSRMatrix(C.tocoo())
+    bad = C.copy()
+    bad.indices = bad.indices.astype(np.int64)
+    bad.indptr = bad.indptr.astype(np.int64)
+    with pytest.raises(ValueError):
+        gpu.CSRMatrix(bad)
+
+
+def test_random_state(gpu):
+    rs = gpu.RandomState(42)
+    u = rs.uniform(2000, 64, low=-0.5, high=0.25).to_numpy()
+    assert u.shape == (2000, 64) and u.min() >= -0.5 and u.max() <= 0.25
+    assert abs(u.mean() + 0.125) < 5e-3
+    n = rs.randn(2000, 64, mean=1.0, stddev=2.0).to_numpy()
+    assert abs(n.mean() - 1.0) < 2e-2 and abs(n.std() - 2.0) < 2e-2
+    again = gpu.RandomState(42).uniform(2000, 64, low=-0.5, high=0.25).to_numpy()
+    assert_array_equal(u, again)
+    assert not np.array_equal(u, gpu.RandomState(43).uniform(2000, 64, low=-0.5, high=0.25).to_numpy())
+
+
+def test_bpr_update_is_out_of_scope(gpu):
+    with pytest.raises(NotImplementedError):
+        gpu.bpr_update()
