@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""bench.py -- ALS training throughput on MI355X (BASELINE.json metric: "ALS user+item updates/sec
+per iteration (factors=128); top-k recs/sec").
+
+A *step* is one full ALS iteration of the hot path over the synthetic confidence matrix: user half
+sweep (gramian YtY + per-row 3-step CG solves) then item half sweep (gramian XtX + solves), plus --
+for N > 1 -- the RCCL exchange of the gramians and of the freshly solved factor shards.  Inputs are
+resident in HBM before the timed region starts.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N = 1 workload: BASELINE configs[2] -- last.fm-360K-shaped synthetic CSR (358,868 users x 292,385
+items, ~17.5M nnz requested), factors=128, CG cg_steps=3, fp32.  N > 1: weak scaling -- every rank
+owns one such shard of users and of items (global matrix = N x users, N x items, N x nnz).
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed on the library
+stream inside the timed region) and `cpu_baseline` (the reference's own Cython CPU solver from
+oracle/_ref, or the plain-C oracle port, on a bounded row sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+# scipy-openblas is built for <= 64 threads; the GPU box has 256 logical cores
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "64")
+
+import numpy as np  # noqa: E402
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FACTORS = 128
+REG = 0.01
+CG_STEPS = 3
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured streaming ceiling)
+WAVE_ROW_MAX = int(os.environ.get("IMP_WAVE_ROW_MAX", "256"))
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--shape", default="lastfm360k")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; flagged in the output)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-topk", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def cg_algorithmic_bytes(lengths, f):
+    """nnz*(4f+8) + R*(8f+8) + 4f^2 for the rows one launch processes."""
+    nnz = int(lengths.sum())
+    rows = int(len(lengths))
+    return nnz * (4 * f + 8) + rows * (8 * f + 8) + 4 * f * f
+
+
+def kernel_bytes_per_iteration(Cui, Ciu, f):
+    """Algorithmic bytes of the wave-per-row CG launches (one per half sweep) of one iteration."""
+    out = {"als_cg_wave_rows": 0, "als_cg_block_rows": 0}
+    for M in (Cui, Ciu):
+        lens = np.diff(M.indptr)
+        wave = lens[(lens > 0) & (lens <= WAVE_ROW_MAX)]
+        block = lens[lens > WAVE_ROW_MAX]
+        if len(wave):
+            out["als_cg_wave_rows"] += cg_algorithmic_bytes(wave, f)
+        if len(block):
+            out["als_cg_block_rows"] += cg_algorithmic_bytes(block, f)
+    return out
+
+
+def cpu_baseline(Cui, Ciu, X0, Y0, seconds):
+    """Times the reference CPU solver (oracle/_ref, else the plain-C port) on a bounded row sample."""
+    from oracle import oracle as port
+    from oracle import ref
+
+    als_ref, _ = ref.load()
+    cores = os.cpu_count() or 1
+    kind = "reference" if als_ref is not None else "port"
+    limiter = None
+    if als_ref is not None:
+        try:
+            from threadpoolctl import threadpool_limits
+
+            limiter = threadpool_limits(1, "blas")  # the reference demands single-threaded BLAS (utils.py:18-62)
+        except ImportError:
+            pass
+    else:
+        port.build()
+
+    def run(M, A, B):
+        A = A.copy()
+        t = time.time()
+        if als_ref is not None:
+            als_ref.least_squares_cg(M, A, B, REG, num_threads=0, cg_steps=CG_STEPS)
+        else:
+            port.least_squares_cg(M, A, B, REG, num_threads=0, cg_steps=CG_STEPS)
+        return time.time() - t
+
+    # probe on 2000 rows of each side, then size the sample for ~`seconds`
+    pu, pi = min(2000, Cui.shape[0]), min(2000, Ciu.shape[0])
+    t_probe = run(Cui[:pu], X0[:pu], Y0) + run(Ciu[:pi], Y0[:pi], X0)
+    rate = (pu + pi) / max(t_probe, 1e-6)
+    frac = min(1.0, seconds * rate / (Cui.shape[0] + Ciu.shape[0]))
+    su, si = max(pu, int(Cui.shape[0] * frac)), max(pi, int(Ciu.shape[0] * frac))
+    t = run(Cui[:su], X0[:su], Y0) + run(Ciu[:si], Y0[:si], X0)
+    if limiter is not None:
+        limiter.restore_original_limits()
+    nnz = int(Cui.indptr[su] + Ciu.indptr[si])
+    return {
+        "value": (su + si) / t,
+        "unit": "updates/s",
+        "cores": cores,
+        "kind": kind,
+        "sample": f"one CG(cg_steps=3,f={X0.shape[1]}) half-sweep over the first {su} users + first {si} items "
+                  f"({nnz} nnz) of the same matrix, {t:.1f}s, OpenMP num_threads=0, BLAS threads=1",
+        "nnz_visits_per_s": nnz / t,
+    }
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N (N>1) must be launched with torch.distributed.run, one rank per GPU")
+        args.gpus = world
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        import implicit_amd.gpu as gpu
+    if not gpu.HAS_CUDA:
+        sys.exit("bench.py: libimplicit_hip.so / HIP device unavailable (no CPU fallback exists)")
+    from implicit_amd.synthetic import SHAPES, synthetic_csr
+
+    gpu.set_device(local_rank)
+    users, items, nnz_target, gamma = SHAPES[args.shape]
+    if args.scale != 1.0:
+        users, items, nnz_target = int(users * args.scale), int(items * args.scale), int(nnz_target * args.scale)
+
+    if world > 1:
+        from implicit_amd.gpu import sharded
+
+        result = sharded.bench(args, gpu, users, items, nnz_target, gamma, FACTORS, REG, CG_STEPS)
+        if rank == 0:
+            print(json.dumps(result))
+        return
+
+    # ---- single GPU ---------------------------------------------------------------------------------
+    t0 = time.time()
+    Cui = synthetic_csr(users, items, nnz_target, gamma=gamma, seed=42)
+    Ciu = Cui.T.tocsr()
+    rng = np.random.default_rng(7)
+    X0 = rng.random((users, FACTORS), dtype=np.float32) * 0.01
+    Y0 = rng.random((items, FACTORS), dtype=np.float32) * 0.01
+    t_gen = time.time() - t0
+
+    t0 = time.time()
+    Cui_d, Ciu_d = gpu.CSRMatrix(Cui), gpu.CSRMatrix(Ciu)
+    X, Y = gpu.Matrix(X0), gpu.Matrix(Y0)
+    gram = gpu.Matrix.zeros(FACTORS, FACTORS)
+    solver = gpu.LeastSquaresSolver()
+    gpu.synchronize()
+    t_upload = time.time() - t0
+
+    def step():
+        solver.calculate_yty(Y, gram, REG)
+        solver.least_squares(Cui_d, X, gram, Y, CG_STEPS)
+        solver.calculate_yty(X, gram, REG)
+        solver.least_squares(Ciu_d, Y, gram, X, CG_STEPS)
+
+    for _ in range(args.warmup):
+        step()
+    gpu.synchronize()
+    gpu.Profiler.enable(True)
+    gpu.Profiler.reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    gpu.synchronize()
+    elapsed = time.perf_counter() - t0
+    gpu.Profiler.enable(False)
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = (users + items) / (elapsed / args.steps)
+
+    # ---- roofline of the dominant kernel ----------------------------------------------------------
+    kbytes = kernel_bytes_per_iteration(Cui, Ciu, FACTORS)
+    kernels = {}
+    for name in gpu.Profiler.names():
+        ms, n = gpu.Profiler.get(name)
+        kernels[name] = {"total_ms": ms, "launches": n}
+    dom = max(kernels, key=lambda k: kernels[k]["total_ms"])
+    roofline = None
+    if dom in kbytes and kernels[dom]["launches"]:
+        launches = kernels[dom]["launches"]
+        bytes_per_launch = kbytes[dom] / 2.0  # two launches (user side, item side) per iteration
+        avg_ms = kernels[dom]["total_ms"] / launches
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
+                    "algorithmic_bytes_per_launch": bytes_per_launch}
+
+    out = {
+        "metric": "ALS user+item updates/sec per iteration (factors=128)",
+        "value": value,
+        "unit": "updates/s",
+        "n_gpus": 1,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"BASELINE configs[2]: last.fm-360K-shaped synthetic CSR, ALS CG cg_steps={CG_STEPS}"
+                        if args.shape == "lastfm360k" and args.scale == 1.0 else f"{args.shape} x{args.scale} (debug)",
+            "users": users, "items": items, "nnz": int(Cui.nnz), "factors": FACTORS, "regularization": REG,
+            "solver": "cg", "cg_steps": CG_STEPS, "parallelism": "1 GPU",
+        },
+        "nnz_visits_per_s": 2 * int(Cui.nnz) / (elapsed / args.steps),
+        "roofline": roofline,
+        "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in kernels.items()},
+        "setup_s": {"generate": t_gen, "upload": t_upload},
+    }
+
+    if not args.no_topk:
+        out["topk"] = bench_topk(gpu, Cui, X, Y, k=10)
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(Cui, Ciu, X0, Y0, args.cpu_seconds)
+    print(json.dumps(out))
+
+
+def bench_topk(gpu, Cui, X, Y, k=10, queries=20_000, batch=1000):
+    """recommend()-shaped scoring: top-k over all items for `queries` users in batches of 1000 with the
+    liked-items filter active (examples/lastfm.py:150-156 of the reference)."""
+    knn = gpu.KnnQuery()
+    queries = min(queries, Cui.shape[0])
+    filt = [gpu.COOMatrix(Cui[s:s + batch].tocoo()) for s in range(0, queries, batch)]
+    views = [X[s:min(s + batch, queries)] for s in range(0, queries, batch)]
+    knn.topk(Y, views[0], k, query_filter=filt[0])  # warm-up
+    gpu.synchronize()
+    t0 = time.perf_counter()
+    for v, fl in zip(views, filt):
+        knn.topk(Y, v, k, query_filter=fl)
+    gpu.synchronize()
+    t = time.perf_counter() - t0
+    return {"metric": "top-k recs/sec", "value": queries / t, "unit": "recs/s", "k": k, "queries": queries,
+            "batch": batch, "items": Y.shape[0], "filter_already_liked_items": True,
+            "note": "ids/scores returned to host memory per batch (PCIe D2H included)"}
+
+
+if __name__ == "__main__":
+    main()

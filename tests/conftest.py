@@ -2,6 +2,9 @@ import os
 import sys
 import warnings
 
+# scipy-openblas is built for <= 64 threads and crashes on the 256-core GPU box without this
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "64")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,0 +1,214 @@
+"""Model-level behaviour through the shim, following the reference's RecommenderBaseTestMixin
+(tests/recommender_base_test.py) and tests/als_test.py, for the GPU AlternatingLeastSquares."""
+import pickle
+
+import numpy as np
+import pytest
+from numpy.testing import assert_array_equal
+from scipy.sparse import csr_matrix
+
+pytestmark = pytest.mark.gpu
+
+
+def get_checker_board(X):
+    """even users like even items, odd users odd items, diagonal withheld (recommender_base_test.py:20-28)"""
+    ret = np.zeros((X, X))
+    for i in range(X):
+        for j in range(i % 2, X, 2):
+            ret[i, j] = 1.0
+    return csr_matrix(ret - np.eye(X))
+
+
+def _model(gpu, **kw):
+    from implicit_amd.als import AlternatingLeastSquares
+
+    args = dict(factors=32, regularization=0, random_state=23, use_gpu=True)
+    args.update(kw)
+    return AlternatingLeastSquares(**args)
+
+
+@pytest.mark.parametrize("use_cg", [True, False])
+def test_recommend_checkerboard(gpu, use_cg):
+    user_items = get_checker_board(50)
+    model = _model(gpu, use_cg=use_cg, regularization=0 if use_cg else 1e-3)
+    model.fit(user_items, show_progress=False)
+    for userid in range(50):
+        ids, _ = model.recommend(userid, user_items[userid], N=1)
+        assert len(ids) == 1 and ids[0] == userid
+    ids, _ = model.recommend(0, user_items[0], N=10000)
+    assert len(ids)
+    ids, _ = model.recommend(0, user_items[0], N=1, filter_items=[0])
+    assert 0 not in set(ids)
+
+
+def test_recommend_batch_matches_scalar(gpu):
+    user_items = get_checker_board(50)
+    model = _model(gpu)
+    model.fit(user_items, show_progress=False)
+    userids = np.arange(50)
+    ids, scores = model.recommend(userids, user_items[userids], N=1)
+    for u in userids:
+        assert ids[u][0] == u
+        i1, s1 = model.recommend(u, user_items[u], N=1)
+        assert np.allclose(i1, ids[u]) and np.allclose(s1, scores[u])
+    ids, scores = model.recommend(userids, user_items[userids], N=5, filter_already_liked_items=False)
+    for u in range(50):
+        i1, s1 = model.recommend(u, user_items[u], N=5, filter_already_liked_items=False)
+        assert np.allclose(s1, scores[u]) and np.allclose(i1, ids[u])
+    sel = np.array([2, 3, 4])
+    ids, _ = model.recommend(sel, user_items[sel], N=1, filter_items=[0])
+    assert all(0 not in row for row in ids)
+
+
+def test_recalculate_user(gpu):
+    user_items = get_checker_board(50)
+    model = _model(gpu)  # regularization=0 as in the reference's mixin
+    model.fit(user_items, show_progress=False)
+    userids = np.arange(50)
+    batch_ids, batch_scores = model.recommend(userids, user_items[userids], N=1, recalculate_user=True)
+    for u in range(50):
+        ids, scores = model.recommend(u, user_items[u], N=1)
+        ids2, scores2 = model.recommend(0, user_items[u], N=1, recalculate_user=True)
+        assert ids[0] == ids2[0] == batch_ids[u][0]
+        assert scores[0] == pytest.approx(scores2[0], abs=1e-3)
+        assert batch_scores[u][0] == pytest.approx(scores2[0], abs=1e-3)
+
+
+def test_similar_items_and_users(gpu):
+    user_items = get_checker_board(256)
+    model = _model(gpu)  # factors=32, regularization=0 as in the reference's mixin
+    model.fit(user_items, show_progress=False)
+    ids, scores = model.similar_items(np.arange(50), N=10)
+    assert ids.shape == (50, 10)
+    for itemid in range(50):
+        assert ids[itemid][0] == itemid  # recommender_base_test.py:238-264
+        assert all(i % 2 == itemid % 2 for i in ids[itemid])
+        assert scores[itemid][0] == pytest.approx(1.0, abs=1e-4)
+        one_ids, one_scores = model.similar_items(itemid, N=10)
+        assert all(i % 2 == itemid % 2 for i in one_ids)
+    ids, scores = model.similar_users(np.arange(4), N=5)
+    assert ids.shape == (4, 5) and all(ids[u][0] == u for u in range(4))
+    sub = np.arange(0, 50, 2)
+    ids, _ = model.similar_items(0, N=5, items=sub)
+    assert set(ids) <= set(sub)
+    ids, _ = model.similar_items(0, N=5, filter_items=[0])
+    assert 0 not in ids
+
+
+def test_recommend_items_subset_and_errors(gpu):
+    user_items = get_checker_board(50)
+    model = _model(gpu)
+    model.fit(user_items, show_progress=False)
+    ids, _ = model.recommend(0, user_items[0], N=3, items=[0, 2, 4, 6, 1])
+    assert set(ids) <= {0, 2, 4, 6, 1} and ids[0] == 0
+    with pytest.raises(IndexError):
+        model.recommend(0, user_items[0], items=[0, 50])
+    with pytest.raises(ValueError):
+        model.recommend(0, user_items[0], items=[0], filter_items=[1])
+    with pytest.raises(ValueError):
+        model.recommend(0, user_items[0].tocoo())
+    with pytest.raises(ValueError):
+        model.recommend([0, 1], user_items[0])
+
+
+def test_zero_length_rows_and_dtypes(gpu):
+    """recommender_base_test.py:285-302,337-344"""
+    ui = get_checker_board(50).tolil()
+    ui[42] = 0
+    ui[:, 42] = 0
+    ui = ui.tocsr()
+    model = _model(gpu)
+    model.fit(ui.astype(np.float64), show_progress=False)
+    ids, _ = model.recommend(0, ui[0].astype(np.float32), N=10)
+    assert 42 not in ids
+    uf = model.user_factors.to_numpy()
+    assert not uf[42].any()
+
+
+def test_factorize_known_answer(gpu):
+    """tests/als_test.py:142-186: exact reconstruction of the 7x6 matrix to 1e-3."""
+    counts = csr_matrix([[1, 1, 0, 1, 0, 0], [0, 1, 1, 1, 0, 0], [1, 0, 1, 0, 0, 0], [1, 1, 0, 0, 0, 0],
+                         [0, 0, 1, 1, 0, 1], [0, 1, 0, 0, 0, 1], [0, 0, 0, 0, 1, 1]], dtype=np.float64)
+    for use_cg in (True, False):
+        model = _model(gpu, factors=6, regularization=0, alpha=2.0, use_cg=use_cg, random_state=42)
+        model.fit(counts, show_progress=False)
+        rec = model.user_factors.to_numpy() @ model.item_factors.to_numpy().T
+        assert np.abs(rec - counts.toarray()).max() < 1e-3, use_cg
+
+
+def test_fit_matches_oracle_fit_free_running(gpu, oracle):
+    """Same seed, same init draw order as the CPU path: 3 free-running iterations stay within 1e-3
+    (per-sweep parity is the 1e-4 gate, tests/test_gpu_als.py; free-running drift is the oracle's own
+    fp32 noise amplified -- SURVEY App. A.5)."""
+    from implicit_amd.synthetic import synthetic_csr
+
+    C = synthetic_csr(1500, 700, 40_000, seed=4)
+    model = _model(gpu, factors=64, regularization=0.05, iterations=3, random_state=11)
+    model.fit(C, show_progress=False)
+    X, Y = oracle.fit(C, 64, regularization=0.05, iterations=3, random_state=11)
+    ex = np.linalg.norm(model.user_factors.to_numpy() - X) / np.linalg.norm(X)
+    ey = np.linalg.norm(model.item_factors.to_numpy() - Y) / np.linalg.norm(Y)
+    print(f"free-running 3 iterations: rel X {ex:.2e} Y {ey:.2e}")
+    assert ex < 1e-3 and ey < 1e-3
+
+
+def test_callbacks_loss_and_zero_iterations(gpu):
+    user_items = get_checker_board(30)
+    seen = []
+    model = _model(gpu, iterations=3, calculate_training_loss=True, regularization=0.01)
+    model.fit(user_items, show_progress=False, callback=lambda it, t, loss: seen.append((it, loss)))
+    assert [s[0] for s in seen] == [0, 1, 2]
+    assert seen[-1][1] is not None and seen[-1][1] <= seen[0][1]
+    m0 = _model(gpu, factors=128, iterations=0, calculate_training_loss=True)
+    m0.fit(csr_matrix(np.ones((10, 10))), show_progress=False)
+
+
+def test_pickle_and_save_load(gpu, tmp_path):
+    user_items = get_checker_board(50)
+    model = _model(gpu)
+    model.fit(user_items, show_progress=False)
+    want = model.recommend(0, user_items[0], N=5)
+    clone = pickle.loads(pickle.dumps(model))
+    assert_array_equal(clone.recommend(0, user_items[0], N=5)[0], want[0])
+    path = str(tmp_path / "model.npz")
+    model.save(path)
+    loaded = type(model).load(path)
+    assert_array_equal(loaded.recommend(0, user_items[0], N=5)[0], want[0])
+    assert loaded.factors == model.factors
+
+
+def test_partial_fit(gpu):
+    """tests/als_test.py:272-301: new users/items get factors, storage grows."""
+    from implicit_amd.synthetic import synthetic_csr
+
+    C = synthetic_csr(100, 60, 1500, seed=2)
+    model = _model(gpu, factors=16, regularization=0.05)
+    model.fit(C, show_progress=False)
+    new_user = csr_matrix(([1.0, 1.0, 1.0], ([0, 0, 0], [1, 5, 9])), shape=(1, 60), dtype=np.float32)
+    model.partial_fit_users([105], new_user)
+    assert model.user_factors.shape[0] == 106
+    uf = model.user_factors.to_numpy()
+    assert uf[105].any() and not uf[101].any()
+    ids, _ = model.recommend(105, new_user, N=3)
+    assert len(ids) == 3
+    new_item = csr_matrix(([1.0, 1.0], ([0, 0], [3, 7])), shape=(1, 106), dtype=np.float32)
+    model.partial_fit_items([60], new_item)
+    assert model.item_factors.shape[0] == 61 and model.item_factors.to_numpy()[60].any()
+
+
+def test_fp16_model(gpu):
+    user_items = get_checker_board(50)
+    model = _model(gpu, dtype=np.float16)
+    model.fit(user_items, show_progress=False)
+    assert model.user_factors.to_numpy().dtype == np.float16
+    for userid in range(0, 50, 7):
+        ids, _ = model.recommend(userid, user_items[userid], N=1)
+        assert ids[0] == userid
+
+
+def test_non_csr_input_warns(gpu):
+    from implicit_amd.utils import ParameterWarning
+
+    model = _model(gpu, iterations=1)
+    with pytest.warns(ParameterWarning):
+        model.fit(get_checker_board(20).tocoo(), show_progress=False)

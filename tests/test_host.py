@@ -1,0 +1,52 @@
+"""Host-side logic that needs no GPU: synthetic generator, CSR checks, filter remapping, sharding plan."""
+import warnings
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+from numpy.testing import assert_array_equal
+
+
+def test_synthetic_csr_is_canonical_and_deterministic():
+    from implicit_amd.synthetic import synthetic_csr
+
+    a = synthetic_csr(500, 300, 6000, seed=3, neg_frac=0.1, empty_frac=0.05)
+    b = synthetic_csr(500, 300, 6000, seed=3, neg_frac=0.1, empty_frac=0.05)
+    assert a.shape == (500, 300) and a.indices.dtype == np.int32 and a.indptr.dtype == np.int32 and a.dtype == np.float32
+    assert (a != b).nnz == 0
+    assert a.has_canonical_format
+    assert 0.8 * 6000 < a.nnz <= 6000 * 1.05
+    lens = np.diff(a.indptr)
+    assert (lens == 0).any() and (a.data < 0).any()
+    assert np.abs(a.data).min() >= 1.0 and np.abs(a.data).max() <= 5.0
+
+
+def test_check_csr_warns_and_converts():
+    from implicit_amd.utils import ParameterWarning, check_csr
+
+    m = sp.random(5, 4, density=0.5, format="csr", dtype=np.float32, random_state=0)
+    assert check_csr(m) is m
+    with pytest.warns(ParameterWarning):
+        out = check_csr(m.tocoo())
+    assert isinstance(out, sp.csr_matrix)
+
+
+def test_filter_items_remap_matches_reference_semantics():
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        from implicit_amd.gpu.matrix_factorization_base import _filter_items_from_sparse_matrix
+
+    liked = sp.csr_matrix(np.array([[1, 0, 1, 0, 1, 0], [0, 1, 0, 0, 0, 1]], dtype=np.float32))
+    items = np.array([1, 2, 4])
+    out = _filter_items_from_sparse_matrix(items, liked).toarray()
+    # row 0 liked {0,2,4} -> positions of 2 and 4 in items = {1,2}; row 1 liked {1,5} -> position of 1 = {0}
+    assert_array_equal(out[:, :3] != 0, [[False, True, True], [True, False, False]])
+
+
+def test_check_random_state():
+    from implicit_amd.utils import check_random_state
+
+    a = check_random_state(5).random(3)
+    b = check_random_state(5).random(3)
+    assert_array_equal(a, b)
+    assert isinstance(check_random_state(np.random.RandomState(1)), np.random.Generator)

@@ -1,0 +1,124 @@
+"""N > 1 path on CPU: world_size-2 `gloo` run of implicit_amd.gpu.sharded.iteration with the oracle as
+the per-shard solver (tests may use the oracle; the product never does).  Checks the shard plan, the
+view/offset bookkeeping and the exchange order: after each iteration every rank must hold the same
+full X, Y and they must equal a single-process oracle fit of the global matrix (only the gramian's
+cross-rank summation order differs)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class NumpyBackend:
+    """Per-shard solver for the CPU test: the oracle's CG on numpy arrays (views share storage)."""
+
+    def __init__(self, oracle):
+        self.o = oracle
+
+    def calculate_yty(self, rows, gram, reg):
+        f = rows.shape[1]
+        gram[...] = self.o.gramian(np.ascontiguousarray(rows)) + np.float32(reg) * np.eye(f, dtype=np.float32)
+
+    def least_squares(self, C, X_rows, gram, Y, cg_steps):
+        assert X_rows.flags.c_contiguous and C.shape[0] == X_rows.shape[0]
+        self.o.least_squares_cg(C, X_rows, Y, 0.0, cg_steps=cg_steps, YtY=gram)
+
+    @staticmethod
+    def rows(M, start, stop):
+        return M[int(start):int(stop)]
+
+
+class GlooComm:
+    def __init__(self, dist, torch):
+        self.dist, self.torch = dist, torch
+        self.rank, self.nranks = dist.get_rank(), dist.get_world_size()
+
+    def allreduce_sum(self, M):
+        t = self.torch.from_numpy(M)
+        self.dist.all_reduce(t)
+
+    def allgather_rows(self, M, offs):
+        for r in range(self.nranks):
+            part = self.torch.from_numpy(M[int(offs[r]):int(offs[r + 1])])
+            self.dist.broadcast(part, src=r)
+
+    def barrier(self):
+        self.dist.barrier()
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.setdefault("OPENBLAS_NUM_THREADS", "4")
+    import torch
+    import torch.distributed as dist
+
+    from implicit_amd.gpu import sharded
+    from implicit_amd.synthetic import synthetic_csr
+    from oracle import oracle
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    f, reg = 32, 0.05
+    C = synthetic_csr(600, 400, 12_000, seed=8, neg_frac=0.05, empty_frac=0.02)
+    Ct = C.T.tocsr()
+    lens_u, lens_i = np.diff(C.indptr), np.diff(Ct.indptr)
+    u_off = sharded.shard_offsets(C.shape[0], world, weights=lens_u)
+    i_off = sharded.shard_offsets(Ct.shape[0], world, weights=lens_i)
+    rng = np.random.default_rng(3)
+    X = rng.random((600, f), dtype=np.float32) * 0.1 - 0.05
+    Y = rng.random((400, f), dtype=np.float32) * 0.1 - 0.05
+    Cui_shard = C[u_off[rank]:u_off[rank + 1]]
+    Ciu_shard = Ct[i_off[rank]:i_off[rank + 1]]
+    gram = np.zeros((f, f), dtype=np.float32)
+    comm = GlooComm(dist, torch)
+    backend = NumpyBackend(oracle)
+    for _ in range(3):
+        sharded.iteration(backend, comm, Cui_shard, Ciu_shard, X, Y, u_off, i_off, gram, reg, 3)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), X=X, Y=Y, u_off=u_off, i_off=i_off)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_two_rank_gloo_matches_single_process(tmp_path, oracle):
+    import torch.multiprocessing as mp
+
+    from implicit_amd.synthetic import synthetic_csr
+
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    np.testing.assert_array_equal(r0["X"], r1["X"])  # replicas identical bit for bit
+    np.testing.assert_array_equal(r0["Y"], r1["Y"])
+    assert 0 < r0["u_off"][1] < 600 and 0 < r0["i_off"][1] < 400
+
+    C = synthetic_csr(600, 400, 12_000, seed=8, neg_frac=0.05, empty_frac=0.02)
+    rng = np.random.default_rng(3)
+    X = rng.random((600, 32), dtype=np.float32) * 0.1 - 0.05
+    Y = rng.random((400, 32), dtype=np.float32) * 0.1 - 0.05
+    Xs, Ys = oracle.fit(C, 32, regularization=0.05, iterations=3, user_factors=X, item_factors=Y)
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)  # noqa: E731
+    assert rel(r0["X"], Xs) < 1e-5 and rel(r0["Y"], Ys) < 1e-5
+
+
+def test_shard_offsets_balance_by_weight():
+    from implicit_amd.gpu.sharded import shard_offsets
+
+    assert list(shard_offsets(10, 3)) == [0, 4, 7, 10]
+    w = np.array([100, 1, 1, 1, 1, 1, 1, 1, 1, 92])
+    offs = shard_offsets(10, 2, weights=w)
+    assert offs[0] == 0 and offs[-1] == 10 and 1 <= offs[1] <= 9
+    left, right = w[:offs[1]].sum(), w[offs[1]:].sum()
+    assert abs(left - right) <= 100
+    offs = shard_offsets(3, 8)  # more ranks than rows: empty shards are legal
+    assert offs[0] == 0 and offs[-1] == 3 and (np.diff(offs) >= 0).all()
