@@ -37,7 +37,6 @@ FACTORS = 128
 REG = 0.01
 CG_STEPS = 3
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured streaming ceiling)
-WAVE_ROW_MAX = int(os.environ.get("IMP_WAVE_ROW_MAX", "256"))
 
 
 def parse_args():
@@ -60,17 +59,21 @@ def cg_algorithmic_bytes(lengths, f):
     return nnz * (4 * f + 8) + rows * (8 * f + 8) + 4 * f * f
 
 
-def kernel_bytes_per_iteration(Cui, Ciu, f):
-    """Algorithmic bytes of the wave-per-row CG launches (one per half sweep) of one iteration."""
-    out = {"als_cg_wave_rows": 0, "als_cg_block_rows": 0}
+SHORT_ROW, LONG_ROW = 32, int(os.environ.get("IMP_LONG_ROW", "256"))  # imp_csr::kShortRow / kLongRow
+# schedule class -> the kernels that execute it (long rows: one partial + one combine launch per CG pass)
+CLASS_KERNELS = {"short": ["als_cg_short_rows"], "mid": ["als_cg_mid_rows"],
+                 "long": ["als_cg_long_partial", "als_cg_long_combine"]}
+
+
+def class_bytes_per_iteration(Cui, Ciu, f):
+    """Algorithmic bytes (single-pass traffic) of each row-length class over one iteration."""
+    out = {k: 0 for k in CLASS_KERNELS}
     for M in (Cui, Ciu):
         lens = np.diff(M.indptr)
-        wave = lens[(lens > 0) & (lens <= WAVE_ROW_MAX)]
-        block = lens[lens > WAVE_ROW_MAX]
-        if len(wave):
-            out["als_cg_wave_rows"] += cg_algorithmic_bytes(wave, f)
-        if len(block):
-            out["als_cg_block_rows"] += cg_algorithmic_bytes(block, f)
+        for name, sel in (("short", (lens > 0) & (lens <= SHORT_ROW)), ("mid", (lens > SHORT_ROW) & (lens <= LONG_ROW)),
+                          ("long", lens > LONG_ROW)):
+            if sel.any():
+                out[name] += cg_algorithmic_bytes(lens[sel], f)
     return out
 
 
@@ -192,21 +195,38 @@ def main():
     value = (users + items) / (elapsed / args.steps)
 
     # ---- roofline of the dominant kernel ----------------------------------------------------------
-    kbytes = kernel_bytes_per_iteration(Cui, Ciu, FACTORS)
+    cbytes = class_bytes_per_iteration(Cui, Ciu, FACTORS)
     kernels = {}
     for name in gpu.Profiler.names():
         ms, n = gpu.Profiler.get(name)
         kernels[name] = {"total_ms": ms, "launches": n}
-    dom = max(kernels, key=lambda k: kernels[k]["total_ms"])
+    classes = {}
+    for cname, knames in CLASS_KERNELS.items():
+        ms = sum(kernels.get(k, {"total_ms": 0})["total_ms"] for k in knames)
+        launches = sum(kernels.get(k, {"launches": 0})["launches"] for k in knames)
+        if ms > 0:
+            classes[cname] = {"ms_per_step": ms / args.steps, "launches_per_step": launches / args.steps,
+                              "algorithmic_GB_per_step": cbytes[cname] / 1e9,
+                              "achieved_GBps": cbytes[cname] * args.steps / (ms * 1e-3) / 1e9}
     roofline = None
-    if dom in kbytes and kernels[dom]["launches"]:
-        launches = kernels[dom]["launches"]
-        bytes_per_launch = kbytes[dom] / 2.0  # two launches (user side, item side) per iteration
-        avg_ms = kernels[dom]["total_ms"] / launches
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
-                    "algorithmic_bytes_per_launch": bytes_per_launch}
+    if classes:
+        dom = max(classes, key=lambda c: classes[c]["ms_per_step"])
+        d = classes[dom]
+        sweeps = 2 * args.steps  # the class runs once per half sweep
+        total_ms = d["ms_per_step"] * args.steps
+        bytes_per_sweep = cbytes[dom] / 2.0
+        roofline = {"bound": "hbm", "kernel": "+".join(CLASS_KERNELS[dom]), "row_class": dom,
+                    "achieved": d["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": d["achieved_GBps"] / HBM_PEAK_GBS, "traffic": None,
+                    "avg_launch_ms": total_ms / max(1, kernels[CLASS_KERNELS[dom][0]]["launches"]),
+                    "avg_ms_per_half_sweep": total_ms / sweeps,
+                    "algorithmic_bytes_per_half_sweep": bytes_per_sweep,
+                    "note": "achieved = algorithmic bytes of this row class per half sweep / HIP-event time of its "
+                            "launch(es) in that half sweep; whole-iteration figure in `iteration_roofline`"}
+    total_bytes = sum(cbytes.values())
+    iteration_roofline = {"algorithmic_GB_per_step": total_bytes / 1e9,
+                          "achieved_GBps": total_bytes / (elapsed / args.steps) / 1e9,
+                          "frac_of_8TBps": total_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS}
 
     out = {
         "metric": "ALS user+item updates/sec per iteration (factors=128)",
@@ -229,6 +249,8 @@ def main():
         },
         "nnz_visits_per_s": 2 * int(Cui.nnz) / (elapsed / args.steps),
         "roofline": roofline,
+        "iteration_roofline": iteration_roofline,
+        "row_classes": classes,
         "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in kernels.items()},
         "setup_s": {"generate": t_gen, "upload": t_upload},
     }

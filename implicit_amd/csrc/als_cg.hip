@@ -5,31 +5,38 @@
 // iterations, rsnew < 1e-20 break, empty rows zeroed.  It replaces the reference's CUDA launcher
 // and kernel (implicit/gpu/als.cu:23-111,154-197) behind LeastSquaresSolver::least_squares.
 //
-// MI355X mapping (not the reference's one-thread-per-factor block):
-//   * a 64-lane wavefront owns a row; lane l holds VPL consecutive factors of x, r, p, Ap in
-//     registers, so every gathered factor row Y[i,:] is ONE fully coalesced wave load
-//     (dwordx2 at f=128, dwordx4 at f=256) and the dot / axpy of the oracle's inner loop are
-//     2*VPL FMAs per lane plus one DPP wave reduction -- no LDS round trip, no block barrier per nnz
-//     (the reference does two __syncthreads per nnz, dot.cuh:27-59);
-//   * (YtY + reg I) is staged once per workgroup in LDS (64 KiB at f=128) and applied as a
-//     broadcast mat-vec: p_j comes from v_readlane, row j of the gramian from one conflict-free
-//     ds_read per lane;
-//   * rows are scheduled by length class (imp_csr::order): short rows one wave each, long rows one
-//     workgroup each with the nnz and the gramian rows split over its waves and the partial
-//     vectors combined through LDS in a fixed order (deterministic, identical in every wave).
+// MI355X mapping (not the reference's one-thread-per-factor block with a block reduction per nnz):
+//   * a 64-lane wavefront owns a row; lane l holds VPL consecutive factors of x, r, p, Ap in registers, so
+//     every gathered factor row Y[i,:] is ONE fully coalesced wave load (dwordx2 at f=128);
+//   * the nonzeros of a row are processed in TILES of T gathered rows held in registers: T partial dot
+//     products per lane are reduced with a butterfly REDUCE-SCATTER (v_permlane32_swap, v_permlane16_swap,
+//     then DPP row rotations) -- ~2.5 cross-lane instructions per dot instead of 7 -- the T weights are
+//     formed in the lanes that own them, broadcast with v_readlane and applied as T axpys;
+//   * rows with <= T nonzeros keep their gathered tile in registers across the 1+cg_steps passes, so
+//     their factor rows are read from memory exactly once (the roofline's single-pass traffic);
+//   * (YtY + reg I) is staged once per workgroup in LDS (64 KiB at f=128) and applied as a broadcast
+//     mat-vec: p_j from v_readlane, row j of the gramian from one conflict-free ds_read per lane;
+//   * rows are scheduled by length class (imp_csr::order): short (resident tile), mid (streamed
+//     tiles), and LONG rows (> kLongRow nnz) which are cut into segments: every CG pass becomes a
+//     segment-parallel partial kernel plus a per-row combine/update kernel, so a 150K-nnz row is
+//     spread over the whole chip instead of serialising one workgroup (fixed summation order).
+//   * any other f <= 512 runs a generic lane-strided variant of the same structure.
 #include "common.h"
 #include "wave_ops.h"
+#include "als_tile.h"
 
 namespace imp {
 
-// acc += A0[j0..j1) contribution of the symmetric mat-vec: acc[e] += sum_j A0[j][e] * vec[j]
+void least_squares_cg_group(const imp_csr *C, float *X, const float *Y, const float *A0, int f, int cg_steps);  // als_cg_group.hip
+
+// acc[e] += sum_{j in [j_begin, j_end)} A0[j][e] * vec[j]   (A0 symmetric)
 // A0s: LDS image (leading dimension LD = 64*VPL, zero padded) or the global f x f matrix (LD = f).
 template <int VPL, bool VEC>
 __device__ __forceinline__ void gram_matvec(const float *A0s, int LD, int lane, const float (&vec)[VPL],
                                             float (&acc)[VPL], int j_begin, int j_end) {
 #pragma unroll
   for (int v = 0; v < VPL; ++v) {
-    // j = elem(l, v): iterate over the lanes that own slot v
+#pragma unroll 4
     for (int l = 0; l < 64; ++l) {
       int j = VEC ? l * VPL + v : l + 64 * v;
       if (j < j_begin || j >= j_end) continue;  // wave-uniform
@@ -42,18 +49,16 @@ __device__ __forceinline__ void gram_matvec(const float *A0s, int LD, int lane, 
   }
 }
 
-// One pass over (a slice of) the row's nonzeros:  acc += sum_k w_k * y_k with
-//   FIRST : w = (c > 0 ? c : 0) - (|c| - 1) * (y_k . vec)      (_als.pyx:190-201)
-//   else  : w = (|c| - 1) * (y_k . vec)                         (_als.pyx:214-222)
+// ---- generic per-nnz pass (any f): 4 gathers in flight, one DPP all-reduce per dot -------------------
 template <int VPL, bool VEC, bool FIRST>
-__device__ __forceinline__ void sparse_pass(const int32_t *__restrict__ indices, const float *__restrict__ data,
-                                            const float *__restrict__ Y, int f, int lane, int begin, int end,
-                                            int chunk_stride, const float (&vec)[VPL], float (&acc)[VPL]) {
+__device__ __forceinline__ void sparse_pass_simple(const int32_t *__restrict__ indices, const float *__restrict__ data,
+                                                   const float *__restrict__ Y, int f, int lane, int begin, int end,
+                                                   const float (&vec)[VPL], float (&acc)[VPL]) {
   constexpr int U = 4;
-  for (int k0 = begin; k0 < end; k0 += chunk_stride) {
+  for (int k0 = begin; k0 < end; k0 += 64) {
     int cnt = min(64, end - k0);
     int my_idx = 0;
-    float my_c = 1.f;  // |c| - 1 = 0 and c > 0 ... neutralised below through the count guard
+    float my_c = 0.f;
     if (lane < cnt) {
       my_idx = indices[k0 + lane];
       my_c = data[k0 + lane];
@@ -72,16 +77,7 @@ __device__ __forceinline__ void sparse_pass(const int32_t *__restrict__ indices,
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (j + u < cnt) {  // wave-uniform
-          float c = lane_bcast(my_c, j + u);
-          float w;
-          if (FIRST) {
-            float t = c > 0.f ? c : 0.f;
-            float a = c > 0.f ? c : -c;
-            w = t - (a - 1.f) * d[u];
-          } else {
-            float a = c < 0.f ? -c : c;
-            w = (a - 1.f) * d[u];
-          }
+          float w = nnz_weight<FIRST>(lane_bcast(my_c, j + u), d[u]);
 #pragma unroll
           for (int v = 0; v < VPL; ++v) acc[v] = fmaf(w, y[u][v], acc[v]);
         }
@@ -90,28 +86,35 @@ __device__ __forceinline__ void sparse_pass(const int32_t *__restrict__ indices,
   }
 }
 
-// Fixed-order sum of the WPR per-wave partial vectors through LDS; every wave ends with the same bits.
-template <int VPL, int WPR>
-__device__ __forceinline__ void combine(float *scratch, int wave, int lane, float (&acc)[VPL]) {
-  if constexpr (WPR > 1) {
-    constexpr int LD = 64 * VPL;
-    __syncthreads();  // previous readers done
-#pragma unroll
-    for (int v = 0; v < VPL; ++v) scratch[wave * LD + lane * VPL + v] = acc[v];
-    __syncthreads();
-#pragma unroll
-    for (int v = 0; v < VPL; ++v) {
-      float s = 0.f;
-#pragma unroll
-      for (int w = 0; w < WPR; ++w) s += scratch[w * LD + lane * VPL + v];
-      acc[v] = s;
+template <int VPL, bool VEC, bool FIRST>
+__device__ __forceinline__ void sparse_pass(const int32_t *__restrict__ indices, const float *__restrict__ data,
+                                            const float *__restrict__ Y, int f, int lane, int begin, int end,
+                                            const float (&vec)[VPL], float (&acc)[VPL]) {
+  if constexpr (VEC)
+    sparse_pass_tiled<VPL, tile_size<VPL>(), FIRST>(indices, data, Y, f, lane, begin, end, vec, acc);
+  else
+    sparse_pass_simple<VPL, VEC, FIRST>(indices, data, Y, f, lane, begin, end, vec, acc);
+}
+
+template <int VPL, bool VEC, int BLOCK, bool A_LDS>
+__device__ __forceinline__ const float *stage_gramian(float *smem, const float *__restrict__ A0, int f) {
+  constexpr int LD = 64 * VPL;
+  if constexpr (A_LDS) {
+    for (int i = threadIdx.x; i < f * LD; i += BLOCK) {
+      int r = i / LD, c = i - r * LD;
+      smem[i] = c < f ? A0[(size_t)r * f + c] : 0.f;
     }
+    __syncthreads();
+    return smem;
+  } else {
+    return A0;
   }
 }
 
-// BLOCK threads; WPR waves cooperate on one row (WPR == 1: each wave walks its own rows).
-template <int VPL, bool VEC, int WPR, int BLOCK, bool A_LDS>
-__global__ __launch_bounds__(BLOCK) void als_cg_kernel(const int32_t *__restrict__ order, int first, int count,
+// ---- fused kernel: one wavefront per row, rows [first, first+count) of the schedule -------------------------
+// RESIDENT: every row has <= T nonzeros and its gathered tile stays in registers across all passes.
+template <int VPL, bool VEC, int BLOCK, bool A_LDS, bool RESIDENT>
+__global__ __launch_bounds__(BLOCK, (A_LDS && VPL == 2) ? 4 : 2) void als_cg_kernel(const int32_t *__restrict__ order, int first, int count,
                                                        const int32_t *__restrict__ indptr,
                                                        const int32_t *__restrict__ indices,
                                                        const float *__restrict__ data, float *__restrict__ X,
@@ -119,32 +122,14 @@ __global__ __launch_bounds__(BLOCK) void als_cg_kernel(const int32_t *__restrict
                                                        int f, int cg_steps) {
   constexpr int LD = 64 * VPL;
   constexpr int WAVES = BLOCK / 64;
-  constexpr int GROUPS = WAVES / WPR;  // rows in flight per block
+  constexpr int T = tile_size<VPL>();
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *A0s = smem;                                   // [f][LD] when A_LDS
-  float *scratch = smem + (A_LDS ? (size_t)f * LD : 0);  // [GROUPS][WPR][LD]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int group = wave / WPR, sub = wave % WPR;
-
-  const float *Amat;
-  if constexpr (A_LDS) {
-    for (int i = threadIdx.x; i < f * LD; i += BLOCK) {
-      int r = i / LD, c = i - r * LD;
-      A0s[i] = c < f ? A0[(size_t)r * f + c] : 0.f;
-    }
-    __syncthreads();
-    Amat = A0s;
-  } else {
-    Amat = A0;
-  }
+  const float *Amat = stage_gramian<VPL, VEC, BLOCK, A_LDS>(smem, A0, f);
   const int lda = A_LDS ? LD : f;
-  float *my_scratch = scratch + (size_t)group * WPR * LD;
 
-  // gramian rows handled by this wave in the dense mat-vec
-  const int j_begin = (int)((long)f * sub / WPR), j_end = (int)((long)f * (sub + 1) / WPR);
-
-  for (int i = blockIdx.x * GROUPS + group; i < count; i += gridDim.x * GROUPS) {
+  for (int i = blockIdx.x * WAVES + wave; i < count; i += gridDim.x * WAVES) {
     const int u = __builtin_amdgcn_readfirstlane(order[first + i]);
     const int row_begin = __builtin_amdgcn_readfirstlane(indptr[u]);
     const int row_end = __builtin_amdgcn_readfirstlane(indptr[u + 1]);
@@ -152,14 +137,19 @@ __global__ __launch_bounds__(BLOCK) void als_cg_kernel(const int32_t *__restrict
     float x[VPL], r[VPL], p[VPL], Ap[VPL];
     load_row<VPL, VEC>(xrow, f, lane, x);
 
+    Tile<VPL, T> tile;
+    if constexpr (RESIDENT) load_tile<VPL, T>(tile, indices, data, Y, f, lane, row_begin, row_end);
+
     // r = -(A0 x) + sum_k (c+ - (|c|-1) y.x) y        (_als.pyx:187-201)
 #pragma unroll
     for (int v = 0; v < VPL; ++v) Ap[v] = 0.f;
-    gram_matvec<VPL, VEC>(Amat, lda, lane, x, Ap, j_begin, j_end);
+    gram_matvec<VPL, VEC>(Amat, lda, lane, x, Ap, 0, f);
 #pragma unroll
     for (int v = 0; v < VPL; ++v) r[v] = -Ap[v];
-    sparse_pass<VPL, VEC, true>(indices, data, Y, f, lane, row_begin + sub * 64, row_end, 64 * WPR, x, r);
-    combine<VPL, WPR>(my_scratch, sub, lane, r);
+    if constexpr (RESIDENT)
+      tile_apply<VPL, T, true>(tile, lane, row_begin, row_end, x, r);
+    else
+      sparse_pass<VPL, VEC, true>(indices, data, Y, f, lane, row_begin, row_end, x, r);
 
 #pragma unroll
     for (int v = 0; v < VPL; ++v) p[v] = r[v];
@@ -168,9 +158,11 @@ __global__ __launch_bounds__(BLOCK) void als_cg_kernel(const int32_t *__restrict
       for (int it = 0; it < cg_steps; ++it) {
 #pragma unroll
         for (int v = 0; v < VPL; ++v) Ap[v] = 0.f;
-        gram_matvec<VPL, VEC>(Amat, lda, lane, p, Ap, j_begin, j_end);
-        sparse_pass<VPL, VEC, false>(indices, data, Y, f, lane, row_begin + sub * 64, row_end, 64 * WPR, p, Ap);
-        combine<VPL, WPR>(my_scratch, sub, lane, Ap);
+        gram_matvec<VPL, VEC>(Amat, lda, lane, p, Ap, 0, f);
+        if constexpr (RESIDENT)
+          tile_apply<VPL, T, false>(tile, lane, row_begin, row_end, p, Ap);
+        else
+          sparse_pass<VPL, VEC, false>(indices, data, Y, f, lane, row_begin, row_end, p, Ap);
 
         float alpha = rsold / wave_allsum(dot_local<VPL>(p, Ap));
 #pragma unroll
@@ -185,12 +177,122 @@ __global__ __launch_bounds__(BLOCK) void als_cg_kernel(const int32_t *__restrict
         for (int v = 0; v < VPL; ++v) p[v] = fmaf(beta, p[v], r[v]);
         rsold = rsnew;
       }
-      if (sub == 0) {
 #pragma unroll
-        for (int v = 0; v < VPL; ++v) {
-          int e = elem<VPL, VEC>(lane, v);
-          if (e < f) xrow[e] = x[v];
-        }
+      for (int v = 0; v < VPL; ++v) {
+        int e = elem<VPL, VEC>(lane, v);
+        if (e < f) xrow[e] = x[v];
+      }
+    }
+  }
+}
+
+// ---- long rows: every CG pass = segment-parallel partial kernel + per-row combine/update kernel -------------
+// workspace (floats): partial[n_seg][LD] | rvec[n_long][LD] | pvec[n_long][LD] | scal[n_long][2] (rsold, done)
+template <int VPL, bool VEC, bool FIRST>
+__global__ __launch_bounds__(256) void cg_long_partial_kernel(const LongPlanDev plan, const int32_t *__restrict__ indices,
+                                                              const float *__restrict__ data, const float *__restrict__ X,
+                                                              const float *__restrict__ Y, int f, float *__restrict__ partial,
+                                                              const float *__restrict__ pvec, const float *__restrict__ scal) {
+  constexpr int LD = 64 * VPL;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int s = wave; s < plan.n_seg; s += nwaves) {
+    const int li = __builtin_amdgcn_readfirstlane(plan.seg_row[s]);
+    if (!FIRST && scal[2 * li + 1] != 0.f) continue;  // row finished (early exit)
+    const int begin = __builtin_amdgcn_readfirstlane(plan.seg_begin[s]);
+    const int end = __builtin_amdgcn_readfirstlane(plan.seg_end[s]);
+    float vec[VPL], acc[VPL];
+    if (FIRST)
+      load_row<VPL, VEC>(X + (size_t)plan.rows[li] * f, f, lane, vec);
+    else
+      load_row<VPL, VEC>(pvec + (size_t)li * LD, VEC ? LD : f, lane, vec);
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) acc[v] = 0.f;
+    sparse_pass<VPL, VEC, FIRST>(indices, data, Y, f, lane, begin, end, vec, acc);
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      int e = elem<VPL, VEC>(lane, v);
+      partial[(size_t)s * LD + e] = acc[v];
+    }
+  }
+}
+
+// PHASE 0: r = sum(partials) - A0 x ; p = r ; rsold = r.r ; done = rsold < 1e-20
+// PHASE 1: Ap = sum(partials) + A0 p ; alpha ; x += alpha p ; r -= alpha Ap ; rsnew ; done |= rsnew < 1e-20 ; p = r + beta p
+template <int VPL, bool VEC, int BLOCK, bool A_LDS, int PHASE>
+__global__ __launch_bounds__(BLOCK) void cg_long_combine_kernel(const LongPlanDev plan, float *__restrict__ X,
+                                                                const float *__restrict__ A0, int f,
+                                                                const float *__restrict__ partial, float *__restrict__ rvec,
+                                                                float *__restrict__ pvec, float *__restrict__ scal) {
+  constexpr int LD = 64 * VPL;
+  constexpr int WAVES = BLOCK / 64;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const float *Amat = stage_gramian<VPL, VEC, BLOCK, A_LDS>(smem, A0, f);
+  const int lda = A_LDS ? LD : f;
+  const int vld = VEC ? LD : f;  // logical length for guarded loads from the LD-strided workspaces
+  for (int li = blockIdx.x * WAVES + wave; li < plan.n_long; li += gridDim.x * WAVES) {
+    if (PHASE == 1 && scal[2 * li + 1] != 0.f) continue;
+    float *xrow = X + (size_t)plan.rows[li] * f;
+    float acc[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) acc[v] = 0.f;
+    const int s0 = plan.row_seg[li], s1 = plan.row_seg[li + 1];
+    for (int s = s0; s < s1; ++s) {  // fixed order
+      float t[VPL];
+      load_row<VPL, VEC>(partial + (size_t)s * LD, vld, lane, t);
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) acc[v] += t[v];
+    }
+    float x[VPL], dense[VPL];
+    load_row<VPL, VEC>(xrow, f, lane, x);
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) dense[v] = 0.f;
+    if (PHASE == 0) {
+      gram_matvec<VPL, VEC>(Amat, lda, lane, x, dense, 0, f);
+      float r[VPL];
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) r[v] = acc[v] - dense[v];
+      float rsold = wave_allsum(dot_local<VPL>(r, r));
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        int e = elem<VPL, VEC>(lane, v);
+        rvec[(size_t)li * LD + e] = r[v];
+        pvec[(size_t)li * LD + e] = r[v];
+      }
+      if (lane == 0) {
+        scal[2 * li] = rsold;
+        scal[2 * li + 1] = rsold < 1e-20f ? 1.f : 0.f;
+      }
+    } else {
+      float p[VPL], r[VPL];
+      load_row<VPL, VEC>(pvec + (size_t)li * LD, vld, lane, p);
+      load_row<VPL, VEC>(rvec + (size_t)li * LD, vld, lane, r);
+      gram_matvec<VPL, VEC>(Amat, lda, lane, p, dense, 0, f);
+      float Ap[VPL];
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) Ap[v] = dense[v] + acc[v];
+      float rsold = scal[2 * li];
+      float alpha = rsold / wave_allsum(dot_local<VPL>(p, Ap));
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        x[v] = fmaf(alpha, p[v], x[v]);
+        r[v] = fmaf(-alpha, Ap[v], r[v]);
+      }
+      float rsnew = wave_allsum(dot_local<VPL>(r, r));
+      float beta = rsnew / rsold;
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        int e = elem<VPL, VEC>(lane, v);
+        if (e < f) xrow[e] = x[v];
+        rvec[(size_t)li * LD + e] = r[v];
+        pvec[(size_t)li * LD + e] = fmaf(beta, p[v], r[v]);
+      }
+      if (lane == 0) {
+        scal[2 * li] = rsnew;
+        if (rsnew < 1e-20f) scal[2 * li + 1] = 1.f;
       }
     }
   }
@@ -213,32 +315,99 @@ void zero_rows(const int32_t *order, int first, int count, float *X, int f) {
   IMP_CHECK_HIP(hipGetLastError());
 }
 
-template <int VPL, bool VEC, int WPR, int BLOCK, bool A_LDS>
-static void launch_bin(const imp_csr *C, int first, int count, float *X, const float *Y, const float *A0, int f,
-                       int cg_steps, const char *name) {
+static DeviceArray<float> &long_workspace() {
+  static DeviceArray<float> *ws = new DeviceArray<float>;  // leaked on purpose (no hipFree at exit)
+  return *ws;
+}
+
+template <int VPL, bool VEC, bool A_LDS, bool RESIDENT>
+static void launch_fused(const imp_csr *C, int first, int count, float *X, const float *Y, const float *A0, int f,
+                         int cg_steps, const char *name) {
   if (count <= 0) return;
+  constexpr int BLOCK = 512;
   constexpr int LD = 64 * VPL;
-  constexpr int GROUPS = (BLOCK / 64) / WPR;
-  size_t lds = (A_LDS ? (size_t)f * LD : 0) * sizeof(float) + (size_t)(BLOCK / 64) * LD * sizeof(float);
-  auto kern = als_cg_kernel<VPL, VEC, WPR, BLOCK, A_LDS>;
-  IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  int blocks_per_cu = std::max<size_t>(1, std::min<size_t>(2048 / BLOCK, (160 * 1024) / std::max<size_t>(lds, 1)));
-  int grid = std::min((count + GROUPS - 1) / GROUPS, ctx().num_cus * blocks_per_cu);
+  size_t lds = (A_LDS ? (size_t)f * LD : 0) * sizeof(float);
+  auto kern = als_cg_kernel<VPL, VEC, BLOCK, A_LDS, RESIDENT>;
+  IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)std::max<size_t>(lds, 16)));
+  int blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / BLOCK, (160 * 1024) / std::max<size_t>(lds, 1)));
+  int grid = std::min((count + BLOCK / 64 - 1) / (BLOCK / 64), ctx().num_cus * blocks_per_cu);
   IMP_PROF(name);
-  kern<<<grid, BLOCK, lds, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(),
-                                       C->data.data(), X, Y, A0, f, cg_steps);
+  kern<<<grid, BLOCK, lds, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(), C->data.data(), X, Y,
+                                       A0, f, cg_steps);
   IMP_CHECK_HIP(hipGetLastError());
 }
 
 template <int VPL, bool VEC, bool A_LDS>
-static void launch_all(const imp_csr *C, float *X, const float *Y, const float *A0, int f, int cg_steps) {
+static void launch_long(const imp_csr *C, float *X, const float *Y, const float *A0, int f, int cg_steps) {
+  const int n_long = C->n_long, n_seg = C->n_seg;
+  if (n_long <= 0) return;
   constexpr int BLOCK = 512;
-  // bin 0: long rows, one workgroup per row; bin 1: one wave per row; bin 2: empty rows
-  launch_bin<VPL, VEC, BLOCK / 64, BLOCK, A_LDS>(C, C->bin_start[0], C->bin_start[1] - C->bin_start[0], X, Y, A0, f,
-                                                 cg_steps, "als_cg_block_rows");
-  launch_bin<VPL, VEC, 1, BLOCK, A_LDS>(C, C->bin_start[1], C->bin_start[2] - C->bin_start[1], X, Y, A0, f, cg_steps,
-                                        "als_cg_wave_rows");
-  zero_rows(C->order.data(), C->bin_start[2], C->bin_start[3] - C->bin_start[2], X, f);
+  constexpr int LD = 64 * VPL;
+  size_t need = ((size_t)n_seg + 2 * (size_t)n_long) * LD + 2 * (size_t)n_long;
+  auto &ws = long_workspace();
+  if (ws.size < need) ws.alloc(need);
+  float *partial = ws.data();
+  float *rvec = partial + (size_t)n_seg * LD;
+  float *pvec = rvec + (size_t)n_long * LD;
+  float *scal = pvec + (size_t)n_long * LD;
+  LongPlanDev plan = C->long_plan_dev();
+
+  size_t lds = (A_LDS ? (size_t)f * LD : 0) * sizeof(float);
+  auto comb0 = cg_long_combine_kernel<VPL, VEC, BLOCK, A_LDS, 0>;
+  auto comb1 = cg_long_combine_kernel<VPL, VEC, BLOCK, A_LDS, 1>;
+  IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(comb0), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)std::max<size_t>(lds, 16)));
+  IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(comb1), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)std::max<size_t>(lds, 16)));
+  int grid_part = std::min((n_seg + 3) / 4, ctx().num_cus * 8);
+  int grid_comb = std::min((n_long + BLOCK / 64 - 1) / (BLOCK / 64), ctx().num_cus * 2);
+  {
+    IMP_PROF("als_cg_long_partial");
+    cg_long_partial_kernel<VPL, VEC, true>
+        <<<grid_part, 256, 0, stream()>>>(plan, C->indices.data(), C->data.data(), X, Y, f, partial, pvec, scal);
+    IMP_CHECK_HIP(hipGetLastError());
+  }
+  {
+    IMP_PROF("als_cg_long_combine");
+    comb0<<<grid_comb, BLOCK, lds, stream()>>>(plan, X, A0, f, partial, rvec, pvec, scal);
+    IMP_CHECK_HIP(hipGetLastError());
+  }
+  for (int it = 0; it < cg_steps; ++it) {
+    {
+      IMP_PROF("als_cg_long_partial");
+      cg_long_partial_kernel<VPL, VEC, false>
+          <<<grid_part, 256, 0, stream()>>>(plan, C->indices.data(), C->data.data(), X, Y, f, partial, pvec, scal);
+      IMP_CHECK_HIP(hipGetLastError());
+    }
+    {
+      IMP_PROF("als_cg_long_combine");
+      comb1<<<grid_comb, BLOCK, lds, stream()>>>(plan, X, A0, f, partial, rvec, pvec, scal);
+      IMP_CHECK_HIP(hipGetLastError());
+    }
+  }
+}
+
+template <int VPL, bool VEC, bool A_LDS>
+static void launch_all(const imp_csr *C, float *X, const float *Y, const float *A0, int f, int cg_steps) {
+  // schedule classes: 0 long (segment-split), 1 mid (streamed tiles), 2 short (resident tile), 3 empty
+  const int32_t *b = C->bin_start;
+  launch_long<VPL, VEC, A_LDS>(C, X, Y, A0, f, cg_steps);
+  static const bool no_group = getenv("IMP_NO_GROUP") != nullptr;  // A/B switch: per-wave VALU gramian product
+  if (VEC && A_LDS && (f == 64 || f == 128) && !no_group) {
+    least_squares_cg_group(C, X, Y, A0, f, cg_steps);  // 16 rows per workgroup, gramian product on MFMA
+  } else {
+    bool resident_ok = false;
+    if constexpr (VEC) resident_ok = tile_size<VPL>() >= imp_csr::kShortRow;
+    if constexpr (VEC) {
+      if (resident_ok) {
+        launch_fused<VPL, VEC, A_LDS, false>(C, b[1], b[2] - b[1], X, Y, A0, f, cg_steps, "als_cg_mid_rows");
+        launch_fused<VPL, VEC, A_LDS, true>(C, b[2], b[3] - b[2], X, Y, A0, f, cg_steps, "als_cg_short_rows");
+      }
+    }
+    if (!resident_ok) launch_fused<VPL, VEC, A_LDS, false>(C, b[1], b[3] - b[1], X, Y, A0, f, cg_steps, "als_cg_mid_rows");
+  }
+  zero_rows(C->order.data(), b[3], b[4] - b[3], X, f);
 }
 
 void least_squares_cg(const imp_csr *C, imp_matrix *X, const imp_matrix *YtY, const imp_matrix *Y, int cg_steps) {

@@ -1,0 +1,185 @@
+// K1g: CG half sweep for f = 64 / 128 with the dense (YtY + reg I) . p product on the matrix cores.
+//
+// Same arithmetic contract as als_cg.hip (oracle: implicit/cpu/_als.pyx:152-248).  At f = 128 and the
+// typical ~50 nonzeros per row, the f x f gramian product is MORE than half of the FMAs of a row
+// (f^2 vs 2 n f per pass), and as a per-wave broadcast mat-vec it costs ~5 VALU/LDS instructions per
+// gramian row.  Here a 1024-thread workgroup owns SIXTEEN rows (one wavefront each, consecutive in the
+// length-sorted schedule so they have almost the same nnz) and runs them in lockstep:
+//
+//   every pass:  each wave writes its vector (x or p) into LDS  P[16][f]            -> barrier
+//                D[f][16] = A0 . P^T  with v_mfma_f32_16x16x4_f32 (exact fp32):      the f/16 output tiles x
+//                the 16/(f/16) K-slices are dealt to the 16 waves, A0 and P fragments are ds_read_b128
+//                (4 consecutive k per lane: the k index is permuted identically for both operands),
+//                partial tiles go to LDS  Out[KH][16][f]                              -> barrier
+//                each wave reads its row of Out (sum of the KH K-slices) back in its own
+//                lane-owns-2-factors layout and continues with the sparse part (als_tile.h).
+//
+// Early exits of the oracle (rsold < 1e-20, rsnew < 1e-20) become per-wave `active` predicates so that
+// all waves execute the same barriers.  LDS: A0 (f x (f+8), conflict-free b128 fragment reads) + P + Out
+// = 95 KiB at f = 128 -> one 16-wave workgroup per CU.
+#include "als_tile.h"
+#include "common.h"
+
+namespace imp {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int F> struct GroupCfg {
+  static constexpr int VPL = F / 64;
+  static constexpr int LD = F + 8;          // leading dimension of A0 / P / Out rows in LDS (floats)
+  static constexpr int NT = F / 16;         // 16-factor output tiles
+  static constexpr int KH = 16 / NT;        // K-slices so that NT * KH == 16 waves
+  static constexpr int KB = (F / 16) / KH;  // 16-factor k-blocks per wave
+  static constexpr size_t lds_floats = (size_t)F * LD + 16 * LD + (size_t)KH * 16 * LD;
+};
+
+// acc <- (A0 . vec) for this wave's row; all 16 waves of the block must call it together.
+template <int F>
+__device__ __forceinline__ void group_gram_matvec(const float *A0s, float *Ps, float *Outs, int wave, int lane, bool valid,
+                                                  const float (&vec)[F / 64], float (&out)[F / 64]) {
+  using Cfg = GroupCfg<F>;
+  constexpr int VPL = Cfg::VPL, LD = Cfg::LD;
+  // publish this row's vector (zeros for idle waves so their columns stay finite)
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) Ps[wave * LD + lane * VPL + v] = valid ? vec[v] : 0.f;
+  __syncthreads();
+  const int ti = wave % Cfg::NT, kh = wave / Cfg::NT;
+  const int i = lane & 15, kq = lane >> 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kb = 0; kb < Cfg::KB; ++kb) {
+    const int k0 = (kh * Cfg::KB + kb) * 16 + 4 * kq;
+    const float4 a = *reinterpret_cast<const float4 *>(A0s + (16 * ti + i) * LD + k0);
+    const float4 b = *reinterpret_cast<const float4 *>(Ps + i * LD + k0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+  }
+  // D tile: column = lane & 15 (row of the group), rows 4*(lane>>4) + reg (factor within the tile)
+  *reinterpret_cast<float4 *>(Outs + (kh * 16 + i) * LD + 16 * ti + 4 * kq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  __syncthreads();
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    float s = 0.f;
+#pragma unroll
+    for (int h = 0; h < Cfg::KH; ++h) s += Outs[(h * 16 + wave) * LD + lane * VPL + v];
+    out[v] = s;
+  }
+}
+
+template <int F, bool RESIDENT>
+__global__ __launch_bounds__(1024) void als_cg_group_kernel(const int32_t *__restrict__ order, int first, int count,
+                                                            const int32_t *__restrict__ indptr,
+                                                            const int32_t *__restrict__ indices,
+                                                            const float *__restrict__ data, float *__restrict__ X,
+                                                            const float *__restrict__ Y, const float *__restrict__ A0,
+                                                            int cg_steps) {
+  using Cfg = GroupCfg<F>;
+  constexpr int VPL = Cfg::VPL, LD = Cfg::LD, T = 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *A0s = smem;
+  float *Ps = A0s + (size_t)F * LD;
+  float *Outs = Ps + 16 * LD;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int e = threadIdx.x; e < F * F; e += 1024) {
+    int r = e / F, c = e - r * F;
+    A0s[r * LD + c] = A0[e];
+  }
+  __syncthreads();
+
+  const int groups = (count + 15) / 16;
+  for (int g = blockIdx.x; g < groups; g += gridDim.x) {
+    const int i = g * 16 + wave;
+    const bool valid = i < count;
+    int u = 0, row_begin = 0, row_end = 0;
+    if (valid) {
+      u = __builtin_amdgcn_readfirstlane(order[first + i]);
+      row_begin = __builtin_amdgcn_readfirstlane(indptr[u]);
+      row_end = __builtin_amdgcn_readfirstlane(indptr[u + 1]);
+    }
+    float *xrow = X + (size_t)u * F;
+    float x[VPL], r[VPL], p[VPL], Ap[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) x[v] = 0.f;
+    if (valid) load_row<VPL, true>(xrow, F, lane, x);
+
+    Tile<VPL, T> tile;
+    if constexpr (RESIDENT) load_tile<VPL, T>(tile, indices, data, Y, F, lane, row_begin, row_end);
+
+    // r = -(A0 x) + sum_k (c+ - (|c|-1) y.x) y        (_als.pyx:187-201)
+    group_gram_matvec<F>(A0s, Ps, Outs, wave, lane, valid, x, Ap);
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) r[v] = -Ap[v];
+    if constexpr (RESIDENT)
+      tile_apply<VPL, T, true>(tile, lane, row_begin, row_end, x, r);
+    else
+      sparse_pass_tiled<VPL, T, true>(indices, data, Y, F, lane, row_begin, row_end, x, r);
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) p[v] = r[v];
+    float rsold = wave_allsum(dot_local<VPL>(r, r));
+    bool active = valid && rsold >= 1e-20f;  // else: x untouched (_als.pyx:206)
+    const bool store = active;
+
+    for (int it = 0; it < cg_steps; ++it) {
+      group_gram_matvec<F>(A0s, Ps, Outs, wave, lane, active, p, Ap);
+      if (active) {  // wave-uniform
+        if constexpr (RESIDENT)
+          tile_apply<VPL, T, false>(tile, lane, row_begin, row_end, p, Ap);
+        else
+          sparse_pass_tiled<VPL, T, false>(indices, data, Y, F, lane, row_begin, row_end, p, Ap);
+        float alpha = rsold / wave_allsum(dot_local<VPL>(p, Ap));
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          x[v] = fmaf(alpha, p[v], x[v]);
+          r[v] = fmaf(-alpha, Ap[v], r[v]);
+        }
+        float rsnew = wave_allsum(dot_local<VPL>(r, r));
+        if (rsnew < 1e-20f) {
+          active = false;  // the oracle breaks here (_als.pyx:235); keep taking the barriers
+        } else {
+          float beta = rsnew / rsold;
+#pragma unroll
+          for (int v = 0; v < VPL; ++v) p[v] = fmaf(beta, p[v], r[v]);
+          rsold = rsnew;
+        }
+      }
+    }
+    if (store) {
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) xrow[lane * VPL + v] = x[v];
+    }
+  }
+}
+
+template <int F, bool RESIDENT>
+static void launch_group(const imp_csr *C, int first, int count, float *X, const float *Y, const float *A0, int cg_steps,
+                         const char *name) {
+  if (count <= 0) return;
+  size_t lds = GroupCfg<F>::lds_floats * sizeof(float);
+  auto kern = als_cg_group_kernel<F, RESIDENT>;
+  IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / lds));
+  int grid = std::min((count + 15) / 16, ctx().num_cus * per_cu);
+  IMP_PROF(name);
+  kern<<<grid, 1024, lds, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(), C->data.data(), X, Y, A0,
+                                      cg_steps);
+  IMP_CHECK_HIP(hipGetLastError());
+}
+
+// mid (streamed tiles) and short (resident tile) row classes of a CSR for f = 64 or 128
+void least_squares_cg_group(const imp_csr *C, float *X, const float *Y, const float *A0, int f, int cg_steps) {
+  const int32_t *b = C->bin_start;
+  if (f == 128) {
+    launch_group<128, false>(C, b[1], b[2] - b[1], X, Y, A0, cg_steps, "als_cg_mid_rows");
+    launch_group<128, true>(C, b[2], b[3] - b[2], X, Y, A0, cg_steps, "als_cg_short_rows");
+  } else if (f == 64) {
+    launch_group<64, false>(C, b[1], b[2] - b[1], X, Y, A0, cg_steps, "als_cg_mid_rows");
+    launch_group<64, true>(C, b[2], b[3] - b[2], X, Y, A0, cg_steps, "als_cg_short_rows");
+  } else {
+    throw std::invalid_argument("least_squares_cg_group: f must be 64 or 128");
+  }
+}
+
+}  // namespace imp

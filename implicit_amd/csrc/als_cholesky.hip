@@ -140,7 +140,7 @@ int64_t least_squares_cholesky(const imp_csr *C, imp_matrix *X, const imp_matrix
   size_t lds = ((size_t)(f + 1) * lda + (size_t)kCholTile * f + (size_t)kCholTile * (f + 1)) * sizeof(float);
   if (!g_failed) IMP_CHECK_HIP(hipMalloc(&g_failed, sizeof(unsigned long long)));
   IMP_CHECK_HIP(hipMemsetAsync(g_failed, 0xFF, sizeof(unsigned long long), stream()));
-  int nonempty = C->bin_start[2];
+  int nonempty = C->nonempty();
   if (nonempty > 0) {
     IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(als_cholesky_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -152,7 +152,7 @@ int64_t least_squares_cholesky(const imp_csr *C, imp_matrix *X, const imp_matrix
                                                       g_failed);
     IMP_CHECK_HIP(hipGetLastError());
   }
-  zero_rows(C->order.data(), C->bin_start[2], C->bin_start[3] - C->bin_start[2], X->f32(), f);
+  zero_rows(C->order.data(), C->bin_start[3], C->bin_start[4] - C->bin_start[3], X->f32(), f);
   unsigned long long failed = 0;
   IMP_CHECK_HIP(hipMemcpyAsync(&failed, g_failed, sizeof(failed), hipMemcpyDeviceToHost, stream()));
   sync();

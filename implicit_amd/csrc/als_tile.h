@@ -1,0 +1,112 @@
+// Register-tile building blocks of the CG kernels (shared by als_cg.hip and als_cg_group.hip).
+#ifndef IMPLICIT_AMD_CSRC_ALS_TILE_H_
+#define IMPLICIT_AMD_CSRC_ALS_TILE_H_
+#include "wave_ops.h"
+
+namespace imp {
+
+// w_k of one nonzero:  FIRST: (c > 0 ? c : 0) - (|c| - 1) * d   (_als.pyx:190-201)
+//                      else : (|c| - 1) * d                      (_als.pyx:214-222)
+template <bool FIRST> __device__ __forceinline__ float nnz_weight(float c, float d) {
+  float a = c > 0.f ? c : -c;
+  float t = (FIRST && c > 0.f) ? c : 0.f;
+  return FIRST ? t - (a - 1.f) * d : (a - 1.f) * d;
+}
+
+// ---- tiled pass (vector layouts f = 64, 128, 256) ----------------------------------------------------------
+// T gathered rows live in registers.  After the reduce-scatter lane (16-lane row r, slot j) owns the dot
+// product of tile entry t = J*r + j, J = T/4.
+__device__ __forceinline__ float swap32_sum(float a, float b) {
+  // lanes 0-31 get a[l] + a[l+32]; lanes 32-63 get b[l-32] + b[l]
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+__device__ __forceinline__ float swap16_sum(float a, float b) {
+  // even 16-lane rows get a[row] + a[row+1]; odd rows get b[row-1] + b[row]
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+__device__ __forceinline__ float row_allsum(float v) {
+  v += dpp_mov<0x128>(v);  // row_ror:8
+  v += dpp_mov<0x124>(v);  // row_ror:4
+  v += dpp_mov<0x122>(v);  // row_ror:2
+  v += dpp_mov<0x121>(v);  // row_ror:1
+  return v;
+}
+
+template <int VPL, int T> struct Tile {
+  float y[T][VPL];   // gathered factor rows (zero beyond cnt)
+  float c[T / 4];    // confidences of the entries this lane's row owns after the reduce-scatter
+  int cnt;           // valid entries (wave-uniform)
+};
+
+template <int VPL, int T>
+__device__ __forceinline__ void load_tile(Tile<VPL, T> &tile, const int32_t *__restrict__ indices,
+                                          const float *__restrict__ data, const float *__restrict__ Y, int f, int lane,
+                                          int k0, int end) {
+  constexpr int J = T / 4;
+  const int cnt = min(T, end - k0);
+  tile.cnt = cnt;
+  int my_idx = lane < cnt ? indices[k0 + lane] : 0;
+  const int base = k0 + J * (lane >> 4);
+#pragma unroll
+  for (int j = 0; j < J; ++j) tile.c[j] = base + j < end ? data[base + j] : 0.f;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    if (t < cnt) {  // wave-uniform
+      int col = lane_bcast(my_idx, t);
+      load_row<VPL, true>(Y + (size_t)col * f, f, lane, tile.y[t]);
+    } else {
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) tile.y[t][v] = 0.f;
+    }
+  }
+}
+
+template <int VPL, int T, bool FIRST>
+__device__ __forceinline__ void tile_apply(const Tile<VPL, T> &tile, int lane, int k0, int end,
+                                           const float (&vec)[VPL], float (&acc)[VPL]) {
+  constexpr int J = T / 4;
+  float part[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) part[t] = dot_local<VPL>(tile.y[t], vec);
+  float h[T / 2];
+#pragma unroll
+  for (int t = 0; t < T / 2; ++t) h[t] = swap32_sum(part[t], part[t + T / 2]);
+  float q[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) q[j] = swap16_sum(h[j], h[j + J]);
+  float w[J];
+  const int base = k0 + J * (lane >> 4);
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    float d = row_allsum(q[j]);
+    float wj = nnz_weight<FIRST>(tile.c[j], d);
+    w[j] = base + j < end ? wj : 0.f;
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    if (t < tile.cnt) {  // wave-uniform
+      float wt = lane_bcast(w[t % J], 16 * (t / J));
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) acc[v] = fmaf(wt, tile.y[t][v], acc[v]);
+    }
+  }
+}
+
+// acc += sum over nnz [begin, end) streamed through register tiles
+template <int VPL, int T, bool FIRST>
+__device__ __forceinline__ void sparse_pass_tiled(const int32_t *__restrict__ indices, const float *__restrict__ data,
+                                                  const float *__restrict__ Y, int f, int lane, int begin, int end,
+                                                  const float (&vec)[VPL], float (&acc)[VPL]) {
+  for (int k0 = begin; k0 < end; k0 += T) {
+    Tile<VPL, T> tile;
+    load_tile<VPL, T>(tile, indices, data, Y, f, lane, k0, end);
+    tile_apply<VPL, T, FIRST>(tile, lane, k0, end, vec, acc);
+  }
+}
+
+template <int VPL> constexpr int tile_size() { return VPL <= 2 ? 32 : 16; }
+
+}  // namespace imp
+#endif  // IMPLICIT_AMD_CSRC_ALS_TILE_H_

@@ -116,18 +116,42 @@ struct imp_intvector {
   size_t size = 0;
 };
 
-// Rows are scheduled in length classes so that a wavefront, a workgroup or several workgroups
-// cooperate on one row depending on its nnz (SURVEY section 7 "load imbalance").
+// Device view of the long-row plan (passed to kernels by value).
+struct LongPlanDev {
+  int n_long, n_seg;
+  const int32_t *rows;       // [n_long]   row id of each long row
+  const int32_t *row_seg;    // [n_long+1] first segment of each long row
+  const int32_t *seg_row;    // [n_seg]    long-row index of each segment
+  const int32_t *seg_begin;  // [n_seg]    nnz range of each segment
+  const int32_t *seg_end;    // [n_seg]
+};
+
+// Rows are scheduled in length classes so that the work per wavefront is even and the longest rows
+// start first (SURVEY section 7 "load imbalance"): `order` = row ids sorted by descending nnz;
+// class b covers order[bin_start[b] .. bin_start[b+1]):
+//   0 long  (> kLongRow nnz): cut into segments of <= kSegment nnz, segment-parallel CG passes
+//   1 mid   (kShortRow < nnz <= kLongRow): one wavefront per row, gathered tiles streamed per pass
+//   2 short (1..kShortRow nnz): one wavefront per row, the gathered tile stays in registers
+//   3 empty
 struct imp_csr {
+  static constexpr int kBins = 4;
+  static constexpr int kShortRow = 32;
+  static constexpr int kLongRow = 256;
+  static constexpr int kSegment = 512;
   int32_t rows = 0, cols = 0;
   int64_t nnz = 0;
   imp::DeviceArray<int32_t> indptr, indices;
   imp::DeviceArray<float> data;
-  // row ids sorted by descending length; bin b covers order[bin_start[b] .. bin_start[b+1])
   imp::DeviceArray<int32_t> order;
-  static constexpr int kBins = 3;  // 0: empty rows, 1: wave-per-row, 2: workgroup-per-row
-  int32_t bin_start[kBins + 1] = {0, 0, 0, 0};
+  int32_t bin_start[kBins + 1] = {0, 0, 0, 0, 0};
   int32_t max_row = 0;
+  // long-row plan
+  int32_t n_long = 0, n_seg = 0;
+  imp::DeviceArray<int32_t> row_seg, seg_row, seg_begin, seg_end;
+  LongPlanDev long_plan_dev() const {
+    return LongPlanDev{n_long, n_seg, order.data(), row_seg.data(), seg_row.data(), seg_begin.data(), seg_end.data()};
+  }
+  int32_t nonempty() const { return bin_start[3]; }
 };
 
 struct imp_coo {

@@ -415,29 +415,50 @@ int imp_csr_create(int32_t rows, int32_t cols, int64_t nnz, const int32_t *indpt
     m->data.upload(data, (size_t)nnz);
 
     // Row schedule: counting sort of row ids by descending length, cut into length classes.
-    int32_t wave_max = 256;
-    if (const char *e = getenv("IMP_WAVE_ROW_MAX")) wave_max = std::max(1, atoi(e));
+    int32_t long_row = imp_csr::kLongRow, short_row = imp_csr::kShortRow, segment = imp_csr::kSegment;
+    if (const char *e = getenv("IMP_LONG_ROW")) long_row = std::max(short_row, atoi(e));
+    if (const char *e = getenv("IMP_SEGMENT")) segment = std::max(32, atoi(e));
     int32_t max_len = 0;
     for (int32_t r = 0; r < rows; ++r) max_len = std::max(max_len, indptr[r + 1] - indptr[r]);
     m->max_row = max_len;
     std::vector<int32_t> count((size_t)max_len + 2, 0);
     for (int32_t r = 0; r < rows; ++r) count[indptr[r + 1] - indptr[r]]++;
-    // start offset of each length in descending order
     std::vector<int32_t> start((size_t)max_len + 2, 0);
-    int32_t acc = 0, n_long = 0, n_wave = 0;
+    int32_t acc = 0, n_long = 0, n_mid = 0, n_short = 0;
     for (int32_t len = max_len; len >= 0; --len) {
       start[len] = acc;
       acc += count[len];
-      if (len > wave_max) n_long += count[len];
-      else if (len > 0) n_wave += count[len];
+      if (len > long_row) n_long += count[len];
+      else if (len > short_row) n_mid += count[len];
+      else if (len > 0) n_short += count[len];
     }
     std::vector<int32_t> order((size_t)rows);
     for (int32_t r = 0; r < rows; ++r) order[start[indptr[r + 1] - indptr[r]]++] = r;
     m->order.upload(order.data(), order.size());
-    m->bin_start[0] = 0;               // [0, n_long): workgroup-per-row
-    m->bin_start[1] = n_long;          // [n_long, n_long + n_wave): wave-per-row
-    m->bin_start[2] = n_long + n_wave; // [.., rows): empty rows
-    m->bin_start[3] = rows;
+    m->bin_start[0] = 0;
+    m->bin_start[1] = n_long;
+    m->bin_start[2] = n_long + n_mid;
+    m->bin_start[3] = n_long + n_mid + n_short;
+    m->bin_start[4] = rows;
+
+    // long rows -> segments
+    std::vector<int32_t> row_seg((size_t)n_long + 1, 0), seg_row, seg_begin, seg_end;
+    for (int32_t li = 0; li < n_long; ++li) {
+      int32_t r = order[li];
+      row_seg[li] = (int32_t)seg_row.size();
+      for (int32_t b = indptr[r]; b < indptr[r + 1]; b += segment) {
+        seg_row.push_back(li);
+        seg_begin.push_back(b);
+        seg_end.push_back(std::min(indptr[r + 1], b + segment));
+      }
+    }
+    row_seg[n_long] = (int32_t)seg_row.size();
+    m->n_long = n_long;
+    m->n_seg = (int32_t)seg_row.size();
+    m->row_seg.upload(row_seg.data(), row_seg.size());
+    m->seg_row.upload(seg_row.data(), seg_row.size());
+    m->seg_begin.upload(seg_begin.data(), seg_begin.size());
+    m->seg_end.upload(seg_end.data(), seg_end.size());
     sync();
     *out = m.release();
   });
