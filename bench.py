@@ -59,9 +59,10 @@ def cg_algorithmic_bytes(lengths, f):
     return nnz * (4 * f + 8) + rows * (8 * f + 8) + 4 * f * f
 
 
-SHORT_ROW, LONG_ROW = 32, int(os.environ.get("IMP_LONG_ROW", "256"))  # imp_csr::kShortRow / kLongRow
+SHORT_ROW, LONG_ROW = 32, 512  # imp_csr::kShortRow / kLongRow
 # schedule class -> the kernels that execute it (long rows: one partial + one combine launch per CG pass)
-CLASS_KERNELS = {"short": ["als_cg_short_rows"], "mid": ["als_cg_mid_rows"],
+CLASS_KERNELS = {"short": ["als_cg_short_rows"],
+                 "mid": ["als_cg_team2_rows", "als_cg_team4_rows", "als_cg_team8_rows", "als_cg_team16_rows"],
                  "long": ["als_cg_long_partial", "als_cg_long_combine"]}
 
 
@@ -212,7 +213,7 @@ def main():
     if classes:
         dom = max(classes, key=lambda c: classes[c]["ms_per_step"])
         d = classes[dom]
-        sweeps = 2 * args.steps  # the class runs once per half sweep
+        sweeps = 2 * args.steps  # the class runs once per half sweep (mid: one launch per team width)
         total_ms = d["ms_per_step"] * args.steps
         bytes_per_sweep = cbytes[dom] / 2.0
         roofline = {"bound": "hbm", "kernel": "+".join(CLASS_KERNELS[dom]), "row_class": dom,

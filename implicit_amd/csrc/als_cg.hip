@@ -29,26 +29,6 @@ namespace imp {
 
 void least_squares_cg_group(const imp_csr *C, float *X, const float *Y, const float *A0, int f, int cg_steps);  // als_cg_group.hip
 
-// acc[e] += sum_{j in [j_begin, j_end)} A0[j][e] * vec[j]   (A0 symmetric)
-// A0s: LDS image (leading dimension LD = 64*VPL, zero padded) or the global f x f matrix (LD = f).
-template <int VPL, bool VEC>
-__device__ __forceinline__ void gram_matvec(const float *A0s, int LD, int lane, const float (&vec)[VPL],
-                                            float (&acc)[VPL], int j_begin, int j_end) {
-#pragma unroll
-  for (int v = 0; v < VPL; ++v) {
-#pragma unroll 4
-    for (int l = 0; l < 64; ++l) {
-      int j = VEC ? l * VPL + v : l + 64 * v;
-      if (j < j_begin || j >= j_end) continue;  // wave-uniform
-      float pj = lane_bcast(vec[v], l);
-      float row[VPL];
-      load_row<VPL, VEC>(A0s + (size_t)j * LD, LD, lane, row);
-#pragma unroll
-      for (int w = 0; w < VPL; ++w) acc[w] = fmaf(pj, row[w], acc[w]);
-    }
-  }
-}
-
 // ---- generic per-nnz pass (any f): 4 gathers in flight, one DPP all-reduce per dot -------------------
 template <int VPL, bool VEC, bool FIRST>
 __device__ __forceinline__ void sparse_pass_simple(const int32_t *__restrict__ indices, const float *__restrict__ data,
@@ -390,24 +370,24 @@ static void launch_long(const imp_csr *C, float *X, const float *Y, const float 
 
 template <int VPL, bool VEC, bool A_LDS>
 static void launch_all(const imp_csr *C, float *X, const float *Y, const float *A0, int f, int cg_steps) {
-  // schedule classes: 0 long (segment-split), 1 mid (streamed tiles), 2 short (resident tile), 3 empty
+  // schedule classes (imp_csr): 0 long (segment-split), 1..4 mid, 5 short, 6 empty
   const int32_t *b = C->bin_start;
   launch_long<VPL, VEC, A_LDS>(C, X, Y, A0, f, cg_steps);
-  static const bool no_group = getenv("IMP_NO_GROUP") != nullptr;  // A/B switch: per-wave VALU gramian product
+  static const bool no_group = getenv("IMP_NO_GROUP") != nullptr;  // A/B switch: generic one-wave-per-row kernels
   if (VEC && A_LDS && (f == 64 || f == 128) && !no_group) {
-    least_squares_cg_group(C, X, Y, A0, f, cg_steps);  // 16 rows per workgroup, gramian product on MFMA
+    least_squares_cg_group(C, X, Y, A0, f, cg_steps);  // wave teams with resident tiles + MFMA gramian product
   } else {
     bool resident_ok = false;
     if constexpr (VEC) resident_ok = tile_size<VPL>() >= imp_csr::kShortRow;
     if constexpr (VEC) {
       if (resident_ok) {
-        launch_fused<VPL, VEC, A_LDS, false>(C, b[1], b[2] - b[1], X, Y, A0, f, cg_steps, "als_cg_mid_rows");
-        launch_fused<VPL, VEC, A_LDS, true>(C, b[2], b[3] - b[2], X, Y, A0, f, cg_steps, "als_cg_short_rows");
+        launch_fused<VPL, VEC, A_LDS, false>(C, b[1], b[5] - b[1], X, Y, A0, f, cg_steps, "als_cg_mid_rows");
+        launch_fused<VPL, VEC, A_LDS, true>(C, b[5], b[6] - b[5], X, Y, A0, f, cg_steps, "als_cg_short_rows");
       }
     }
-    if (!resident_ok) launch_fused<VPL, VEC, A_LDS, false>(C, b[1], b[3] - b[1], X, Y, A0, f, cg_steps, "als_cg_mid_rows");
+    if (!resident_ok) launch_fused<VPL, VEC, A_LDS, false>(C, b[1], b[6] - b[1], X, Y, A0, f, cg_steps, "als_cg_mid_rows");
   }
-  zero_rows(C->order.data(), b[3], b[4] - b[3], X, f);
+  zero_rows(C->order.data(), C->first_empty(), C->n_empty(), X, f);
 }
 
 void least_squares_cg(const imp_csr *C, imp_matrix *X, const imp_matrix *YtY, const imp_matrix *Y, int cg_steps) {

@@ -153,6 +153,109 @@ __global__ __launch_bounds__(1024) void als_cg_group_kernel(const int32_t *__res
   }
 }
 
+// ---- mid rows: a TEAM of WPR wavefronts per row, the whole row resident in registers ---------------------------
+// Wave `sub` of the team keeps nnz [32 sub, 32 sub + 32) of the row as a register tile for all 1+cg_steps passes
+// (the factor rows are gathered ONCE), applies the gramian rows [f sub / WPR, f (sub+1) / WPR) on the VALU, and the
+// WPR partial vectors are summed through LDS in a fixed order; every wave of the team then performs the same
+// CG update on identical bits.  A 1024-thread workgroup runs 16 / WPR teams in lockstep.
+template <int F, int WPR>
+__global__ __launch_bounds__(1024) void als_cg_team_kernel(const int32_t *__restrict__ order, int first, int count,
+                                                           const int32_t *__restrict__ indptr,
+                                                           const int32_t *__restrict__ indices,
+                                                           const float *__restrict__ data, float *__restrict__ X,
+                                                           const float *__restrict__ Y, const float *__restrict__ A0,
+                                                           int cg_steps) {
+  constexpr int VPL = F / 64, T = 32, TEAMS = 16 / WPR;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *A0s = smem;                    // [F][F]
+  float *scratch = A0s + (size_t)F * F;  // [16][F]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int team = wave / WPR, sub = wave % WPR;
+  for (int e = threadIdx.x; e < F * F; e += 1024) A0s[e] = A0[e];
+  __syncthreads();
+  const int j_begin = F * sub / WPR, j_end = F * (sub + 1) / WPR;
+
+  auto combine = [&](float (&acc)[VPL]) {
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) scratch[wave * F + lane * VPL + v] = acc[v];
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < WPR; ++w) s += scratch[(team * WPR + w) * F + lane * VPL + v];
+      acc[v] = s;
+    }
+    __syncthreads();
+  };
+
+  const int groups = (count + TEAMS - 1) / TEAMS;
+  for (int g = blockIdx.x; g < groups; g += gridDim.x) {
+    const int i = g * TEAMS + team;
+    const bool valid = i < count;
+    int u = 0, row_begin = 0, row_end = 0;
+    if (valid) {
+      u = __builtin_amdgcn_readfirstlane(order[first + i]);
+      row_begin = __builtin_amdgcn_readfirstlane(indptr[u]);
+      row_end = __builtin_amdgcn_readfirstlane(indptr[u + 1]);
+    }
+    float *xrow = X + (size_t)u * F;
+    float x[VPL], r[VPL], p[VPL], Ap[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) x[v] = 0.f;
+    if (valid) load_row<VPL, true>(xrow, F, lane, x);
+    const int k0 = row_begin + T * sub;  // this wave's slice of the row (may be empty)
+    Tile<VPL, T> tile;
+    load_tile<VPL, T>(tile, indices, data, Y, F, lane, min(k0, row_end), row_end);
+
+    // r = -(A0 x) + sum_k (c+ - (|c|-1) y.x) y        (_als.pyx:187-201)
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) Ap[v] = 0.f;
+    gram_matvec<VPL, true>(A0s, F, lane, x, Ap, j_begin, j_end);
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) r[v] = -Ap[v];
+    tile_apply<VPL, T, true>(tile, lane, min(k0, row_end), row_end, x, r);
+    combine(r);
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) p[v] = r[v];
+    float rsold = wave_allsum(dot_local<VPL>(r, r));
+    bool active = valid && rsold >= 1e-20f;  // else: x untouched (_als.pyx:206)
+    const bool store = active && sub == 0;
+
+    for (int it = 0; it < cg_steps; ++it) {
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) Ap[v] = 0.f;
+      if (active) {  // wave-uniform and identical across the team
+        gram_matvec<VPL, true>(A0s, F, lane, p, Ap, j_begin, j_end);
+        tile_apply<VPL, T, false>(tile, lane, min(k0, row_end), row_end, p, Ap);
+      }
+      combine(Ap);
+      if (active) {
+        float alpha = rsold / wave_allsum(dot_local<VPL>(p, Ap));
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          x[v] = fmaf(alpha, p[v], x[v]);
+          r[v] = fmaf(-alpha, Ap[v], r[v]);
+        }
+        float rsnew = wave_allsum(dot_local<VPL>(r, r));
+        if (rsnew < 1e-20f) {
+          active = false;  // the oracle breaks here (_als.pyx:235); keep taking the barriers
+        } else {
+          float beta = rsnew / rsold;
+#pragma unroll
+          for (int v = 0; v < VPL; ++v) p[v] = fmaf(beta, p[v], r[v]);
+          rsold = rsnew;
+        }
+      }
+    }
+    if (store) {
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) xrow[lane * VPL + v] = x[v];
+    }
+  }
+}
+
 template <int F, bool RESIDENT>
 static void launch_group(const imp_csr *C, int first, int count, float *X, const float *Y, const float *A0, int cg_steps,
                          const char *name) {
@@ -168,18 +271,37 @@ static void launch_group(const imp_csr *C, int first, int count, float *X, const
   IMP_CHECK_HIP(hipGetLastError());
 }
 
-// mid (streamed tiles) and short (resident tile) row classes of a CSR for f = 64 or 128
+template <int F, int WPR>
+static void launch_team(const imp_csr *C, int first, int count, float *X, const float *Y, const float *A0, int cg_steps,
+                        const char *name) {
+  if (count <= 0) return;
+  constexpr int TEAMS = 16 / WPR;
+  size_t lds = ((size_t)F * F + 16 * F) * sizeof(float);
+  auto kern = als_cg_team_kernel<F, WPR>;
+  IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / lds));
+  int grid = std::min((count + TEAMS - 1) / TEAMS, ctx().num_cus * per_cu);
+  IMP_PROF(name);
+  kern<<<grid, 1024, lds, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(), C->data.data(), X, Y, A0,
+                                      cg_steps);
+  IMP_CHECK_HIP(hipGetLastError());
+}
+
+template <int F>
+static void run_classes(const imp_csr *C, float *X, const float *Y, const float *A0, int cg_steps) {
+  const int32_t *b = C->bin_start;  // classes: 1 (256,512]  2 (128,256]  3 (64,128]  4 (32,64]  5 (0,32]
+  launch_team<F, 16>(C, b[1], b[2] - b[1], X, Y, A0, cg_steps, "als_cg_team16_rows");
+  launch_team<F, 8>(C, b[2], b[3] - b[2], X, Y, A0, cg_steps, "als_cg_team8_rows");
+  launch_team<F, 4>(C, b[3], b[4] - b[3], X, Y, A0, cg_steps, "als_cg_team4_rows");
+  launch_team<F, 2>(C, b[4], b[5] - b[4], X, Y, A0, cg_steps, "als_cg_team2_rows");
+  launch_group<F, true>(C, b[5], b[6] - b[5], X, Y, A0, cg_steps, "als_cg_short_rows");
+}
+
+// mid (wave teams, resident tiles) and short (one wave per row, MFMA gramian product) classes for f = 64 or 128
 void least_squares_cg_group(const imp_csr *C, float *X, const float *Y, const float *A0, int f, int cg_steps) {
-  const int32_t *b = C->bin_start;
-  if (f == 128) {
-    launch_group<128, false>(C, b[1], b[2] - b[1], X, Y, A0, cg_steps, "als_cg_mid_rows");
-    launch_group<128, true>(C, b[2], b[3] - b[2], X, Y, A0, cg_steps, "als_cg_short_rows");
-  } else if (f == 64) {
-    launch_group<64, false>(C, b[1], b[2] - b[1], X, Y, A0, cg_steps, "als_cg_mid_rows");
-    launch_group<64, true>(C, b[2], b[3] - b[2], X, Y, A0, cg_steps, "als_cg_short_rows");
-  } else {
-    throw std::invalid_argument("least_squares_cg_group: f must be 64 or 128");
-  }
+  if (f == 128) run_classes<128>(C, X, Y, A0, cg_steps);
+  else if (f == 64) run_classes<64>(C, X, Y, A0, cg_steps);
+  else throw std::invalid_argument("least_squares_cg_group: f must be 64 or 128");
 }
 
 }  // namespace imp

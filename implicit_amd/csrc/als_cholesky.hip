@@ -152,7 +152,7 @@ int64_t least_squares_cholesky(const imp_csr *C, imp_matrix *X, const imp_matrix
                                                       g_failed);
     IMP_CHECK_HIP(hipGetLastError());
   }
-  zero_rows(C->order.data(), C->bin_start[3], C->bin_start[4] - C->bin_start[3], X->f32(), f);
+  zero_rows(C->order.data(), C->first_empty(), C->n_empty(), X->f32(), f);
   unsigned long long failed = 0;
   IMP_CHECK_HIP(hipMemcpyAsync(&failed, g_failed, sizeof(failed), hipMemcpyDeviceToHost, stream()));
   sync();

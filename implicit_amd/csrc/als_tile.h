@@ -5,6 +5,28 @@
 
 namespace imp {
 
+// acc[e] += sum_{j in [j_begin, j_end)} A0[j][e] * vec[j]   (A0 symmetric)
+// A0s: LDS image (leading dimension LD = 64*VPL, zero padded) or the global f x f matrix (LD = f).
+template <int VPL, bool VEC>
+__device__ __forceinline__ void gram_matvec(const float *A0s, int LD, int lane, const float (&vec)[VPL],
+                                            float (&acc)[VPL], int j_begin, int j_end) {
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    // factor j = elem(l, v); walk only the lanes l whose j lies in [j_begin, j_end)
+    const int l_begin = VEC ? (j_begin - v + VPL - 1) / VPL : max(j_begin - 64 * v, 0);
+    const int l_end = VEC ? min(64, (j_end - v + VPL - 1) / VPL) : min(64, j_end - 64 * v);
+#pragma unroll 4
+    for (int l = l_begin; l < l_end; ++l) {
+      const int j = VEC ? l * VPL + v : l + 64 * v;
+      float pj = lane_bcast(vec[v], l);
+      float row[VPL];
+      load_row<VPL, VEC>(A0s + (size_t)j * LD, LD, lane, row);
+#pragma unroll
+      for (int w = 0; w < VPL; ++w) acc[w] = fmaf(pj, row[w], acc[w]);
+    }
+  }
+}
+
 // w_k of one nonzero:  FIRST: (c > 0 ? c : 0) - (|c| - 1) * d   (_als.pyx:190-201)
 //                      else : (|c| - 1) * d                      (_als.pyx:214-222)
 template <bool FIRST> __device__ __forceinline__ float nnz_weight(float c, float d) {
@@ -45,20 +67,27 @@ __device__ __forceinline__ void load_tile(Tile<VPL, T> &tile, const int32_t *__r
                                           const float *__restrict__ data, const float *__restrict__ Y, int f, int lane,
                                           int k0, int end) {
   constexpr int J = T / 4;
-  const int cnt = min(T, end - k0);
+  const int cnt = max(0, min(T, end - k0));
   tile.cnt = cnt;
-  int my_idx = lane < cnt ? indices[k0 + lane] : 0;
+  // lanes beyond cnt repeat the last valid entry: their gathers stay in bounds and their weights are masked
+  const int my_idx = cnt > 0 ? indices[k0 + min(lane, cnt - 1)] : 0;
   const int base = k0 + J * (lane >> 4);
 #pragma unroll
   for (int j = 0; j < J; ++j) tile.c[j] = base + j < end ? data[base + j] : 0.f;
+  // all column ids first (one wait on the index load), then the gathers back to back in groups of 8
+  unsigned col[T];
 #pragma unroll
-  for (int t = 0; t < T; ++t) {
-    if (t < cnt) {  // wave-uniform
-      int col = lane_bcast(my_idx, t);
-      load_row<VPL, true>(Y + (size_t)col * f, f, lane, tile.y[t]);
+  for (int t = 0; t < T; ++t) col[t] = (unsigned)lane_bcast(my_idx, t);
+#pragma unroll
+  for (int g = 0; g < T / 8; ++g) {
+    if (8 * g < cnt) {  // wave-uniform
+#pragma unroll
+      for (int t = 8 * g; t < 8 * g + 8; ++t) load_row<VPL, true>(Y + (size_t)col[t] * f, f, lane, tile.y[t]);
     } else {
 #pragma unroll
-      for (int v = 0; v < VPL; ++v) tile.y[t][v] = 0.f;
+      for (int t = 8 * g; t < 8 * g + 8; ++t)
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) tile.y[t][v] = 0.f;
     }
   }
 }
@@ -85,11 +114,14 @@ __device__ __forceinline__ void tile_apply(const Tile<VPL, T> &tile, int lane, i
     w[j] = base + j < end ? wj : 0.f;
   }
 #pragma unroll
-  for (int t = 0; t < T; ++t) {
-    if (t < tile.cnt) {  // wave-uniform
-      float wt = lane_bcast(w[t % J], 16 * (t / J));
+  for (int g = 0; g < T / 8; ++g) {
+    if (8 * g < tile.cnt) {  // wave-uniform; entries past cnt inside the group carry weight 0
 #pragma unroll
-      for (int v = 0; v < VPL; ++v) acc[v] = fmaf(wt, tile.y[t][v], acc[v]);
+      for (int t = 8 * g; t < 8 * g + 8; ++t) {
+        float wt = lane_bcast(w[t % J], 16 * (t / J));
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) acc[v] = fmaf(wt, tile.y[t][v], acc[v]);
+      }
     }
   }
 }

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <climits>
 #include <cstdint>
 #include <cstdio>
 #include <memory>
@@ -128,22 +129,25 @@ struct LongPlanDev {
 
 // Rows are scheduled in length classes so that the work per wavefront is even and the longest rows
 // start first (SURVEY section 7 "load imbalance"): `order` = row ids sorted by descending nnz;
-// class b covers order[bin_start[b] .. bin_start[b+1]):
-//   0 long  (> kLongRow nnz): cut into segments of <= kSegment nnz, segment-parallel CG passes
-//   1 mid   (kShortRow < nnz <= kLongRow): one wavefront per row, gathered tiles streamed per pass
-//   2 short (1..kShortRow nnz): one wavefront per row, the gathered tile stays in registers
-//   3 empty
+// class b covers order[bin_start[b] .. bin_start[b+1]) and holds the rows with
+// kClassMax[b+1] < nnz <= kClassMax[b]:
+//   0 long  (> 512 nnz): cut into segments of <= kSegment nnz, segment-parallel CG passes
+//   1..4 mid (256,512], (128,256], (64,128], (32,64]: a TEAM of 16/8/4/2 wavefronts per row, every
+//        wavefront keeps one 32-row gathered tile in registers for all passes
+//   5 short (1..32 nnz): one wavefront per row, resident tile, 16 rows per workgroup (MFMA gramian product)
+//   6 empty
 struct imp_csr {
-  static constexpr int kBins = 4;
+  static constexpr int kBins = 7;
   static constexpr int kShortRow = 32;
-  static constexpr int kLongRow = 256;
+  static constexpr int kLongRow = 512;
   static constexpr int kSegment = 512;
+  static constexpr int32_t kClassMax[kBins + 1] = {INT32_MAX, 512, 256, 128, 64, 32, 0, -1};
   int32_t rows = 0, cols = 0;
   int64_t nnz = 0;
   imp::DeviceArray<int32_t> indptr, indices;
   imp::DeviceArray<float> data;
   imp::DeviceArray<int32_t> order;
-  int32_t bin_start[kBins + 1] = {0, 0, 0, 0, 0};
+  int32_t bin_start[kBins + 1] = {0, 0, 0, 0, 0, 0, 0, 0};
   int32_t max_row = 0;
   // long-row plan
   int32_t n_long = 0, n_seg = 0;
@@ -151,7 +155,9 @@ struct imp_csr {
   LongPlanDev long_plan_dev() const {
     return LongPlanDev{n_long, n_seg, order.data(), row_seg.data(), seg_row.data(), seg_begin.data(), seg_end.data()};
   }
-  int32_t nonempty() const { return bin_start[3]; }
+  int32_t nonempty() const { return bin_start[kBins - 1]; }
+  int32_t first_empty() const { return bin_start[kBins - 1]; }
+  int32_t n_empty() const { return bin_start[kBins] - bin_start[kBins - 1]; }
 };
 
 struct imp_coo {

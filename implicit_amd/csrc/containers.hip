@@ -415,8 +415,7 @@ int imp_csr_create(int32_t rows, int32_t cols, int64_t nnz, const int32_t *indpt
     m->data.upload(data, (size_t)nnz);
 
     // Row schedule: counting sort of row ids by descending length, cut into length classes.
-    int32_t long_row = imp_csr::kLongRow, short_row = imp_csr::kShortRow, segment = imp_csr::kSegment;
-    if (const char *e = getenv("IMP_LONG_ROW")) long_row = std::max(short_row, atoi(e));
+    int32_t segment = imp_csr::kSegment;
     if (const char *e = getenv("IMP_SEGMENT")) segment = std::max(32, atoi(e));
     int32_t max_len = 0;
     for (int32_t r = 0; r < rows; ++r) max_len = std::max(max_len, indptr[r + 1] - indptr[r]);
@@ -424,22 +423,21 @@ int imp_csr_create(int32_t rows, int32_t cols, int64_t nnz, const int32_t *indpt
     std::vector<int32_t> count((size_t)max_len + 2, 0);
     for (int32_t r = 0; r < rows; ++r) count[indptr[r + 1] - indptr[r]]++;
     std::vector<int32_t> start((size_t)max_len + 2, 0);
-    int32_t acc = 0, n_long = 0, n_mid = 0, n_short = 0;
+    int32_t acc = 0;
+    int32_t class_count[imp_csr::kBins] = {0};
     for (int32_t len = max_len; len >= 0; --len) {
       start[len] = acc;
       acc += count[len];
-      if (len > long_row) n_long += count[len];
-      else if (len > short_row) n_mid += count[len];
-      else if (len > 0) n_short += count[len];
+      int b = 0;
+      while (len <= imp_csr::kClassMax[b + 1]) ++b;  // kClassMax[b+1] < len <= kClassMax[b]
+      class_count[b] += count[len];
     }
     std::vector<int32_t> order((size_t)rows);
     for (int32_t r = 0; r < rows; ++r) order[start[indptr[r + 1] - indptr[r]]++] = r;
     m->order.upload(order.data(), order.size());
     m->bin_start[0] = 0;
-    m->bin_start[1] = n_long;
-    m->bin_start[2] = n_long + n_mid;
-    m->bin_start[3] = n_long + n_mid + n_short;
-    m->bin_start[4] = rows;
+    for (int b = 0; b < imp_csr::kBins; ++b) m->bin_start[b + 1] = m->bin_start[b] + class_count[b];
+    const int32_t n_long = class_count[0];
 
     // long rows -> segments
     std::vector<int32_t> row_seg((size_t)n_long + 1, 0), seg_row, seg_begin, seg_end;

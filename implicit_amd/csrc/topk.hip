@@ -4,15 +4,16 @@
 // select_k).  Semantics follow the CPU oracle implicit/cpu/topk.pyx:15-67 + select.h:12-40:
 //   scores = query . items^T (exact fp32), optional divide by item_norms, per-query (COO) and global
 //   item filters set to -FLT_MAX, then the k best per row, written best-first.
-// Tie rule: total order (score desc, column desc) -- identical to the oracle's output order and to
-// its retained set whenever there is no exact tie straddling the k-th score.
+// Output order (score desc, column desc) is the oracle's.  When more entries tie with the k-th score than
+// there are places left, the retained set follows the reference heap's arrival-order rule exactly
+// (closed form in select_kernel), so ids are bit-identical to select.h even on all-zero / all-filtered rows.
 //
 // Stage 1  score_gemm_kernel : fp32 MFMA (v_mfma_f32_32x32x2_f32), LDS-staged K-tiles of both operands
 //          with odd row stride (conflict-free fragment reads), norm divide fused in the epilogue.
 // Stage 2  filters (tiny scatter kernels).
 // Stage 3  select_kernel : one workgroup per query row, MSB-first 8-bit radix select on the 64-bit key
-//          (ordered(score) << 32 | column) with early exit once the boundary bucket is taken whole,
-//          then a gather of the k winners and an in-LDS bitonic sort.
+//          (ordered(score) << 32 | column) over the score bytes with early exit once the boundary bucket
+//          is taken whole, exact tie resolution otherwise, a gather of the k winners and an in-LDS bitonic sort.
 #include <cfloat>
 
 #include "common.h"
@@ -101,6 +102,7 @@ __global__ void coo_filter_kernel(float *__restrict__ S, int start, int end, int
 
 __device__ __forceinline__ uint32_t ordered(float s) {
   uint32_t u = __float_as_uint(s);
+  if (u == 0x80000000u) u = 0u;  // -0.0 compares equal to +0.0 in the reference's heap
   return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
 }
 __device__ __forceinline__ float unordered(uint32_t u) {
@@ -122,7 +124,8 @@ __global__ __launch_bounds__(BLOCK) void select_kernel(const float *__restrict__
 
   uint64_t prefix = 0, mask = 0;
   unsigned int remaining = k;  // k <= ni guaranteed by the host
-  for (int digit = 7; digit >= 0; --digit) {
+  bool ambiguous = false;      // more keys tie with the k-th SCORE than there are places left
+  for (int digit = 7; digit >= 4; --digit) {  // the four score bytes of the key
     const int shift = digit * 8;
     for (int i = tid; i < 256; i += BLOCK) hist[i] = 0;
     __syncthreads();
@@ -149,17 +152,82 @@ __global__ __launch_bounds__(BLOCK) void select_kernel(const float *__restrict__
     bool whole = sh_count == remaining;
     __syncthreads();
     if (whole) break;  // boundary bucket taken entirely: no finer digits needed
+    if (digit == 4) ambiguous = true;
   }
 
-  // gather the winners: (key & mask) >= prefix selects exactly k keys
   if (tid == 0) sh_count = 0;
   for (int i = tid; i < kpad; i += BLOCK) cand[i] = 0;  // pads sort last
   __syncthreads();
-  for (int i = tid; i < ni; i += BLOCK) {
-    uint64_t key = make_key(row[i], i);
-    if ((key & mask) >= prefix) {
-      unsigned int slot = atomicAdd(&sh_count, 1u);
-      if (slot < (unsigned)kpad) cand[slot] = key;
+  if (!ambiguous) {
+    // (key & mask) >= prefix selects exactly k keys
+    for (int i = tid; i < ni; i += BLOCK) {
+      uint64_t key = make_key(row[i], i);
+      if ((key & mask) >= prefix) {
+        unsigned int slot = atomicAdd(&sh_count, 1u);
+        if (slot < (unsigned)kpad) cand[slot] = key;
+      }
+    }
+  } else {
+    // Exact emulation of the reference's heap (implicit/cpu/select.h:12-40) for ties at the k-th score t:
+    // tied entries enter in column order until the heap holds k entries >= t (saturation column s);
+    // each later entry > t then evicts the tied entry with the LOWEST column.  So the survivors are the
+    // tied columns <= s minus the e lowest ones, e = #{column > s : score > t}.
+    const uint32_t t32 = (uint32_t)(prefix >> 32);
+    __shared__ int sh_s;
+    __shared__ unsigned int sh_e;
+    if (tid < 64) {
+      unsigned int running = 0, e = 0;
+      int s_col = -1;
+      for (int c0 = 0; c0 < ni; c0 += 64) {
+        const int c = c0 + tid;
+        const uint32_t key = c < ni ? ordered(row[c]) : 0u;
+        const bool ge = c < ni && key >= t32, gt = c < ni && key > t32;
+        const unsigned long long m_ge = __ballot(ge), m_gt = __ballot(gt);
+        if (s_col < 0) {
+          const unsigned int cnt = __popcll(m_ge);
+          if (running + cnt >= (unsigned)k) {
+            const unsigned int need = k - running;  // the need-th set bit of m_ge is the saturation column
+            const unsigned int incl = __popcll(m_ge & ((2ull << tid) - 1ull));
+            const unsigned long long hit = __ballot(ge && incl == need);
+            const int L = __ffsll((long long)hit) - 1;
+            s_col = c0 + L;
+            e += __popcll(m_gt & ~((2ull << L) - 1ull));
+          } else {
+            running += cnt;
+          }
+        } else {
+          e += __popcll(m_gt);
+        }
+      }
+      if (tid == 0) {
+        sh_s = s_col;
+        sh_e = e;
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < ni; i += BLOCK) {  // everything strictly above the tie score
+      const float sc = row[i];
+      if (ordered(sc) > t32) {
+        unsigned int slot = atomicAdd(&sh_count, 1u);
+        if (slot < (unsigned)kpad) cand[slot] = make_key(sc, i);
+      }
+    }
+    if (tid < 64) {  // the surviving ties, ranked by column
+      const int s_col = sh_s;
+      const unsigned int e = sh_e;
+      unsigned int seen = 0;
+      for (int c0 = 0; c0 <= s_col; c0 += 64) {
+        const int c = c0 + tid;
+        const float sc = c < ni ? row[c] : 0.f;
+        const bool tie = c <= s_col && ordered(sc) == t32;
+        const unsigned long long m_tie = __ballot(tie);
+        const unsigned int rank = seen + __popcll(m_tie & ((1ull << tid) - 1ull)) + 1;
+        if (tie && rank > e) {
+          unsigned int slot = atomicAdd(&sh_count, 1u);
+          if (slot < (unsigned)kpad) cand[slot] = make_key(sc, c);
+        }
+        seen += __popcll(m_tie);
+      }
     }
   }
   __syncthreads();

@@ -85,23 +85,55 @@ def test_topk_vs_oracle_with_filters(gpu, oracle, f, k):
             assert len(set(ids[r]) ^ set(want_ids[r, :k])) <= 2
 
 
-def test_topk_ties_and_all_filtered_tail(gpu):
-    """Documented tie rule: (score desc, column desc); k > items.rows writes items.rows entries."""
-    items = np.zeros((6, 4), dtype=np.float32)
-    items[:, 0] = [5, 5, 9, 5, 1, 9]
-    q = np.array([[1, 0, 0, 0]], dtype=np.float32)
+def test_topk_ties_match_select_h_exactly(gpu, oracle):
+    """Exact ties: the retained set follows the reference heap's arrival-order rule (select.h:12-40,
+    SURVEY App. A.4) bit for bit -- including the golden tie rows produced by the compiled reference."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "als_golden.npz"))
     knn = gpu.KnnQuery()
-    ids, d = knn.topk(gpu.Matrix(items), gpu.Matrix(q), 4)
-    assert_array_equal(ids[0], [5, 2, 3, 1])
-    assert_allclose(d[0], [9, 9, 5, 5])
-    ids, d = knn.topk(gpu.Matrix(items), gpu.Matrix(q), 8)
-    assert_array_equal(ids[0][:6], [5, 2, 3, 1, 0, 4])
-    assert_array_equal(ids[0][6:], [0, 0])
-    assert_allclose(d[0][6:], [0, 0])
-    # filtered entries score -FLT_MAX and come last
-    ids, d = knn.topk(gpu.Matrix(items), gpu.Matrix(q), 6, item_filter=gpu.IntVector(np.array([2, 5], dtype=np.int32)))
-    assert set(ids[0][:4]) == {0, 1, 3, 4} and set(ids[0][4:]) == {2, 5}
-    assert (d[0][4:] == -np.finfo(np.float32).max).all()
+    one = gpu.Matrix(np.ones((1, 1), dtype=np.float32))
+    for i in range(int(g["n_ties"])):
+        row = g[f"tie{i}_row"]
+        for k in (2, 3, 5):
+            ids, dist = knn.topk(gpu.Matrix(row.reshape(-1, 1).copy()), one, k)
+            assert_array_equal(ids, g[f"tie{i}_k{k}_ids"], err_msg=f"row {row} k={k}")
+            assert_array_equal(dist, g[f"tie{i}_k{k}_dist"])
+    # heavy ties: small-integer scores, every k, against the oracle's heap
+    rng = np.random.default_rng(4)
+    items = rng.integers(0, 4, size=(700, 1)).astype(np.float32)
+    items[::37] = -0.0
+    queries = np.array([[1.0], [0.0], [-1.0], [2.0]], dtype=np.float32)
+    for k in (1, 7, 64, 300, 700):
+        want_ids, want_d = oracle.topk(items, queries, k)
+        ids, d = knn.topk(gpu.Matrix(items), gpu.Matrix(queries), k)
+        assert_array_equal(ids, want_ids, err_msg=f"k={k}")
+        assert_array_equal(d, want_d)
+
+
+def test_topk_zero_queries_and_all_filtered_tail(gpu, oracle):
+    """Users without interactions (zero factors) and N larger than the unfiltered items
+    (recommender_base_test.py:54-57): ids identical to the CPU path, filtered entries score -FLT_MAX."""
+    rng = np.random.default_rng(9)
+    items = (rng.standard_normal((300, 16)) * 0.2).astype(np.float32)
+    queries = (rng.standard_normal((5, 16)) * 0.2).astype(np.float32)
+    queries[2] = 0
+    liked = sp.random(5, 300, density=0.3, format="csr", dtype=np.float32, random_state=2)
+    filt = np.arange(0, 300, 3, dtype=np.int32)
+    knn = gpu.KnnQuery()
+    for k in (10, 150, 300):
+        want_ids, want_d = oracle.topk(items, queries, k, filter_query_items=liked, filter_items=filt)
+        ids, d = knn.topk(gpu.Matrix(items), gpu.Matrix(queries), k, query_filter=gpu.COOMatrix(liked.tocoo()),
+                          item_filter=gpu.IntVector(filt))
+        assert_array_equal(ids, want_ids, err_msg=f"k={k}")
+        assert_allclose(d, want_d, rtol=2e-5, atol=1e-7)
+    assert (d[:, -1] == -np.finfo(np.float32).max).all()
+    # k > items.rows: only items.rows entries are written, the rest keep the zero initialisation
+    ids, d = knn.topk(gpu.Matrix(items[:6]), gpu.Matrix(queries), 8)
+    want_ids, want_d = oracle.topk(items[:6], queries, 8)
+    assert_array_equal(ids, want_ids)
+    assert_array_equal(ids[:, 6:], 0)
+    assert_array_equal(d[:, 6:], 0)
 
 
 def test_topk_argument_errors(gpu):
