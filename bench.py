@@ -25,8 +25,9 @@ import sys
 import time
 import warnings
 
-# scipy-openblas is built for <= 64 threads; the GPU box has 256 logical cores
-os.environ.setdefault("OPENBLAS_NUM_THREADS", "64")
+# scipy-openblas is built for <= 64/128 threads and aborts on the 256-core GPU box; the reference wants
+# single-threaded BLAS under its OpenMP loop anyway (implicit/utils.py:18-62)
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
 
 import numpy as np  # noqa: E402
 
@@ -35,7 +36,7 @@ sys.path.insert(0, ROOT)
 
 FACTORS = 128
 REG = 0.01
-CG_STEPS = 3
+CG_STEPS = int(os.environ.get("IMP_BENCH_CG_STEPS", "3"))  # debug override; the metric is quoted at 3
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured streaming ceiling)
 
 
@@ -84,7 +85,8 @@ def cpu_baseline(Cui, Ciu, X0, Y0, seconds):
     from oracle import ref
 
     als_ref, _ = ref.load()
-    cores = os.cpu_count() or 1
+    # OpenBLAS (reached by the reference from every OpenMP thread) supports at most 128 concurrent callers
+    cores = min(os.cpu_count() or 1, 64)
     kind = "reference" if als_ref is not None else "port"
     limiter = None
     if als_ref is not None:
@@ -101,9 +103,9 @@ def cpu_baseline(Cui, Ciu, X0, Y0, seconds):
         A = A.copy()
         t = time.time()
         if als_ref is not None:
-            als_ref.least_squares_cg(M, A, B, REG, num_threads=0, cg_steps=CG_STEPS)
+            als_ref.least_squares_cg(M, A, B, REG, num_threads=cores, cg_steps=CG_STEPS)
         else:
-            port.least_squares_cg(M, A, B, REG, num_threads=0, cg_steps=CG_STEPS)
+            port.least_squares_cg(M, A, B, REG, num_threads=cores, cg_steps=CG_STEPS)
         return time.time() - t
 
     # probe on 2000 rows of each side, then size the sample for ~`seconds`
@@ -122,7 +124,8 @@ def cpu_baseline(Cui, Ciu, X0, Y0, seconds):
         "cores": cores,
         "kind": kind,
         "sample": f"one CG(cg_steps=3,f={X0.shape[1]}) half-sweep over the first {su} users + first {si} items "
-                  f"({nnz} nnz) of the same matrix, {t:.1f}s, OpenMP num_threads=0, BLAS threads=1",
+                  f"({nnz} nnz) of the same matrix, {t:.1f}s, OpenMP num_threads={cores} of {os.cpu_count()} logical cores, "
+                  f"BLAS threads=1",
         "nnz_visits_per_s": nnz / t,
     }
 
@@ -149,7 +152,7 @@ def main():
     if args.scale != 1.0:
         users, items, nnz_target = int(users * args.scale), int(items * args.scale), int(nnz_target * args.scale)
 
-    if world > 1:
+    if world > 1 or os.environ.get("IMP_FORCE_SHARDED"):  # the env knob exercises the N>1 code path with one rank
         from implicit_amd.gpu import sharded
 
         result = sharded.bench(args, gpu, users, items, nnz_target, gamma, FACTORS, REG, CG_STEPS)
@@ -272,12 +275,18 @@ def bench_topk(gpu, Cui, X, Y, k=10, queries=20_000, batch=1000):
     views = [X[s:min(s + batch, queries)] for s in range(0, queries, batch)]
     knn.topk(Y, views[0], k, query_filter=filt[0])  # warm-up
     gpu.synchronize()
+    gpu.Profiler.reset()
+    gpu.Profiler.enable(True)
     t0 = time.perf_counter()
     for v, fl in zip(views, filt):
         knn.topk(Y, v, k, query_filter=fl)
     gpu.synchronize()
     t = time.perf_counter() - t0
+    gpu.Profiler.enable(False)
+    kernels = {name: gpu.Profiler.get(name)[0] / len(views) for name in gpu.Profiler.names()}
+    flops = 2.0 * queries * Y.shape[0] * Y.shape[1]
     return {"metric": "top-k recs/sec", "value": queries / t, "unit": "recs/s", "k": k, "queries": queries,
+            "kernels_ms_per_batch": kernels, "scoring_TFLOPs": flops / t / 1e12,
             "batch": batch, "items": Y.shape[0], "filter_already_liked_items": True,
             "note": "ids/scores returned to host memory per batch (PCIe D2H included)"}
 

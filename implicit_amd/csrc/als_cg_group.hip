@@ -158,21 +158,22 @@ __global__ __launch_bounds__(1024) void als_cg_group_kernel(const int32_t *__res
 // (the factor rows are gathered ONCE), applies the gramian rows [f sub / WPR, f (sub+1) / WPR) on the VALU, and the
 // WPR partial vectors are summed through LDS in a fixed order; every wave of the team then performs the same
 // CG update on identical bits.  A 1024-thread workgroup runs 16 / WPR teams in lockstep.
-template <int F, int WPR>
-__global__ __launch_bounds__(1024) void als_cg_team_kernel(const int32_t *__restrict__ order, int first, int count,
+template <int F, int WPR, int BLOCK>
+__global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 4 : 4) void als_cg_team_kernel(const int32_t *__restrict__ order, int first, int count,
                                                            const int32_t *__restrict__ indptr,
                                                            const int32_t *__restrict__ indices,
                                                            const float *__restrict__ data, float *__restrict__ X,
                                                            const float *__restrict__ Y, const float *__restrict__ A0,
                                                            int cg_steps) {
-  constexpr int VPL = F / 64, T = 32, TEAMS = 16 / WPR;
+  constexpr int VPL = F / 64, T = 32, WAVES = BLOCK / 64, TEAMS = WAVES / WPR;
+  static_assert(WPR <= WAVES, "a team cannot be wider than the workgroup");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *A0s = smem;                    // [F][F]
-  float *scratch = A0s + (size_t)F * F;  // [16][F]
+  float *scratch = A0s + (size_t)F * F;  // [WAVES][F]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int team = wave / WPR, sub = wave % WPR;
-  for (int e = threadIdx.x; e < F * F; e += 1024) A0s[e] = A0[e];
+  for (int e = threadIdx.x; e < F * F; e += BLOCK) A0s[e] = A0[e];
   __syncthreads();
   const int j_begin = F * sub / WPR, j_end = F * (sub + 1) / WPR;
 
@@ -271,18 +272,18 @@ static void launch_group(const imp_csr *C, int first, int count, float *X, const
   IMP_CHECK_HIP(hipGetLastError());
 }
 
-template <int F, int WPR>
+template <int F, int WPR, int BLOCK>
 static void launch_team(const imp_csr *C, int first, int count, float *X, const float *Y, const float *A0, int cg_steps,
                         const char *name) {
   if (count <= 0) return;
-  constexpr int TEAMS = 16 / WPR;
-  size_t lds = ((size_t)F * F + 16 * F) * sizeof(float);
-  auto kern = als_cg_team_kernel<F, WPR>;
+  constexpr int WAVES = BLOCK / 64, TEAMS = WAVES / WPR;
+  size_t lds = ((size_t)F * F + WAVES * F) * sizeof(float);
+  auto kern = als_cg_team_kernel<F, WPR, BLOCK>;
   IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / lds));
+  int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / BLOCK, (160 * 1024) / lds));
   int grid = std::min((count + TEAMS - 1) / TEAMS, ctx().num_cus * per_cu);
   IMP_PROF(name);
-  kern<<<grid, 1024, lds, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(), C->data.data(), X, Y, A0,
+  kern<<<grid, BLOCK, lds, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(), C->data.data(), X, Y, A0,
                                       cg_steps);
   IMP_CHECK_HIP(hipGetLastError());
 }
@@ -290,10 +291,19 @@ static void launch_team(const imp_csr *C, int first, int count, float *X, const 
 template <int F>
 static void run_classes(const imp_csr *C, float *X, const float *Y, const float *A0, int cg_steps) {
   const int32_t *b = C->bin_start;  // classes: 1 (256,512]  2 (128,256]  3 (64,128]  4 (32,64]  5 (0,32]
-  launch_team<F, 16>(C, b[1], b[2] - b[1], X, Y, A0, cg_steps, "als_cg_team16_rows");
-  launch_team<F, 8>(C, b[2], b[3] - b[2], X, Y, A0, cg_steps, "als_cg_team8_rows");
-  launch_team<F, 4>(C, b[3], b[4] - b[3], X, Y, A0, cg_steps, "als_cg_team4_rows");
-  launch_team<F, 2>(C, b[4], b[5] - b[4], X, Y, A0, cg_steps, "als_cg_team2_rows");
+  // 512-thread workgroups: two fit per CU (LDS 68 KiB, 4 waves/SIMD) and run out of phase, so one gathers
+  // while the other computes; the 16-wave team needs the whole CU
+  static const bool big = getenv("IMP_TEAM_1024") != nullptr;
+  launch_team<F, 16, 1024>(C, b[1], b[2] - b[1], X, Y, A0, cg_steps, "als_cg_team16_rows");
+  if (big) {
+    launch_team<F, 8, 1024>(C, b[2], b[3] - b[2], X, Y, A0, cg_steps, "als_cg_team8_rows");
+    launch_team<F, 4, 1024>(C, b[3], b[4] - b[3], X, Y, A0, cg_steps, "als_cg_team4_rows");
+    launch_team<F, 2, 1024>(C, b[4], b[5] - b[4], X, Y, A0, cg_steps, "als_cg_team2_rows");
+  } else {
+    launch_team<F, 8, 512>(C, b[2], b[3] - b[2], X, Y, A0, cg_steps, "als_cg_team8_rows");
+    launch_team<F, 4, 512>(C, b[3], b[4] - b[3], X, Y, A0, cg_steps, "als_cg_team4_rows");
+    launch_team<F, 2, 512>(C, b[4], b[5] - b[4], X, Y, A0, cg_steps, "als_cg_team2_rows");
+  }
   launch_group<F, true>(C, b[5], b[6] - b[5], X, Y, A0, cg_steps, "als_cg_short_rows");
 }
 

@@ -71,11 +71,23 @@ __global__ __launch_bounds__(256) void gramian_partial_kernel(const float *__res
   }
 }
 
+// out = sum over chunks (fixed order) + reg on the diagonal.  One wavefront per 64 output elements per
+// chunk slice would be overkill: each thread owns one element and walks the chunks with 4 independent
+// accumulators (fixed association -> deterministic).
 __global__ void gramian_reduce_kernel(const float *__restrict__ ws, int chunks, int f, float reg, float *__restrict__ out) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= f * f) return;
-  float s = 0.f;
-  for (int c = 0; c < chunks; ++c) s += ws[(size_t)c * f * f + idx];
+  const size_t stride = (size_t)f * f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int c = 0;
+  for (; c + 4 <= chunks; c += 4) {
+    s0 += ws[(size_t)c * stride + idx];
+    s1 += ws[(size_t)(c + 1) * stride + idx];
+    s2 += ws[(size_t)(c + 2) * stride + idx];
+    s3 += ws[(size_t)(c + 3) * stride + idx];
+  }
+  for (; c < chunks; ++c) s0 += ws[(size_t)c * stride + idx];
+  float s = (s0 + s1) + (s2 + s3);
   int r = idx / f, col = idx - r * f;
   if (r == col) s += reg;
   out[idx] = s;
@@ -115,7 +127,7 @@ void gramian(const float *Y, long n_rows, int f, float reg, float *out) {
   }
   {
     IMP_PROF("gramian_reduce");
-    gramian_reduce_kernel<<<(f * f + 255) / 256, 256, 0, stream()>>>(g_ws.ws.data(), chunks, f, reg, out);
+    gramian_reduce_kernel<<<(f * f + 63) / 64, 64, 0, stream()>>>(g_ws.ws.data(), chunks, f, reg, out);
     IMP_CHECK_HIP(hipGetLastError());
   }
 }

@@ -114,7 +114,9 @@ __device__ __forceinline__ uint64_t make_key(float s, int col) { return ((uint64
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void select_kernel(const float *__restrict__ S, int ni, int k, int kpad,
                                                        int32_t *__restrict__ out_ids, float *__restrict__ out_dist,
-                                                       int out_stride, uint64_t *__restrict__ global_cand, int use_lds) {
+                                                       int out_stride, uint64_t *__restrict__ global_cand, int use_lds,
+                                                       const int *__restrict__ only_flagged) {
+  if (only_flagged && !only_flagged[blockIdx.x]) return;  // rows already finished by select_pruned_kernel
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ unsigned int hist[256];
   __shared__ unsigned int sh_bucket, sh_remaining, sh_count;
@@ -254,6 +256,197 @@ __global__ __launch_bounds__(BLOCK) void select_kernel(const float *__restrict__
   }
 }
 
+
+// ---- fast path (f % 8 == 0): operands straight from global memory, no LDS, no barriers ---------------------------
+// 128 x 128 block tile, 4 waves as 2 x 2, each wave 64 queries x 64 items = 2 x 2 tiles of v_mfma_f32_32x32x2_f32.
+// Lane (r = l & 31, kh = l >> 5) loads ONE float4 = 4 consecutive factors [k0 + 4 kh, +4) of its query / item row per
+// 8-factor block; MFMA step s of the block uses factor k0 + 4 kh + s for BOTH operands (the k index inside an MFMA is
+// a free permutation), so one dwordx4 per operand tile feeds 4 MFMAs.  Epilogue: optional divide by the item norm,
+// coalesced score write, and the per-(query, 64-item) maximum for the pruned select below.
+constexpr int kTileItems = 64;  // granularity of the tile maxima
+
+__global__ __launch_bounds__(256) void score_gemm_direct_kernel(const float *__restrict__ Q, int nq, const float *__restrict__ I,
+                                                                int ni, int f, const float *__restrict__ norms,
+                                                                float *__restrict__ S, float *__restrict__ tile_max,
+                                                                int n_tiles) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, kh = lane >> 5;
+  const int q_base = blockIdx.y * 128 + 64 * (wave >> 1);
+  const int i_base = blockIdx.x * 128 + 64 * (wave & 1);
+  const float *qp[2], *ip[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    qp[t] = Q + (size_t)min(q_base + 32 * t + r, nq - 1) * f + 4 * kh;  // clamped rows: results are discarded
+    ip[t] = I + (size_t)min(i_base + 32 * t + r, ni - 1) * f + 4 * kh;
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+#pragma unroll 2
+  for (int k0 = 0; k0 < f; k0 += 8) {
+    float4 a[2], b[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      a[t] = *reinterpret_cast<const float4 *>(qp[t] + k0);
+      b[t] = *reinterpret_cast<const float4 *>(ip[t] + k0);
+    }
+#pragma unroll
+    for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti) {
+        acc[tq][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tq].x, b[ti].x, acc[tq][ti], 0, 0, 0);
+        acc[tq][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tq].y, b[ti].y, acc[tq][ti], 0, 0, 0);
+        acc[tq][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tq].z, b[ti].z, acc[tq][ti], 0, 0, 0);
+        acc[tq][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tq].w, b[ti].w, acc[tq][ti], 0, 0, 0);
+      }
+  }
+  // C/D layout: column (item) = lane & 31, row (query) = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+  float nrm[2];
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti) {
+    int item = i_base + 32 * ti + r;
+    nrm[ti] = (norms && item < ni) ? norms[item] : 1.f;
+  }
+  const int tile = i_base / kTileItems;
+#pragma unroll
+  for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int q = q_base + 32 * tq + (e & 3) + 8 * (e >> 2) + 4 * kh;
+      float m = -FLT_MAX;
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti) {
+        const int item = i_base + 32 * ti + r;
+        float sc = acc[tq][ti][e];
+        if (norms) sc = sc / nrm[ti];
+        if (item < ni) {
+          if (q < nq) S[(size_t)q * ni + item] = sc;
+          m = fmaxf(m, sc);
+        }
+      }
+      // maximum over the 32 lanes that hold this query row (same lane >> 5)
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+      if (r == 0 && q < nq && tile < n_tiles) tile_max[(size_t)q * n_tiles + tile] = m;
+    }
+}
+
+__global__ void coo_count_kernel(const int32_t *__restrict__ row, size_t nnz, int start, int end, int *__restrict__ counts) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nnz; i += (size_t)gridDim.x * blockDim.x) {
+    int r = row[i];
+    if (r >= start && r < end) atomicAdd(&counts[r - start], 1);
+  }
+}
+
+// Pruned select: tau = the m-th largest tile maximum, m = k + (number of entries the filters may have removed), is a
+// lower bound of the k-th best surviving score (m distinct tiles hold a score >= tau, at most m - k of them filtered).
+// ONE pass over the row collects every score >= tau (a few hundred) into LDS, a bitonic sort orders them and the best
+// k are written.  Rows that overflow the candidate buffer, have too few tiles, or show an exact tie at the k-th score
+// (the reference heap's arrival-order rule then needs the whole row) raise `fallback[row]` and are redone by
+// select_kernel.
+constexpr int kCandCap = 2048;
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void select_pruned_kernel(const float *__restrict__ S, const float *__restrict__ tile_max,
+                                                              int ni, int n_tiles, int k, int extra,
+                                                              const int *__restrict__ filter_counts,
+                                                              int32_t *__restrict__ out_ids, float *__restrict__ out_dist,
+                                                              int out_stride, int *__restrict__ fallback) {
+  __shared__ uint64_t cand[kCandCap];
+  __shared__ unsigned int hist[256];
+  __shared__ unsigned int sh_bucket, sh_remaining, sh_count;
+  const int tid = threadIdx.x;
+  const int q = blockIdx.x;
+  const float *row = S + (size_t)q * ni;
+  const float *tm = tile_max + (size_t)q * n_tiles;
+  const int m = k + extra + (filter_counts ? filter_counts[q] : 0);
+  if (m > n_tiles || k > kCandCap) {  // uniform
+    if (tid == 0) fallback[q] = 1;
+    return;
+  }
+  // m-th largest tile maximum: 4-pass byte radix select over the (L2-resident) maxima
+  uint32_t prefix = 0, mask = 0;
+  unsigned int remaining = m;
+  for (int digit = 3; digit >= 0; --digit) {
+    const int shift = digit * 8;
+    for (int i = tid; i < 256; i += BLOCK) hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n_tiles; i += BLOCK) {
+      uint32_t key = ordered(tm[i]);
+      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 0xFF], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned int acc = 0;
+      int b = 255;
+      for (; b > 0; --b) {
+        if (acc + hist[b] >= remaining) break;
+        acc += hist[b];
+      }
+      sh_bucket = b;
+      sh_remaining = remaining - acc;
+    }
+    __syncthreads();
+    prefix |= (uint32_t)sh_bucket << shift;
+    mask |= 0xFFu << shift;
+    remaining = sh_remaining;
+    __syncthreads();
+  }
+  const uint32_t tau = prefix;  // exact key of the m-th largest maximum
+
+  if (tid == 0) sh_count = 0;
+  __syncthreads();
+  for (int i = tid; i < ni; i += BLOCK) {
+    const float sc = row[i];
+    if (ordered(sc) >= tau) {
+      unsigned int slot = atomicAdd(&sh_count, 1u);
+      if (slot < (unsigned)kCandCap) cand[slot] = make_key(sc, i);
+    }
+  }
+  __syncthreads();
+  const unsigned int n_c = sh_count;
+  if (n_c > (unsigned)kCandCap || n_c < (unsigned)k) {
+    if (tid == 0) fallback[q] = 1;
+    return;
+  }
+  int npad = 2;
+  while (npad < (int)n_c) npad <<= 1;
+  for (int i = n_c + tid; i < npad; i += BLOCK) cand[i] = 0;
+  __syncthreads();
+  for (int size = 2; size <= npad; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (npad >> 1); t += BLOCK) {
+        int lo = 2 * t - (t & (stride - 1));
+        int hi = lo + stride;
+        bool desc = ((lo & size) == 0);
+        uint64_t a = cand[lo], b = cand[hi];
+        if ((a < b) == desc) {
+          cand[lo] = b;
+          cand[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // exact tie at the k-th score -> the heap rule needs the full row
+  const bool tie = (int)n_c > k && (uint32_t)(cand[k - 1] >> 32) == (uint32_t)(cand[k] >> 32);
+  if (tie) {
+    if (tid == 0) fallback[q] = 1;
+    return;
+  }
+  if (tid == 0) fallback[q] = 0;
+  for (int i = tid; i < k; i += BLOCK) {
+    uint64_t key = cand[i];
+    out_ids[(size_t)q * out_stride + i] = (int32_t)(uint32_t)key;
+    out_dist[(size_t)q * out_stride + i] = unordered((uint32_t)(key >> 32));
+  }
+}
+
 static bool is_host_pointer(const void *p) {
   hipPointerAttribute_t attr;
   hipError_t err = hipPointerGetAttributes(&attr, p);
@@ -272,6 +465,15 @@ extern "C" int imp_matrix_astype(const imp_matrix *src, size_t itemsize, imp_mat
 
 struct imp_knn {
   size_t max_temp_memory = 0;
+  // persistent workspaces (grown on demand): no hipMalloc on the query path after the first call
+  DeviceArray<float> scores, tile_max;
+  DeviceArray<uint64_t> gcand;
+  DeviceArray<int32_t> dev_ids, counts, fallback;
+  DeviceArray<float> dev_dist;
+  template <typename T> static T *ensure(DeviceArray<T> &a, size_t n) {
+    if (a.size < n) a.alloc(n);
+    return a.data();
+  }
 };
 
 extern "C" {
@@ -326,18 +528,10 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
     if (kpad < 2) kpad = 2;
 
     const bool host_ids = is_host_pointer(indices), host_dist = is_host_pointer(distances);
-    DeviceArray<int32_t> dev_ids;
-    DeviceArray<float> dev_dist;
     int32_t *d_ids = indices;
     float *d_dist = distances;
-    if (host_ids) {
-      dev_ids.alloc(nq * (size_t)k);
-      d_ids = dev_ids.data();
-    }
-    if (host_dist) {
-      dev_dist.alloc(nq * (size_t)k);
-      d_dist = dev_dist.data();
-    }
+    if (host_ids) d_ids = imp_knn::ensure(knn->dev_ids, nq * (size_t)k);
+    if (host_dist) d_dist = imp_knn::ensure(knn->dev_dist, nq * (size_t)k);
     if (k_eff < k) {
       // entries past k_eff keep the caller's initial values (topk.pyx:20-21 zero-fills them)
       if (host_ids) IMP_CHECK_HIP(hipMemcpyAsync(d_ids, indices, nq * (size_t)k * 4, hipMemcpyHostToDevice, stream()));
@@ -346,33 +540,58 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
 
     size_t temp = std::min<size_t>(knn->max_temp_memory, (size_t)4 << 30);
     size_t batch = std::max<size_t>(1, std::min<size_t>(nq, temp / (sizeof(float) * ni)));
-    DeviceArray<float> scores;
-    scores.alloc(batch * ni);
+    float *scores = imp_knn::ensure(knn->scores, batch * ni);
     const bool use_lds = (size_t)kpad * 8 <= 96 * 1024;
-    DeviceArray<uint64_t> gcand;
-    if (!use_lds) gcand.alloc(batch * (size_t)kpad);
+    uint64_t *gcand = use_lds ? nullptr : imp_knn::ensure(knn->gcand, batch * (size_t)kpad);
+
+    // fast path: direct-operand MFMA GEMM with tile maxima + single-pass pruned select
+    static const bool no_fast = getenv("IMP_TOPK_NO_FAST") != nullptr;
+    const bool fast = !no_fast && (f % 8 == 0) && k_eff <= kCandCap;
+    const int n_tiles = (int)((ni + kTileItems - 1) / kTileItems);
+    float *tile_max = fast ? imp_knn::ensure(knn->tile_max, batch * (size_t)n_tiles) : nullptr;
+    int *fallback = fast ? imp_knn::ensure(knn->fallback, batch) : nullptr;
+    int *counts = (fast && query_filter && query_filter->nnz) ? imp_knn::ensure(knn->counts, batch) : nullptr;
+    const int extra = item_filter ? (int)item_filter->size : 0;
 
     for (size_t start = 0; start < nq; start += batch) {
       size_t end = std::min(nq, start + batch), rows = end - start;
-      {
+      if (fast) {
         IMP_PROF("score_gemm");
+        dim3 grid((unsigned)((ni + 127) / 128), (unsigned)((rows + 127) / 128));
+        score_gemm_direct_kernel<<<grid, 256, 0, stream()>>>(query->f32() + start * f, (int)rows, items->f32(), (int)ni, f,
+                                                             item_norms ? item_norms->f32() : nullptr, scores, tile_max,
+                                                             n_tiles);
+        IMP_CHECK_HIP(hipGetLastError());
+      } else {
+        IMP_PROF("score_gemm_lds");
         dim3 grid((unsigned)((ni + kBN - 1) / kBN), (unsigned)((rows + kBM - 1) / kBM));
         score_gemm_kernel<<<grid, 256, 0, stream()>>>(query->f32() + start * f, (int)rows, items->f32(), (int)ni, f,
-                                                      item_norms ? item_norms->f32() : nullptr, scores.data());
+                                                      item_norms ? item_norms->f32() : nullptr, scores);
         IMP_CHECK_HIP(hipGetLastError());
       }
       if (item_filter && item_filter->size) {
         IMP_PROF("item_filter");
         size_t total = rows * item_filter->size;
         int grid = (int)std::min<size_t>((total + 255) / 256, (size_t)ctx().num_cus * 8);
-        item_filter_kernel<<<grid, 256, 0, stream()>>>(scores.data(), (int)rows, (int)ni, item_filter->v.data(), (int)item_filter->size);
+        item_filter_kernel<<<grid, 256, 0, stream()>>>(scores, (int)rows, (int)ni, item_filter->v.data(), (int)item_filter->size);
         IMP_CHECK_HIP(hipGetLastError());
       }
       if (query_filter && query_filter->nnz) {
         IMP_PROF("coo_filter");
         int grid = (int)std::min<size_t>(((size_t)query_filter->nnz + 255) / 256, (size_t)ctx().num_cus * 8);
-        coo_filter_kernel<<<grid, 256, 0, stream()>>>(scores.data(), (int)start, (int)end, (int)ni, query_filter->row.data(),
+        coo_filter_kernel<<<grid, 256, 0, stream()>>>(scores, (int)start, (int)end, (int)ni, query_filter->row.data(),
                                                       query_filter->col.data(), (size_t)query_filter->nnz);
+        if (counts) {
+          IMP_CHECK_HIP(hipMemsetAsync(counts, 0, rows * sizeof(int), stream()));
+          coo_count_kernel<<<grid, 256, 0, stream()>>>(query_filter->row.data(), (size_t)query_filter->nnz, (int)start, (int)end,
+                                                       counts);
+        }
+        IMP_CHECK_HIP(hipGetLastError());
+      }
+      if (fast) {
+        IMP_PROF("topk_select_pruned");
+        select_pruned_kernel<512><<<(unsigned)rows, 512, 0, stream()>>>(scores, tile_max, (int)ni, n_tiles, k_eff, extra, counts,
+                                                                       d_ids + start * k, d_dist + start * k, k, fallback);
         IMP_CHECK_HIP(hipGetLastError());
       }
       {
@@ -381,8 +600,8 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
         auto kern = select_kernel<512>;
         IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)std::max<size_t>(lds, 1)));
-        kern<<<(unsigned)rows, 512, lds, stream()>>>(scores.data(), (int)ni, k_eff, kpad, d_ids + start * k, d_dist + start * k, k,
-                                                     gcand.data(), use_lds ? 1 : 0);
+        kern<<<(unsigned)rows, 512, lds, stream()>>>(scores, (int)ni, k_eff, kpad, d_ids + start * k, d_dist + start * k, k, gcand,
+                                                     use_lds ? 1 : 0, fast ? fallback : nullptr);
         IMP_CHECK_HIP(hipGetLastError());
       }
     }

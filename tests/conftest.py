@@ -3,7 +3,7 @@ import sys
 import warnings
 
 # scipy-openblas is built for <= 64 threads and crashes on the 256-core GPU box without this
-os.environ.setdefault("OPENBLAS_NUM_THREADS", "64")
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
 
 import pytest
 

@@ -130,12 +130,12 @@ def test_oracle_vs_compiled_reference(oracle, f):
         for M, A, B in ((C, X, Y), (Ct, Y, X)):
             mine = A.copy()
             oracle.least_squares_cg(M, mine, B, 0.01)
-            als.least_squares_cg(M, A, B, 0.01, num_threads=0, cg_steps=3)
+            als.least_squares_cg(M, A, B, 0.01, num_threads=4, cg_steps=3)
             tol = 2e-3 if it == 0 else 5e-5  # cold first iteration: ill-conditioned, see SURVEY App. A.5
             assert rel(mine, A) < tol, (f, it)
     mine, theirs = X.copy(), X.copy()
     oracle.least_squares(C, mine, Y, 0.01)
-    als.least_squares(C, theirs, Y, 0.01, num_threads=0)
+    als.least_squares(C, theirs, Y, 0.01, num_threads=4)
     assert rel(mine, theirs) < 5e-5
     assert oracle.calculate_loss(C, X, Y, 0.01) == pytest.approx(als.calculate_loss(C, X, Y, 0.01), rel=1e-5)
     q = X[:50]
