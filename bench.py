@@ -50,6 +50,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-topk", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--solver", choices=["cg", "cholesky"], default="cg", help="cholesky = BASELINE configs[1] style run")
+    ap.add_argument("--factors", type=int, default=FACTORS)
     return ap.parse_args()
 
 
@@ -77,6 +79,35 @@ def class_bytes_per_iteration(Cui, Ciu, f):
             if sel.any():
                 out[name] += cg_algorithmic_bytes(lens[sel], f)
     return out
+
+
+# substring of the kernel function name -> (schedule class, dispatches per half sweep as a function of cg_steps)
+PMC_KERNELS = {"als_cg_group_kernel": ("short", lambda s: 1), "als_cg_team_kernel": ("mid", lambda s: 1),
+               "cg_long_partial_kernel": ("long", lambda s: 1 + s), "cg_long_combine_kernel": ("long", lambda s: 1 + s)}
+
+
+def pmc_traffic_per_half_sweep(cg_steps):
+    """HBM bytes per half sweep of each row class from the newest committed rocprofv3 PMC summary
+    (profiles/*_pmc_summary.json, produced by profiles/collect.sh on this same bench command): corrected
+    FETCH_SIZE (x2 on gfx950, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, summed over the class's kernels
+    (the mid class runs four team widths = four kernel instantiations, each dispatched once per half sweep)."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    if not files:
+        return None, None
+    summary = json.load(open(files[-1]))
+    out = {}
+    for kname, d in summary.items():
+        for sub, (cls, per_sweep) in PMC_KERNELS.items():
+            if sub in kname and "hbm_read_bytes_per_dispatch_corrected" in d:
+                # cg_long_partial has two instantiations (first pass / later passes): 1 and cg_steps dispatches
+                n = per_sweep(cg_steps)
+                if sub == "cg_long_partial_kernel":
+                    n = 1 if kname.rstrip(">").endswith("true") else cg_steps
+                out[cls] = out.get(cls, 0.0) + n * (d["hbm_read_bytes_per_dispatch_corrected"] +
+                                                     d.get("hbm_write_bytes_per_dispatch", 0.0))
+    return out, os.path.basename(files[-1])
 
 
 def cpu_baseline(Cui, Ciu, X0, Y0, seconds):
@@ -108,22 +139,30 @@ def cpu_baseline(Cui, Ciu, X0, Y0, seconds):
             port.least_squares_cg(M, A, B, REG, num_threads=cores, cg_steps=CG_STEPS)
         return time.time() - t
 
-    # probe on 2000 rows of each side, then size the sample for ~`seconds`
-    pu, pi = min(2000, Cui.shape[0]), min(2000, Ciu.shape[0])
-    t_probe = run(Cui[:pu], X0[:pu], Y0) + run(Ciu[:pi], Y0[:pi], X0)
+    # uniform row samples (every stride-th row: ids are popularity-ordered, a prefix would not be representative);
+    # probe on ~2000 rows of each side, then size the sample for ~`seconds`
+    def sample(M, A, n):
+        stride = max(1, M.shape[0] // max(1, n))
+        rows = np.arange(0, M.shape[0], stride)
+        return M[rows], np.ascontiguousarray(A[rows])
+
+    def timed(nu, ni):
+        Mu, Au = sample(Cui, X0, nu)
+        Mi, Ai = sample(Ciu, Y0, ni)
+        return run(Mu, Au, Y0) + run(Mi, Ai, X0), Mu.shape[0], Mi.shape[0], int(Mu.nnz + Mi.nnz)
+
+    t_probe, pu, pi, _ = timed(2000, 2000)
     rate = (pu + pi) / max(t_probe, 1e-6)
     frac = min(1.0, seconds * rate / (Cui.shape[0] + Ciu.shape[0]))
-    su, si = max(pu, int(Cui.shape[0] * frac)), max(pi, int(Ciu.shape[0] * frac))
-    t = run(Cui[:su], X0[:su], Y0) + run(Ciu[:si], Y0[:si], X0)
+    t, su, si, nnz = timed(max(2000, int(Cui.shape[0] * frac)), max(2000, int(Ciu.shape[0] * frac)))
     if limiter is not None:
         limiter.restore_original_limits()
-    nnz = int(Cui.indptr[su] + Ciu.indptr[si])
     return {
         "value": (su + si) / t,
         "unit": "updates/s",
         "cores": cores,
         "kind": kind,
-        "sample": f"one CG(cg_steps=3,f={X0.shape[1]}) half-sweep over the first {su} users + first {si} items "
+        "sample": f"one CG(cg_steps=3,f={X0.shape[1]}) half-sweep over {su} users + {si} items taken at a uniform stride "
                   f"({nnz} nnz) of the same matrix, {t:.1f}s, OpenMP num_threads={cores} of {os.cpu_count()} logical cores, "
                   f"BLAS threads=1",
         "nnz_visits_per_s": nnz / t,
@@ -131,7 +170,9 @@ def cpu_baseline(Cui, Ciu, X0, Y0, seconds):
 
 
 def main():
+    global FACTORS
     args = parse_args()
+    FACTORS = args.factors
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -178,10 +219,16 @@ def main():
     t_upload = time.time() - t0
 
     def step():
-        solver.calculate_yty(Y, gram, REG)
-        solver.least_squares(Cui_d, X, gram, Y, CG_STEPS)
-        solver.calculate_yty(X, gram, REG)
-        solver.least_squares(Ciu_d, Y, gram, X, CG_STEPS)
+        if args.solver == "cg":
+            solver.calculate_yty(Y, gram, REG)
+            solver.least_squares(Cui_d, X, gram, Y, CG_STEPS)
+            solver.calculate_yty(X, gram, REG)
+            solver.least_squares(Ciu_d, Y, gram, X, CG_STEPS)
+        else:
+            solver.calculate_yty(Y, gram, 0.0)
+            solver.least_squares_cholesky(Cui_d, X, gram, Y, REG)
+            solver.calculate_yty(X, gram, 0.0)
+            solver.least_squares_cholesky(Ciu_d, Y, gram, X, REG)
 
     for _ in range(args.warmup):
         step()
@@ -219,9 +266,13 @@ def main():
         sweeps = 2 * args.steps  # the class runs once per half sweep (mid: one launch per team width)
         total_ms = d["ms_per_step"] * args.steps
         bytes_per_sweep = cbytes[dom] / 2.0
+        traffic, traffic_src = (None, None)
+        if (args.shape, args.scale, args.solver, FACTORS) == ("lastfm360k", 1.0, "cg", 128):
+            traffic, traffic_src = pmc_traffic_per_half_sweep(CG_STEPS)
         roofline = {"bound": "hbm", "kernel": "+".join(CLASS_KERNELS[dom]), "row_class": dom,
                     "achieved": d["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": d["achieved_GBps"] / HBM_PEAK_GBS, "traffic": None,
+                    "frac": d["achieved_GBps"] / HBM_PEAK_GBS,
+                    "traffic": traffic.get(dom) if traffic else None, "traffic_source": traffic_src,
                     "avg_launch_ms": total_ms / max(1, kernels[CLASS_KERNELS[dom][0]]["launches"]),
                     "avg_ms_per_half_sweep": total_ms / sweeps,
                     "algorithmic_bytes_per_half_sweep": bytes_per_sweep,
@@ -247,9 +298,10 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"BASELINE configs[2]: last.fm-360K-shaped synthetic CSR, ALS CG cg_steps={CG_STEPS}"
-                        if args.shape == "lastfm360k" and args.scale == 1.0 else f"{args.shape} x{args.scale} (debug)",
+                        if (args.shape, args.scale, args.solver, FACTORS) == ("lastfm360k", 1.0, "cg", 128)
+                        else f"{args.shape} x{args.scale} f={FACTORS} {args.solver} (not the headline configuration)",
             "users": users, "items": items, "nnz": int(Cui.nnz), "factors": FACTORS, "regularization": REG,
-            "solver": "cg", "cg_steps": CG_STEPS, "parallelism": "1 GPU",
+            "solver": args.solver, "cg_steps": CG_STEPS if args.solver == "cg" else None, "parallelism": "1 GPU",
         },
         "nnz_visits_per_s": 2 * int(Cui.nnz) / (elapsed / args.steps),
         "roofline": roofline,

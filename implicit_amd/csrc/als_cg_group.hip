@@ -158,13 +158,18 @@ __global__ __launch_bounds__(1024) void als_cg_group_kernel(const int32_t *__res
 // (the factor rows are gathered ONCE), applies the gramian rows [f sub / WPR, f (sub+1) / WPR) on the VALU, and the
 // WPR partial vectors are summed through LDS in a fixed order; every wave of the team then performs the same
 // CG update on identical bits.  A 1024-thread workgroup runs 16 / WPR teams in lockstep.
+// Optional phase timers (s_memtime ticks summed over waves): [0] row metadata + x, [1] tile gather (drained),
+// [2] compute between barriers, [3] barrier waits, [4] groups.  Enabled by IMP_CG_STATS=1 (debug only).
+#define IMP_TICK() (stats ? __builtin_amdgcn_s_memtime() : 0ull)
+
 template <int F, int WPR, int BLOCK>
 __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 4 : 4) void als_cg_team_kernel(const int32_t *__restrict__ order, int first, int count,
                                                            const int32_t *__restrict__ indptr,
                                                            const int32_t *__restrict__ indices,
                                                            const float *__restrict__ data, float *__restrict__ X,
                                                            const float *__restrict__ Y, const float *__restrict__ A0,
-                                                           int cg_steps) {
+                                                           int cg_steps, unsigned long long *__restrict__ stats) {
+  unsigned long long t_meta = 0, t_gather = 0, t_comp = 0, t_bar = 0, n_groups = 0, t0 = 0, t1 = 0;
   constexpr int VPL = F / 64, T = 32, WAVES = BLOCK / 64, TEAMS = WAVES / WPR;
   static_assert(WPR <= WAVES, "a team cannot be wider than the workgroup");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -180,7 +185,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 4 : 4) void als_cg_team_kerne
   auto combine = [&](float (&acc)[VPL]) {
 #pragma unroll
     for (int v = 0; v < VPL; ++v) scratch[wave * F + lane * VPL + v] = acc[v];
+    t1 = IMP_TICK();
+    t_comp += t1 - t0;
     __syncthreads();
+    t0 = IMP_TICK();
+    t_bar += t0 - t1;
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
       float s = 0.f;
@@ -188,7 +197,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 4 : 4) void als_cg_team_kerne
       for (int w = 0; w < WPR; ++w) s += scratch[(team * WPR + w) * F + lane * VPL + v];
       acc[v] = s;
     }
+    t1 = IMP_TICK();
+    t_comp += t1 - t0;
     __syncthreads();
+    t0 = IMP_TICK();
+    t_bar += t0 - t1;
   };
 
   const int groups = (count + TEAMS - 1) / TEAMS;
@@ -196,6 +209,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 4 : 4) void als_cg_team_kerne
     const int i = g * TEAMS + team;
     const bool valid = i < count;
     int u = 0, row_begin = 0, row_end = 0;
+    t0 = IMP_TICK();
     if (valid) {
       u = __builtin_amdgcn_readfirstlane(order[first + i]);
       row_begin = __builtin_amdgcn_readfirstlane(indptr[u]);
@@ -206,9 +220,22 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 4 : 4) void als_cg_team_kerne
 #pragma unroll
     for (int v = 0; v < VPL; ++v) x[v] = 0.f;
     if (valid) load_row<VPL, true>(xrow, F, lane, x);
+    if (stats) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      t1 = IMP_TICK();
+      t_meta += t1 - t0;
+      t0 = t1;
+    }
     const int k0 = row_begin + T * sub;  // this wave's slice of the row (may be empty)
     Tile<VPL, T> tile;
     load_tile<VPL, T>(tile, indices, data, Y, F, lane, min(k0, row_end), row_end);
+    if (stats) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      t1 = IMP_TICK();
+      t_gather += t1 - t0;
+      t0 = t1;
+      ++n_groups;
+    }
 
     // r = -(A0 x) + sum_k (c+ - (|c|-1) y.x) y        (_als.pyx:187-201)
 #pragma unroll
@@ -254,6 +281,14 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 4 : 4) void als_cg_team_kerne
 #pragma unroll
       for (int v = 0; v < VPL; ++v) xrow[lane * VPL + v] = x[v];
     }
+    if (stats) t_comp += IMP_TICK() - t0;
+  }
+  if (stats && lane == 0) {
+    atomicAdd(&stats[0], t_meta);
+    atomicAdd(&stats[1], t_gather);
+    atomicAdd(&stats[2], t_comp);
+    atomicAdd(&stats[3], t_bar);
+    atomicAdd(&stats[4], n_groups);
   }
 }
 
@@ -282,10 +317,26 @@ static void launch_team(const imp_csr *C, int first, int count, float *X, const 
   IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / BLOCK, (160 * 1024) / lds));
   int grid = std::min((count + TEAMS - 1) / TEAMS, ctx().num_cus * per_cu);
-  IMP_PROF(name);
-  kern<<<grid, BLOCK, lds, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(), C->data.data(), X, Y, A0,
-                                      cg_steps);
-  IMP_CHECK_HIP(hipGetLastError());
+  static unsigned long long *stats = nullptr;
+  static const bool want_stats = getenv("IMP_CG_STATS") != nullptr;
+  if (want_stats && !stats) {
+    IMP_CHECK_HIP(hipMalloc(&stats, 8 * sizeof(unsigned long long)));
+  }
+  if (want_stats) IMP_CHECK_HIP(hipMemsetAsync(stats, 0, 8 * sizeof(unsigned long long), stream()));
+  {
+    IMP_PROF(name);
+    kern<<<grid, BLOCK, lds, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(), C->data.data(), X, Y,
+                                        A0, cg_steps, want_stats ? stats : nullptr);
+    IMP_CHECK_HIP(hipGetLastError());
+  }
+  if (want_stats) {
+    unsigned long long h[8];
+    IMP_CHECK_HIP(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, stream()));
+    sync();
+    double waves = (double)grid * (BLOCK / 64);
+    fprintf(stderr, "[cg-stats] %s grid=%d waves=%.0f groups/wave=%.1f  per-group ticks: meta %.0f gather %.0f compute %.0f barrier %.0f\n",
+            name, grid, waves, h[4] / waves, (double)h[0] / h[4], (double)h[1] / h[4], (double)h[2] / h[4], (double)h[3] / h[4]);
+  }
 }
 
 template <int F>

@@ -15,7 +15,7 @@ __device__ __forceinline__ void gram_matvec(const float *A0s, int LD, int lane, 
     // factor j = elem(l, v); walk only the lanes l whose j lies in [j_begin, j_end)
     const int l_begin = VEC ? (j_begin - v + VPL - 1) / VPL : max(j_begin - 64 * v, 0);
     const int l_end = VEC ? min(64, (j_end - v + VPL - 1) / VPL) : min(64, j_end - 64 * v);
-#pragma unroll 4
+#pragma unroll 8
     for (int l = l_begin; l < l_end; ++l) {
       const int j = VEC ? l * VPL + v : l + 64 * v;
       float pj = lane_bcast(vec[v], l);
@@ -57,8 +57,9 @@ __device__ __forceinline__ float row_allsum(float v) {
 }
 
 template <int VPL, int T> struct Tile {
-  float y[T][VPL];   // gathered factor rows (zero beyond cnt)
-  float c[T / 4];    // confidences of the entries this lane's row owns after the reduce-scatter
+  float y[T][VPL];   // gathered factor rows (entries beyond cnt repeat a valid row or are zero)
+  float cm1[T / 4];  // |c| - 1 of the entries this lane's 16-lane row owns after the reduce-scatter (0 if invalid)
+  float cpos[T / 4]; // max(c, 0) of the same entries (0 if invalid); only the first pass reads it
   int cnt;           // valid entries (wave-uniform)
 };
 
@@ -73,7 +74,12 @@ __device__ __forceinline__ void load_tile(Tile<VPL, T> &tile, const int32_t *__r
   const int my_idx = cnt > 0 ? indices[k0 + min(lane, cnt - 1)] : 0;
   const int base = k0 + J * (lane >> 4);
 #pragma unroll
-  for (int j = 0; j < J; ++j) tile.c[j] = base + j < end ? data[base + j] : 0.f;
+  for (int j = 0; j < J; ++j) {
+    const bool ok = base + j < end;
+    const float c = ok ? data[base + j] : 0.f;
+    tile.cm1[j] = ok ? fabsf(c) - 1.f : 0.f;  // invalid slots get weight 0 in every pass
+    tile.cpos[j] = c > 0.f ? c : 0.f;
+  }
   // all column ids first (one wait on the index load), then the gathers back to back in groups of 8
   unsigned col[T];
 #pragma unroll
@@ -101,17 +107,30 @@ __device__ __forceinline__ void tile_apply(const Tile<VPL, T> &tile, int lane, i
   for (int t = 0; t < T; ++t) part[t] = dot_local<VPL>(tile.y[t], vec);
   float h[T / 2];
 #pragma unroll
-  for (int t = 0; t < T / 2; ++t) h[t] = swap32_sum(part[t], part[t + T / 2]);
+  for (int t = 0; t < T / 2; t += 4) {
+    float *lo = &part[t], *hi = &part[t + T / 2];
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\t"
+                 "v_permlane32_swap_b32 %2, %6\n\tv_permlane32_swap_b32 %3, %7"
+                 : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) h[t + u] = lo[u] + hi[u];
+  }
   float q[J];
 #pragma unroll
-  for (int j = 0; j < J; ++j) q[j] = swap16_sum(h[j], h[j + J]);
+  for (int j = 0; j < J; j += 4) {
+    float *lo = &h[j], *hi = &h[j + J];
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\t"
+                 "v_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7"
+                 : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) q[j + u] = lo[u] + hi[u];
+  }
   float w[J];
-  const int base = k0 + J * (lane >> 4);
 #pragma unroll
   for (int j = 0; j < J; ++j) {
     float d = row_allsum(q[j]);
-    float wj = nnz_weight<FIRST>(tile.c[j], d);
-    w[j] = base + j < end ? wj : 0.f;
+    // FIRST: c+ - (|c|-1) d   else: (|c|-1) d     (_als.pyx:190-201, 214-222); same operations as nnz_weight
+    w[j] = FIRST ? tile.cpos[j] - tile.cm1[j] * d : tile.cm1[j] * d;
   }
 #pragma unroll
   for (int g = 0; g < T / 8; ++g) {
