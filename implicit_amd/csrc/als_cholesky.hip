@@ -128,6 +128,93 @@ __global__ __launch_bounds__(256) void als_cholesky_kernel(const int32_t *__rest
   }
 }
 
+
+// ---- f <= 64: one WAVEFRONT per row, the whole system in registers ---------------------------------------------
+// Lane i owns row i of A (64 VGPRs) and b[i].  A-build: for every nonzero the gathered factor row arrives as one
+// coalesced wave load (lane j holds y[j]); y[j] is broadcast with v_readlane and lane i accumulates
+// A[i][j] += ((|c|-1) y[i]) * y[j] for all j.  Right-looking Cholesky with the k loop fully unrolled (static register
+// indices): pivot and column entries travel by v_readlane, no LDS and no barrier; the forward substitution rides
+// along (b is treated as an extra column); the back substitution does one wave reduction per unknown.
+// ~100 VALU instructions per nonzero + ~5.5K per row instead of 3 block barriers per column.
+template <int FMAX>
+__global__ __launch_bounds__(256) void als_cholesky_wave_kernel(const int32_t *__restrict__ order, int first, int count,
+                                                                const int32_t *__restrict__ indptr,
+                                                                const int32_t *__restrict__ indices,
+                                                                const float *__restrict__ data, float *__restrict__ X,
+                                                                const float *__restrict__ Y, const float *__restrict__ YtY,
+                                                                int f, float reg, unsigned long long *failed_row) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const bool row_ok = lane < f;
+  for (int ri = wave; ri < count; ri += nwaves) {
+    const int u = __builtin_amdgcn_readfirstlane(order[first + ri]);
+    const int row_begin = __builtin_amdgcn_readfirstlane(indptr[u]);
+    const int row_end = __builtin_amdgcn_readfirstlane(indptr[u + 1]);
+    float A[FMAX];
+    float b = 0.f;
+    // A = YtY + reg I   (row `lane`; rows/cols >= f are the identity so the unrolled factorisation stays finite)
+#pragma unroll
+    for (int j = 0; j < FMAX; ++j) {
+      float a = (row_ok && j < f) ? YtY[(size_t)lane * f + j] : 0.f;
+      A[j] = a + ((j == lane) ? (j < f ? reg : 1.f) : 0.f);
+    }
+    for (int k0 = row_begin; k0 < row_end; k0 += 64) {
+      const int cnt = min(64, row_end - k0);
+      const int my_idx = indices[k0 + min(lane, cnt - 1)];
+      const float my_c = lane < cnt ? data[k0 + lane] : 0.f;
+      for (int t0 = 0; t0 < cnt; t0 += 8) {
+        // 8 gathers in flight per trip (entries past cnt repeat the last valid row with confidence 1 -> weight 0)
+        float y8[8], c8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int t = min(t0 + q, cnt - 1);
+          const unsigned col = (unsigned)__builtin_amdgcn_readlane(my_idx, t);
+          c8[q] = t0 + q < cnt ? bcast_lane(my_c, t) : 1.f;
+          y8[q] = row_ok ? Y[(size_t)col * f + lane] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float c = c8[q], y = y8[q];
+          const float a = c > 0.f ? c : -c;
+          if (t0 + q < cnt && c > 0.f) b = fmaf(c, y, b);  // wave-uniform branch
+          const float wy = (a - 1.f) * y;
+#pragma unroll
+          for (int j = 0; j < FMAX; ++j) A[j] = fmaf(wy, bcast_lane(y, j), A[j]);
+        }
+      }
+    }
+    // Cholesky A = L L^T in place (lane i keeps L[i][0..i]); z = L^-1 b in `b`
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < FMAX; ++k) {
+      const float d = bcast_lane(A[k], k);  // pivot
+      if (!(d > 0.f)) ok = false;
+      const float inv = 1.0f / sqrtf(d);
+      const float lik = lane == k ? sqrtf(d) : A[k] * inv;  // L[i][k] for i >= k (rows above k hold garbage, unused)
+      A[k] = lik;
+      const float zk = bcast_lane(b, k) * inv;  // z_k = b_k / L_kk
+      b = lane == k ? zk : fmaf(-lik, zk, b);
+#pragma unroll
+      for (int j = k + 1; j < FMAX; ++j) A[j] = fmaf(-lik, bcast_lane(lik, j), A[j]);
+    }
+    if (!ok) {
+      if (lane == 0) atomicMin(failed_row, (unsigned long long)u);
+      continue;
+    }
+    // back substitution L^T x = z:  x_k = (z_k - sum_{i>k} L[i][k] x_i) / L[k][k]; lane i ends with x_i in `b`
+#pragma unroll
+    for (int k = FMAX - 1; k >= 0; --k) {
+      float t = lane > k ? A[k] * b : 0.f;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+      const float xk = (bcast_lane(b, k) - t) / bcast_lane(A[k], k);
+      if (lane == k) b = xk;
+    }
+    if (row_ok) X[(size_t)u * f + lane] = b;
+  }
+}
+
 void zero_rows(const int32_t *order, int first, int count, float *X, int f);  // als_cg.hip
 
 static unsigned long long *g_failed = nullptr;
@@ -141,13 +228,31 @@ int64_t least_squares_cholesky(const imp_csr *C, imp_matrix *X, const imp_matrix
   if (!g_failed) IMP_CHECK_HIP(hipMalloc(&g_failed, sizeof(unsigned long long)));
   IMP_CHECK_HIP(hipMemsetAsync(g_failed, 0xFF, sizeof(unsigned long long), stream()));
   int nonempty = C->nonempty();
-  if (nonempty > 0) {
+  static const bool no_wave = getenv("IMP_CHOL_NO_WAVE") != nullptr;
+  // f <= 64: rows up to 256 nnz go to the register-resident wave kernel; longer rows (and any larger f) to the
+  // workgroup kernel, whose 256 threads share the A-build of one row
+  const int n_block = (f <= 64 && !no_wave) ? C->bin_start[2] : nonempty;
+  const int n_wave = nonempty - n_block;
+  if (n_wave > 0) {
+    int grid = std::min((n_wave + 3) / 4, ctx().num_cus * 8);
+    IMP_PROF("als_cholesky_wave_rows");
+    if (f <= 32)
+      als_cholesky_wave_kernel<32><<<grid, 256, 0, stream()>>>(C->order.data(), n_block, n_wave, C->indptr.data(),
+                                                               C->indices.data(), C->data.data(), X->f32(), Y->f32(),
+                                                               YtY->f32(), f, (float)reg, g_failed);
+    else
+      als_cholesky_wave_kernel<64><<<grid, 256, 0, stream()>>>(C->order.data(), n_block, n_wave, C->indptr.data(),
+                                                               C->indices.data(), C->data.data(), X->f32(), Y->f32(),
+                                                               YtY->f32(), f, (float)reg, g_failed);
+    IMP_CHECK_HIP(hipGetLastError());
+  }
+  if (n_block > 0) {
     IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(als_cholesky_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
-    int grid = std::min(nonempty, ctx().num_cus * per_cu);
+    int grid = std::min(n_block, ctx().num_cus * per_cu);
     IMP_PROF("als_cholesky_rows");
-    als_cholesky_kernel<<<grid, 256, lds, stream()>>>(C->order.data(), 0, nonempty, C->indptr.data(), C->indices.data(),
+    als_cholesky_kernel<<<grid, 256, lds, stream()>>>(C->order.data(), 0, n_block, C->indptr.data(), C->indices.data(),
                                                       C->data.data(), X->f32(), Y->f32(), YtY->f32(), f, (float)reg, lda,
                                                       g_failed);
     IMP_CHECK_HIP(hipGetLastError());
