@@ -64,7 +64,7 @@ def cg_algorithmic_bytes(lengths, f):
 
 SHORT_ROW, LONG_ROW = 32, 512  # imp_csr::kShortRow / kLongRow
 # schedule class -> the kernels that execute it (long rows: one partial + one combine launch per CG pass)
-CLASS_KERNELS = {"short": ["als_cg_short_rows"],
+CLASS_KERNELS = {"short": ["als_cg_short_rows", "als_cg_short16_rows"],
                  "mid": ["als_cg_team2_rows", "als_cg_team4_rows", "als_cg_team8_rows", "als_cg_team16_rows"],
                  "long": ["als_cg_long_partial", "als_cg_long_combine"]}
 

@@ -370,7 +370,7 @@ static void launch_long(const imp_csr *C, float *X, const float *Y, const float 
 
 template <int VPL, bool VEC, bool A_LDS>
 static void launch_all(const imp_csr *C, float *X, const float *Y, const float *A0, int f, int cg_steps) {
-  // schedule classes (imp_csr): 0 long (segment-split), 1..4 mid, 5 short, 6 empty
+  // schedule classes (imp_csr): 0 long (segment-split), 1..4 mid, 5..6 short, 7 empty
   const int32_t *b = C->bin_start;
   launch_long<VPL, VEC, A_LDS>(C, X, Y, A0, f, cg_steps);
   static const bool no_group = getenv("IMP_NO_GROUP") != nullptr;  // A/B switch: generic one-wave-per-row kernels
@@ -382,10 +382,10 @@ static void launch_all(const imp_csr *C, float *X, const float *Y, const float *
     if constexpr (VEC) {
       if (resident_ok) {
         launch_fused<VPL, VEC, A_LDS, false>(C, b[1], b[5] - b[1], X, Y, A0, f, cg_steps, "als_cg_mid_rows");
-        launch_fused<VPL, VEC, A_LDS, true>(C, b[5], b[6] - b[5], X, Y, A0, f, cg_steps, "als_cg_short_rows");
+        launch_fused<VPL, VEC, A_LDS, true>(C, b[5], b[7] - b[5], X, Y, A0, f, cg_steps, "als_cg_short_rows");
       }
     }
-    if (!resident_ok) launch_fused<VPL, VEC, A_LDS, false>(C, b[1], b[6] - b[1], X, Y, A0, f, cg_steps, "als_cg_mid_rows");
+    if (!resident_ok) launch_fused<VPL, VEC, A_LDS, false>(C, b[1], b[7] - b[1], X, Y, A0, f, cg_steps, "als_cg_mid_rows");
   }
   zero_rows(C->order.data(), C->first_empty(), C->n_empty(), X, f);
 }

@@ -68,7 +68,7 @@ __device__ __forceinline__ void group_gram_matvec(const float *A0s, float *Ps, f
   }
 }
 
-template <int F, bool RESIDENT>
+template <int F, bool RESIDENT, int T>
 __global__ __launch_bounds__(1024) void als_cg_group_kernel(const int32_t *__restrict__ order, int first, int count,
                                                             const int32_t *__restrict__ indptr,
                                                             const int32_t *__restrict__ indices,
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(1024) void als_cg_group_kernel(const int32_t *__res
                                                             const float *__restrict__ Y, const float *__restrict__ A0,
                                                             int cg_steps) {
   using Cfg = GroupCfg<F>;
-  constexpr int VPL = Cfg::VPL, LD = Cfg::LD, T = 32;
+  constexpr int VPL = Cfg::VPL, LD = Cfg::LD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *A0s = smem;
   float *Ps = A0s + (size_t)F * LD;
@@ -292,12 +292,12 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 512 ? 4 : 4) void als_cg_team_kerne
   }
 }
 
-template <int F, bool RESIDENT>
+template <int F, bool RESIDENT, int T>
 static void launch_group(const imp_csr *C, int first, int count, float *X, const float *Y, const float *A0, int cg_steps,
                          const char *name) {
   if (count <= 0) return;
   size_t lds = GroupCfg<F>::lds_floats * sizeof(float);
-  auto kern = als_cg_group_kernel<F, RESIDENT>;
+  auto kern = als_cg_group_kernel<F, RESIDENT, T>;
   IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / lds));
   int grid = std::min((count + 15) / 16, ctx().num_cus * per_cu);
@@ -341,7 +341,7 @@ static void launch_team(const imp_csr *C, int first, int count, float *X, const 
 
 template <int F>
 static void run_classes(const imp_csr *C, float *X, const float *Y, const float *A0, int cg_steps) {
-  const int32_t *b = C->bin_start;  // classes: 1 (256,512]  2 (128,256]  3 (64,128]  4 (32,64]  5 (0,32]
+  const int32_t *b = C->bin_start;  // classes: 1 (256,512]  2 (128,256]  3 (64,128]  4 (32,64]  5 (16,32]  6 (0,16]
   // 512-thread workgroups: two fit per CU (LDS 68 KiB, 4 waves/SIMD) and run out of phase, so one gathers
   // while the other computes; the 16-wave team needs the whole CU
   static const bool big = getenv("IMP_TEAM_1024") != nullptr;
@@ -355,7 +355,8 @@ static void run_classes(const imp_csr *C, float *X, const float *Y, const float 
     launch_team<F, 4, 512>(C, b[3], b[4] - b[3], X, Y, A0, cg_steps, "als_cg_team4_rows");
     launch_team<F, 2, 512>(C, b[4], b[5] - b[4], X, Y, A0, cg_steps, "als_cg_team2_rows");
   }
-  launch_group<F, true>(C, b[5], b[6] - b[5], X, Y, A0, cg_steps, "als_cg_short_rows");
+  launch_group<F, true, 32>(C, b[5], b[6] - b[5], X, Y, A0, cg_steps, "als_cg_short_rows");
+  launch_group<F, true, 16>(C, b[6], b[7] - b[6], X, Y, A0, cg_steps, "als_cg_short16_rows");
 }
 
 // mid (wave teams, resident tiles) and short (one wave per row, MFMA gramian product) classes for f = 64 or 128

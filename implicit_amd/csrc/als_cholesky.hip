@@ -190,10 +190,10 @@ __global__ __launch_bounds__(256) void als_cholesky_wave_kernel(const int32_t *_
     for (int k = 0; k < FMAX; ++k) {
       const float d = bcast_lane(A[k], k);  // pivot
       if (!(d > 0.f)) ok = false;
-      const float inv = 1.0f / sqrtf(d);
-      const float lik = lane == k ? sqrtf(d) : A[k] * inv;  // L[i][k] for i >= k (rows above k hold garbage, unused)
-      A[k] = lik;
-      const float zk = bcast_lane(b, k) * inv;  // z_k = b_k / L_kk
+      const float sd = sqrtf(d);
+      const float lik = lane == k ? sd : A[k] / sd;  // L[i][k] for i >= k (rows above k hold garbage, unused);
+      A[k] = lik;                                    // true divisions: reg = 0 systems are badly conditioned
+      const float zk = bcast_lane(b, k) / sd;        // z_k = b_k / L_kk
       b = lane == k ? zk : fmaf(-lik, zk, b);
 #pragma unroll
       for (int j = k + 1; j < FMAX; ++j) A[j] = fmaf(-lik, bcast_lane(lik, j), A[j]);

@@ -134,20 +134,21 @@ struct LongPlanDev {
 //   0 long  (> 512 nnz): cut into segments of <= kSegment nnz, segment-parallel CG passes
 //   1..4 mid (256,512], (128,256], (64,128], (32,64]: a TEAM of 16/8/4/2 wavefronts per row, every
 //        wavefront keeps one 32-row gathered tile in registers for all passes
-//   5 short (1..32 nnz): one wavefront per row, resident tile, 16 rows per workgroup (MFMA gramian product)
-//   6 empty
+//   5 short (16,32] and 6 short (0,16]: one wavefront per row, resident tile of 32 / 16 entries, 16 rows per
+//        workgroup in lock step (MFMA gramian product)
+//   7 empty
 struct imp_csr {
-  static constexpr int kBins = 7;
+  static constexpr int kBins = 8;
   static constexpr int kShortRow = 32;
   static constexpr int kLongRow = 512;
   static constexpr int kSegment = 512;
-  static constexpr int32_t kClassMax[kBins + 1] = {INT32_MAX, 512, 256, 128, 64, 32, 0, -1};
+  static constexpr int32_t kClassMax[kBins + 1] = {INT32_MAX, 512, 256, 128, 64, 32, 16, 0, -1};
   int32_t rows = 0, cols = 0;
   int64_t nnz = 0;
   imp::DeviceArray<int32_t> indptr, indices;
   imp::DeviceArray<float> data;
   imp::DeviceArray<int32_t> order;
-  int32_t bin_start[kBins + 1] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int32_t bin_start[kBins + 1] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   int32_t max_row = 0;
   // long-row plan
   int32_t n_long = 0, n_seg = 0;
