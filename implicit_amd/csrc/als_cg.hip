@@ -28,6 +28,7 @@
 namespace imp {
 
 void least_squares_cg_group(const imp_csr *C, float *X, const float *Y, const float *A0, int f, int cg_steps);  // als_cg_group.hip
+void least_squares_cg_q(const imp_csr *C, float *X, const float *Y, const float *A0, int f, int cg_steps);      // als_cg_q.hip
 
 // ---- generic per-nnz pass (any f): 4 gathers in flight, one DPP all-reduce per dot -------------------
 template <int VPL, bool VEC, bool FIRST>
@@ -374,7 +375,10 @@ static void launch_all(const imp_csr *C, float *X, const float *Y, const float *
   const int32_t *b = C->bin_start;
   launch_long<VPL, VEC, A_LDS>(C, X, Y, A0, f, cg_steps);
   static const bool no_group = getenv("IMP_NO_GROUP") != nullptr;  // A/B switch: generic one-wave-per-row kernels
-  if (VEC && A_LDS && (f == 64 || f == 128) && !no_group) {
+  static const bool use_q = getenv("IMP_NO_Q") == nullptr;  // default: quarter-layout tiles (als_cg_q.hip); IMP_NO_Q=1 -> als_cg_group.hip
+  if (VEC && A_LDS && (f == 64 || f == 128) && !no_group && use_q) {
+    least_squares_cg_q(C, X, Y, A0, f, cg_steps);
+  } else if (VEC && A_LDS && (f == 64 || f == 128) && !no_group) {
     least_squares_cg_group(C, X, Y, A0, f, cg_steps);  // wave teams with resident tiles + MFMA gramian product
   } else {
     bool resident_ok = false;

@@ -1,0 +1,307 @@
+// K1q: the CG half sweep for f = 64 / 128 on quarter-layout register tiles (als_qtile.h).
+//
+// Same arithmetic contract (oracle: implicit/cpu/_als.pyx:152-248) and the same schedule as als_cg_group.hip --
+// short rows: one wavefront per row, 16 rows per workgroup in lock step, gramian product on fp32 MFMA;
+// mid rows: a team of 2/4/8/16 wavefronts per row with the whole row resident -- but the per-pass work of a wave is
+// organised around the four 16-lane DPP rows instead of the whole wave: dots reduce inside one DPP row, weights
+// need no broadcast, and accumulators return to the compact CG-state layout through two permlane-swap levels.
+#include <type_traits>
+
+#include "als_qtile.h"
+#include "common.h"
+
+namespace imp {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- MFMA gramian product for 16 lock-step rows (compact layout in, compact layout out) -------------------------
+template <int F> struct QGroupCfg {
+  static constexpr int LD = F + 8;          // A0 / P / Out row stride in LDS (conflict-free b128 fragment reads)
+  static constexpr int NT = F / 16;         // 16-factor output tiles
+  static constexpr int KH = 16 / NT;        // K-slices so that NT * KH == 16 waves
+  static constexpr int KB = (F / 16) / KH;  // 16-factor k-blocks per wave
+  static constexpr size_t lds_floats = (size_t)F * LD + 16 * LD + (size_t)KH * 16 * LD;
+};
+
+template <int F>
+__device__ __forceinline__ void group_gram_matvec_q(const float *A0s, float *Ps, float *Outs, int wave, int lane, bool valid,
+                                                    const float (&vec)[F / 64], float (&out)[F / 64]) {
+  using Cfg = QGroupCfg<F>;
+  constexpr int FC = F / 64, LD = Cfg::LD;
+#pragma unroll
+  for (int c = 0; c < FC; ++c) Ps[wave * LD + QL<F>::cfactor(lane, c)] = valid ? vec[c] : 0.f;
+  __syncthreads();
+  const int ti = wave % Cfg::NT, kh = wave / Cfg::NT;
+  const int i = lane & 15, kq = lane >> 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kb = 0; kb < Cfg::KB; ++kb) {
+    const int k0 = (kh * Cfg::KB + kb) * 16 + 4 * kq;
+    const float4 a = *reinterpret_cast<const float4 *>(A0s + (16 * ti + i) * LD + k0);
+    const float4 b = *reinterpret_cast<const float4 *>(Ps + i * LD + k0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+  }
+  *reinterpret_cast<float4 *>(Outs + (kh * 16 + i) * LD + 16 * ti + 4 * kq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < FC; ++c) {
+    float s = 0.f;
+#pragma unroll
+    for (int h = 0; h < Cfg::KH; ++h) s += Outs[(h * 16 + wave) * LD + QL<F>::cfactor(lane, c)];
+    out[c] = s;
+  }
+}
+
+// ---- short rows (<= 32 nnz): one wave per row, 16 rows per workgroup ----------------------------------------------
+template <int F>
+__global__ __launch_bounds__(1024) void als_cg_qgroup_kernel(const int32_t *__restrict__ order, int first, int count,
+                                                             const int32_t *__restrict__ indptr,
+                                                             const int32_t *__restrict__ indices,
+                                                             const float *__restrict__ data, float *__restrict__ X,
+                                                             const float *__restrict__ Y, const float *__restrict__ A0,
+                                                             int cg_steps) {
+  using Cfg = QGroupCfg<F>;
+  constexpr int FC = F / 64, FE = F / 16, LD = Cfg::LD;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *A0s = smem;
+  float *Ps = A0s + (size_t)F * LD;
+  float *Outs = Ps + 16 * LD;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int e = threadIdx.x; e < F * F; e += 1024) {
+    int r = e / F, c = e - r * F;
+    A0s[r * LD + c] = A0[e];
+  }
+  __syncthreads();
+
+  const int groups = (count + 15) / 16;
+  for (int g = blockIdx.x; g < groups; g += gridDim.x) {
+    const int i = g * 16 + wave;
+    const bool valid = i < count;
+    int u = 0, row_begin = 0, row_end = 0;
+    if (valid) {
+      u = __builtin_amdgcn_readfirstlane(order[first + i]);
+      row_begin = __builtin_amdgcn_readfirstlane(indptr[u]);
+      row_end = __builtin_amdgcn_readfirstlane(indptr[u + 1]);
+    }
+    float *xrow = X + (size_t)u * F;
+    float x[FC], r[FC], p[FC], Ap[FC], sp[FC];
+#pragma unroll
+    for (int c = 0; c < FC; ++c) x[c] = 0.f;
+    if (valid) load_compact<F>(xrow, lane, x);
+    QTile<F> tile;
+    float cpos[QL<F>::EQ];
+    load_qtile<F>(tile, cpos, indices, data, Y, lane, row_begin, row_end);
+
+    float ve[FE], ae[FE];
+    // r = -(A0 x) + sum_k (c+ - (|c|-1) y.x) y        (_als.pyx:187-201)
+    group_gram_matvec_q<F>(A0s, Ps, Outs, wave, lane, valid, x, Ap);
+    expand_vector<F>(x, ve);
+#pragma unroll
+    for (int e = 0; e < FE; ++e) ae[e] = 0.f;
+    qtile_apply<F, true>(tile, cpos, ve, ae);
+    reduce_expanded<F>(ae, sp);
+#pragma unroll
+    for (int c = 0; c < FC; ++c) p[c] = r[c] = sp[c] - Ap[c];
+    float rsold = dot_compact<F>(r, r);
+    bool active = valid && rsold >= 1e-20f;  // else: x untouched (_als.pyx:206)
+    const bool store = active;
+
+    for (int it = 0; it < cg_steps; ++it) {
+      group_gram_matvec_q<F>(A0s, Ps, Outs, wave, lane, active, p, Ap);
+      if (active) {  // wave-uniform
+        expand_vector<F>(p, ve);
+#pragma unroll
+        for (int e = 0; e < FE; ++e) ae[e] = 0.f;
+        qtile_apply<F, false>(tile, cpos, ve, ae);
+        reduce_expanded<F>(ae, sp);
+#pragma unroll
+        for (int c = 0; c < FC; ++c) Ap[c] += sp[c];
+        float alpha = rsold / dot_compact<F>(p, Ap);
+#pragma unroll
+        for (int c = 0; c < FC; ++c) {
+          x[c] = fmaf(alpha, p[c], x[c]);
+          r[c] = fmaf(-alpha, Ap[c], r[c]);
+        }
+        float rsnew = dot_compact<F>(r, r);
+        if (rsnew < 1e-20f) {
+          active = false;  // the oracle breaks here (_als.pyx:235); keep taking the barriers
+        } else {
+          float beta = rsnew / rsold;
+#pragma unroll
+          for (int c = 0; c < FC; ++c) p[c] = fmaf(beta, p[c], r[c]);
+          rsold = rsnew;
+        }
+      }
+    }
+    if (store) store_compact<F>(xrow, lane, x);
+  }
+}
+
+// ---- mid rows: a team of WPR wavefronts per row, the whole row resident -----------------------------------------------
+template <int F, int WPR, int BLOCK>
+__global__ __launch_bounds__(BLOCK, 4) void als_cg_qteam_kernel(const int32_t *__restrict__ order, int first, int count,
+                                                                const int32_t *__restrict__ indptr,
+                                                                const int32_t *__restrict__ indices,
+                                                                const float *__restrict__ data, float *__restrict__ X,
+                                                                const float *__restrict__ Y, const float *__restrict__ A0,
+                                                                int cg_steps) {
+  constexpr int FC = F / 64, FE = F / 16, T = 32, WAVES = BLOCK / 64, TEAMS = WAVES / WPR;
+  static_assert(WPR <= WAVES && (F / WPR) % 4 == 0, "team width");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *A0s = smem;                        // [F][F]
+  float *scratch = A0s + (size_t)F * F;     // [WAVES][F]  partial vectors of the combine
+  float *vecs = scratch + (size_t)WAVES * F;  // [WAVES][F]  wave-private copy of the operand vector (natural order)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int team = wave / WPR, sub = wave % WPR;
+  for (int e = threadIdx.x; e < F * F; e += BLOCK) A0s[e] = A0[e];
+  __syncthreads();
+  const int j_begin = F * sub / WPR, j_end = F * (sub + 1) / WPR;
+  float *myvec = vecs + (size_t)wave * F;
+
+  // sum of the team's WPR partial vectors (fixed order); every wave of the team gets the same bits
+  auto combine = [&](float (&acc)[FC]) {
+#pragma unroll
+    for (int c = 0; c < FC; ++c) scratch[wave * F + QL<F>::cfactor(lane, c)] = acc[c];
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < FC; ++c) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < WPR; ++w) s += scratch[(team * WPR + w) * F + QL<F>::cfactor(lane, c)];
+      acc[c] = s;
+    }
+    __syncthreads();
+  };
+  // one pass: acc (compact) = [A0 rows of this wave] . v + [tile entries of this wave] weights
+  auto pass = [&](auto first_tag, const QTile<F> &tile, const float (&cpos)[QL<F>::EQ], const float (&v)[FC], float (&acc)[FC],
+                  bool work) {
+    float ve[FE], ae[FE];
+#pragma unroll
+    for (int e = 0; e < FE; ++e) ae[e] = 0.f;
+    if (work) {  // wave-uniform, identical across the team
+#pragma unroll
+      for (int c = 0; c < FC; ++c) myvec[QL<F>::cfactor(lane, c)] = v[c];  // wave-private: no barrier needed
+      expand_vector<F>(v, ve);
+      gram_matvec_q<F>(A0s, F, myvec, lane, j_begin, j_end, ae);
+      qtile_apply<F, decltype(first_tag)::value>(tile, cpos, ve, ae);
+    }
+    reduce_expanded<F>(ae, acc);
+  };
+
+  const int groups = (count + TEAMS - 1) / TEAMS;
+  for (int g = blockIdx.x; g < groups; g += gridDim.x) {
+    const int i = g * TEAMS + team;
+    const bool valid = i < count;
+    int u = 0, row_begin = 0, row_end = 0;
+    if (valid) {
+      u = __builtin_amdgcn_readfirstlane(order[first + i]);
+      row_begin = __builtin_amdgcn_readfirstlane(indptr[u]);
+      row_end = __builtin_amdgcn_readfirstlane(indptr[u + 1]);
+    }
+    float *xrow = X + (size_t)u * F;
+    float x[FC], r[FC], p[FC], Ap[FC];
+#pragma unroll
+    for (int c = 0; c < FC; ++c) x[c] = 0.f;
+    if (valid) load_compact<F>(xrow, lane, x);
+    const int k0 = min(row_begin + T * sub, row_end);  // this wave's slice of the row (may be empty)
+    QTile<F> tile;
+    float cpos[QL<F>::EQ];
+    load_qtile<F>(tile, cpos, indices, data, Y, lane, k0, row_end);
+
+    // r = -(A0 x) + sum_k (c+ - (|c|-1) y.x) y        (_als.pyx:187-201): the dense part enters with a minus sign
+    {
+      float ve[FE], ae[FE];
+#pragma unroll
+      for (int e = 0; e < FE; ++e) ae[e] = 0.f;
+#pragma unroll
+      for (int c = 0; c < FC; ++c) myvec[QL<F>::cfactor(lane, c)] = x[c];
+      expand_vector<F>(x, ve);
+      gram_matvec_q<F>(A0s, F, myvec, lane, j_begin, j_end, ae);
+#pragma unroll
+      for (int e = 0; e < FE; ++e) ae[e] = -ae[e];
+      qtile_apply<F, true>(tile, cpos, ve, ae);
+      reduce_expanded<F>(ae, r);
+    }
+    combine(r);
+#pragma unroll
+    for (int c = 0; c < FC; ++c) p[c] = r[c];
+    float rsold = dot_compact<F>(r, r);
+    bool active = valid && rsold >= 1e-20f;  // else: x untouched (_als.pyx:206)
+    const bool store = active && sub == 0;
+
+    for (int it = 0; it < cg_steps; ++it) {
+      pass(std::false_type{}, tile, cpos, p, Ap, active);
+      combine(Ap);
+      if (active) {
+        float alpha = rsold / dot_compact<F>(p, Ap);
+#pragma unroll
+        for (int c = 0; c < FC; ++c) {
+          x[c] = fmaf(alpha, p[c], x[c]);
+          r[c] = fmaf(-alpha, Ap[c], r[c]);
+        }
+        float rsnew = dot_compact<F>(r, r);
+        if (rsnew < 1e-20f) {
+          active = false;  // the oracle breaks here (_als.pyx:235); keep taking the barriers
+        } else {
+          float beta = rsnew / rsold;
+#pragma unroll
+          for (int c = 0; c < FC; ++c) p[c] = fmaf(beta, p[c], r[c]);
+          rsold = rsnew;
+        }
+      }
+    }
+    if (store) store_compact<F>(xrow, lane, x);
+  }
+}
+
+template <int F>
+static void launch_qgroup(const imp_csr *C, int first, int count, float *X, const float *Y, const float *A0, int cg_steps,
+                          const char *name) {
+  if (count <= 0) return;
+  size_t lds = QGroupCfg<F>::lds_floats * sizeof(float);
+  auto kern = als_cg_qgroup_kernel<F>;
+  IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int grid = std::min((count + 15) / 16, ctx().num_cus * 2);
+  IMP_PROF(name);
+  kern<<<grid, 1024, lds, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(), C->data.data(), X, Y, A0,
+                                      cg_steps);
+  IMP_CHECK_HIP(hipGetLastError());
+}
+
+template <int F, int WPR, int BLOCK>
+static void launch_qteam(const imp_csr *C, int first, int count, float *X, const float *Y, const float *A0, int cg_steps,
+                         const char *name) {
+  if (count <= 0) return;
+  constexpr int WAVES = BLOCK / 64, TEAMS = WAVES / WPR;
+  size_t lds = ((size_t)F * F + 2 * WAVES * F) * sizeof(float);
+  auto kern = als_cg_qteam_kernel<F, WPR, BLOCK>;
+  IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / BLOCK, (160 * 1024) / lds));
+  int grid = std::min((count + TEAMS - 1) / TEAMS, ctx().num_cus * per_cu);
+  IMP_PROF(name);
+  kern<<<grid, BLOCK, lds, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(), C->data.data(), X, Y,
+                                      A0, cg_steps);
+  IMP_CHECK_HIP(hipGetLastError());
+}
+
+template <int F> static void run_classes_q(const imp_csr *C, float *X, const float *Y, const float *A0, int cg_steps) {
+  const int32_t *b = C->bin_start;  // classes: 1 (256,512]  2 (128,256]  3 (64,128]  4 (32,64]  5 (16,32]  6 (0,16]
+  launch_qteam<F, 16, 1024>(C, b[1], b[2] - b[1], X, Y, A0, cg_steps, "als_cg_team16_rows");
+  launch_qteam<F, 8, 512>(C, b[2], b[3] - b[2], X, Y, A0, cg_steps, "als_cg_team8_rows");
+  launch_qteam<F, 4, 512>(C, b[3], b[4] - b[3], X, Y, A0, cg_steps, "als_cg_team4_rows");
+  launch_qteam<F, 2, 512>(C, b[4], b[5] - b[4], X, Y, A0, cg_steps, "als_cg_team2_rows");
+  launch_qgroup<F>(C, b[5], b[7] - b[5], X, Y, A0, cg_steps, "als_cg_short_rows");  // tile steps beyond cnt are skipped
+}
+
+void least_squares_cg_q(const imp_csr *C, float *X, const float *Y, const float *A0, int f, int cg_steps) {
+  if (f == 128) run_classes_q<128>(C, X, Y, A0, cg_steps);
+  else if (f == 64) run_classes_q<64>(C, X, Y, A0, cg_steps);
+  else throw std::invalid_argument("least_squares_cg_q: f must be 64 or 128");
+}
+
+}  // namespace imp

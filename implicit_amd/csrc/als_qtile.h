@@ -1,0 +1,188 @@
+// "Quarter layout" register tiles for the CG kernels (f = 64, 128).
+//
+// A wavefront is split into its four 16-lane DPP rows ("groups").  Group g holds tile entries t = 4 q + g
+// (q = 0..7, 32 entries per wave); lane (g, m) keeps FE = f/16 factors (float4 pieces 4 m + 64 b) of each of
+// its 8 entries (64 VGPRs at f = 128, the same budget as the lane-owns-2-factors tile of als_tile.h).  What changes is
+// the cross-lane work per CG pass:
+//   * a dot product is FE FMAs per lane + a reduction over the 16 lanes of ONE DPP row (4 row_ror adds) -- no
+//     permlane swaps, and the 4 groups reduce 4 different entries at once;
+//   * every lane of a group ends with the dot (hence the weight) of its own entries, so the axpy needs no
+//     v_readlane broadcast;
+//   * the accumulator (FE factors per lane, partial over the group's entries) is brought back to the COMPACT
+//     layout -- lane (g, m) owns FC = f/64 of its FE expanded slots, slots FC g + c -- by a two-level reduce-scatter across the
+//     groups (FE/2 v_permlane32_swap + FE/4 v_permlane16_swap);  the CG state x, r, p, Ap lives in compact form and
+//     only the operand vector of a pass is expanded to FE per lane (3 FC swaps).
+// About 150 VALU instructions per full-tile pass instead of ~330, and entries beyond the row's count are skipped
+// in whole steps (4 q >= cnt is wave-uniform).
+#ifndef IMPLICIT_AMD_CSRC_ALS_QTILE_H_
+#define IMPLICIT_AMD_CSRC_ALS_QTILE_H_
+#include "als_tile.h"
+
+namespace imp {
+
+template <int F> struct QL {
+  static constexpr int FE = F / 16;  // expanded factors per lane
+  static constexpr int FC = F / 64;  // compact factors per lane
+  static constexpr int EQ = 8;       // entries per group -> 32 per wave
+  static_assert(F == 64 || F == 128, "quarter layout is built for f = 64 and 128");
+  // expanded slot e of lane (g, m) is factor 64 (e >> 2) + 4 m + (e & 3): every float4 of a lane is one 16-byte piece of
+  // a 256-byte run covered by its 16-lane group (coalesced gathers, conflict-free ds_read_b128 of gramian rows)
+  __device__ static __forceinline__ int efactor(int lane, int e) { return 64 * (e >> 2) + 4 * (lane & 15) + (e & 3); }
+  // compact slot c of lane (g, m) = expanded slot FC g + c
+  __device__ static __forceinline__ int cfactor(int lane, int c) { return efactor(lane, FC * (lane >> 4) + c); }
+};
+
+// compact <-> memory (a row of X, or an LD-strided LDS vector)
+template <int F> __device__ __forceinline__ void load_compact(const float *__restrict__ row, int lane, float (&v)[F / 64]) {
+  const float *p = row + QL<F>::cfactor(lane, 0);
+  if constexpr (F == 128) {
+    float2 t = *reinterpret_cast<const float2 *>(p);
+    v[0] = t.x, v[1] = t.y;
+  } else {
+    v[0] = *p;
+  }
+}
+template <int F> __device__ __forceinline__ void store_compact(float *__restrict__ row, int lane, const float (&v)[F / 64]) {
+  float *p = row + QL<F>::cfactor(lane, 0);
+  if constexpr (F == 128) {
+    *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[1]);
+  } else {
+    *p = v[0];
+  }
+}
+
+// all-gather across the 4 groups: compact (FC per lane) -> expanded (FE per lane)
+template <int F> __device__ __forceinline__ void expand_vector(const float (&vc)[F / 64], float (&ve)[F / 16]) {
+  constexpr int FC = QL<F>::FC;
+  float pair[2 * FC];  // values of the even / odd group of this lane's group pair
+#pragma unroll
+  for (int c = 0; c < FC; ++c) {
+    float a = vc[c], b = vc[c];
+    // odd rows of a <-> even rows of b: afterwards a = the even group's value, b = the odd group's, in both rows
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    pair[c] = a;
+    pair[FC + c] = b;
+  }
+#pragma unroll
+  for (int i = 0; i < 2 * FC; ++i) {
+    float a = pair[i], b = pair[i];
+    // lanes 32-63 of a <-> lanes 0-31 of b: a = the value held by groups 0/1, b = the value held by groups 2/3
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    ve[i] = a;
+    ve[2 * FC + i] = b;
+  }
+}
+
+// reduce-scatter across the 4 groups: expanded partial sums (FE per lane) -> compact totals (FC per lane)
+template <int F> __device__ __forceinline__ void reduce_expanded(const float (&ae)[F / 16], float (&ac)[F / 64]) {
+  constexpr int FE = QL<F>::FE, FC = QL<F>::FC;
+  float h[FE / 2];
+#pragma unroll
+  for (int i = 0; i < FE / 2; ++i) h[i] = swap32_sum(ae[i], ae[i + FE / 2]);  // groups 0/1 keep e < FE/2
+#pragma unroll
+  for (int c = 0; c < FC; ++c) ac[c] = swap16_sum(h[c], h[c + FC]);  // even group keeps the first FC of its half
+}
+
+template <int F> struct QTile {
+  float y[QL<F>::EQ][QL<F>::FE];  // this lane's slice of its group's 8 entries
+  float cm1[QL<F>::EQ];           // |c| - 1 (0 when the entry is beyond the row)
+  int cnt;                        // valid entries of the whole 32-entry tile (wave-uniform)
+};
+
+// entry t = 4 q + g of the tile covers nnz k0 + t; lanes past the end repeat the last valid entry with weight 0
+template <int F>
+__device__ __forceinline__ void load_qtile(QTile<F> &tile, float (&cpos)[QL<F>::EQ], const int32_t *__restrict__ indices,
+                                           const float *__restrict__ data, const float *__restrict__ Y, int lane, int k0,
+                                           int end) {
+  constexpr int FE = QL<F>::FE, EQ = QL<F>::EQ;
+  const int cnt = max(0, min(4 * EQ, end - k0));
+  tile.cnt = cnt;
+  const int g = lane >> 4;
+  unsigned col[EQ];
+#pragma unroll
+  for (int q = 0; q < EQ; ++q) {
+    const int t = 4 * q + g;
+    const bool ok = t < cnt;
+    const int k = k0 + (cnt > 0 ? min(t, cnt - 1) : 0);
+    col[q] = cnt > 0 ? (unsigned)indices[k] : 0u;
+    const float c = ok ? data[k] : 0.f;
+    tile.cm1[q] = ok ? fabsf(c) - 1.f : 0.f;
+    cpos[q] = c > 0.f ? c : 0.f;
+  }
+  // gathers back to back, in two wave-uniform halves (q < 4 covers tile entries 0..15); few branches keep the
+  // compiler's vmcnt bookkeeping exact so that all loads of a half are in flight together
+  auto gather = [&](int q) {
+    const float *src = Y + (size_t)col[q] * F + 4 * (lane & 15);
+#pragma unroll
+    for (int e = 0; e < FE; e += 4) {
+      float4 v = *reinterpret_cast<const float4 *>(src + 16 * e);  // expanded slots e..e+3 = factors 64 (e/4) + 4 m ..
+      tile.y[q][e] = v.x, tile.y[q][e + 1] = v.y, tile.y[q][e + 2] = v.z, tile.y[q][e + 3] = v.w;
+    }
+  };
+  auto clear = [&](int q) {
+#pragma unroll
+    for (int e = 0; e < FE; ++e) tile.y[q][e] = 0.f;
+  };
+  if (cnt > 16) {
+#pragma unroll
+    for (int q = 0; q < EQ; ++q) gather(q);
+  } else if (cnt > 0) {
+#pragma unroll
+    for (int q = 0; q < EQ / 2; ++q) gather(q);
+#pragma unroll
+    for (int q = EQ / 2; q < EQ; ++q) clear(q);
+  } else {
+#pragma unroll
+    for (int q = 0; q < EQ; ++q) clear(q);
+  }
+}
+
+// ae += sum over this group's entries of w y, with the dots against the expanded vector ve
+//   FIRST: w = c+ - (|c|-1) d    else: w = (|c|-1) d      (_als.pyx:190-201, 214-222)
+template <int F, bool FIRST>
+__device__ __forceinline__ void qtile_apply(const QTile<F> &tile, const float (&cpos)[QL<F>::EQ], const float (&ve)[F / 16],
+                                            float (&ae)[F / 16]) {
+  constexpr int FE = QL<F>::FE, EQ = QL<F>::EQ;
+#pragma unroll
+  for (int q = 0; q < EQ; ++q) {
+    if (4 * q < tile.cnt) {  // wave-uniform
+      float part = 0.f;
+#pragma unroll
+      for (int e = 0; e < FE; ++e) part = fmaf(tile.y[q][e], ve[e], part);
+      const float d = row_allsum(part);
+      const float w = FIRST ? cpos[q] - tile.cm1[q] * d : tile.cm1[q] * d;
+#pragma unroll
+      for (int e = 0; e < FE; ++e) ae[e] = fmaf(w, tile.y[q][e], ae[e]);
+    }
+  }
+}
+
+// Dense part split over the groups: group g adds A0[j][.] * v[j] for j = j_begin + 4 s + g.  `vec_lds` is this wave's
+// private LDS copy of the operand vector in natural factor order (wave-synchronous: written by the caller, no barrier).
+template <int F>
+__device__ __forceinline__ void gram_matvec_q(const float *A0s, int lda, const float *vec_lds, int lane, int j_begin, int j_end,
+                                              float (&ae)[F / 16]) {
+  constexpr int FE = QL<F>::FE;
+  const int g = lane >> 4;
+#pragma unroll 4
+  for (int j0 = j_begin; j0 < j_end; j0 += 4) {
+    const int j = j0 + g;
+    const float vj = vec_lds[j];
+    const float *row = A0s + (size_t)j * lda + 4 * (lane & 15);
+#pragma unroll
+    for (int e = 0; e < FE; e += 4) {
+      const float4 a = *reinterpret_cast<const float4 *>(row + 16 * e);
+      ae[e] = fmaf(vj, a.x, ae[e]);
+      ae[e + 1] = fmaf(vj, a.y, ae[e + 1]);
+      ae[e + 2] = fmaf(vj, a.z, ae[e + 2]);
+      ae[e + 3] = fmaf(vj, a.w, ae[e + 3]);
+    }
+  }
+}
+
+template <int F> __device__ __forceinline__ float dot_compact(const float (&a)[F / 64], const float (&b)[F / 64]) {
+  return wave_allsum(dot_local<F / 64>(a, b));
+}
+
+}  // namespace imp
+#endif  // IMPLICIT_AMD_CSRC_ALS_QTILE_H_
