@@ -78,15 +78,20 @@ __global__ __launch_bounds__(1024) void als_cg_qgroup_kernel(const int32_t *__re
   __syncthreads();
 
   const int groups = (count + 15) / 16;
-  for (int g = blockIdx.x; g < groups; g += gridDim.x) {
+  auto fetch_meta = [&](int g, int &u, int &rb, int &re) {  // one group ahead (two dependent scalar loads)
     const int i = g * 16 + wave;
-    const bool valid = i < count;
-    int u = 0, row_begin = 0, row_end = 0;
-    if (valid) {
+    u = rb = re = 0;
+    if (g < groups && i < count) {
       u = __builtin_amdgcn_readfirstlane(order[first + i]);
-      row_begin = __builtin_amdgcn_readfirstlane(indptr[u]);
-      row_end = __builtin_amdgcn_readfirstlane(indptr[u + 1]);
+      rb = __builtin_amdgcn_readfirstlane(indptr[u]);
+      re = __builtin_amdgcn_readfirstlane(indptr[u + 1]);
     }
+  };
+  int u_next, rb_next, re_next;
+  fetch_meta(blockIdx.x, u_next, rb_next, re_next);
+  for (int g = blockIdx.x; g < groups; g += gridDim.x) {
+    const bool valid = g * 16 + wave < count;
+    const int u = u_next, row_begin = rb_next, row_end = re_next;
     float *xrow = X + (size_t)u * F;
     float x[FC], r[FC], p[FC], Ap[FC], sp[FC];
 #pragma unroll
@@ -95,6 +100,7 @@ __global__ __launch_bounds__(1024) void als_cg_qgroup_kernel(const int32_t *__re
     QTile<F> tile;
     float cpos[QL<F>::EQ];
     load_qtile<F>(tile, cpos, indices, data, Y, lane, row_begin, row_end);
+    fetch_meta(g + gridDim.x, u_next, rb_next, re_next);  // overlaps with the gathers above
 
     float ve[FE], ae[FE];
     // r = -(A0 x) + sum_k (c+ - (|c|-1) y.x) y        (_als.pyx:187-201)
@@ -165,6 +171,7 @@ __global__ __launch_bounds__(BLOCK, 4) void als_cg_qteam_kernel(const int32_t *_
 
   // sum of the team's WPR partial vectors (fixed order); every wave of the team gets the same bits
   auto combine = [&](float (&acc)[FC]) {
+    if constexpr (WPR == 1) return;  // independent waves: nothing to combine, no barrier
 #pragma unroll
     for (int c = 0; c < FC; ++c) scratch[wave * F + QL<F>::cfactor(lane, c)] = acc[c];
     __syncthreads();
@@ -194,15 +201,21 @@ __global__ __launch_bounds__(BLOCK, 4) void als_cg_qteam_kernel(const int32_t *_
   };
 
   const int groups = (count + TEAMS - 1) / TEAMS;
-  for (int g = blockIdx.x; g < groups; g += gridDim.x) {
+  // row metadata (schedule entry -> row id -> nnz range: two dependent scalar loads) is fetched one group ahead
+  auto fetch_meta = [&](int g, int &u, int &rb, int &re) {
     const int i = g * TEAMS + team;
-    const bool valid = i < count;
-    int u = 0, row_begin = 0, row_end = 0;
-    if (valid) {
+    u = rb = re = 0;
+    if (g < groups && i < count) {
       u = __builtin_amdgcn_readfirstlane(order[first + i]);
-      row_begin = __builtin_amdgcn_readfirstlane(indptr[u]);
-      row_end = __builtin_amdgcn_readfirstlane(indptr[u + 1]);
+      rb = __builtin_amdgcn_readfirstlane(indptr[u]);
+      re = __builtin_amdgcn_readfirstlane(indptr[u + 1]);
     }
+  };
+  int u_next, rb_next, re_next;
+  fetch_meta(blockIdx.x, u_next, rb_next, re_next);
+  for (int g = blockIdx.x; g < groups; g += gridDim.x) {
+    const bool valid = g * TEAMS + team < count;
+    const int u = u_next, row_begin = rb_next, row_end = re_next;
     float *xrow = X + (size_t)u * F;
     float x[FC], r[FC], p[FC], Ap[FC];
 #pragma unroll
@@ -212,6 +225,7 @@ __global__ __launch_bounds__(BLOCK, 4) void als_cg_qteam_kernel(const int32_t *_
     QTile<F> tile;
     float cpos[QL<F>::EQ];
     load_qtile<F>(tile, cpos, indices, data, Y, lane, k0, row_end);
+    fetch_meta(g + gridDim.x, u_next, rb_next, re_next);  // overlaps with the gathers above
 
     // r = -(A0 x) + sum_k (c+ - (|c|-1) y.x) y        (_als.pyx:187-201): the dense part enters with a minus sign
     {
@@ -295,7 +309,11 @@ template <int F> static void run_classes_q(const imp_csr *C, float *X, const flo
   launch_qteam<F, 8, 512>(C, b[2], b[3] - b[2], X, Y, A0, cg_steps, "als_cg_team8_rows");
   launch_qteam<F, 4, 512>(C, b[3], b[4] - b[3], X, Y, A0, cg_steps, "als_cg_team4_rows");
   launch_qteam<F, 2, 512>(C, b[4], b[5] - b[4], X, Y, A0, cg_steps, "als_cg_team2_rows");
-  launch_qgroup<F>(C, b[5], b[7] - b[5], X, Y, A0, cg_steps, "als_cg_short_rows");  // tile steps beyond cnt are skipped
+  static const bool short_team1 = getenv("IMP_SHORT_TEAM1") != nullptr;  // A/B: independent waves, VALU gramian product
+  if (short_team1)
+    launch_qteam<F, 1, 512>(C, b[5], b[7] - b[5], X, Y, A0, cg_steps, "als_cg_short_rows");
+  else
+    launch_qgroup<F>(C, b[5], b[7] - b[5], X, Y, A0, cg_steps, "als_cg_short_rows");  // tile steps beyond cnt are skipped
 }
 
 void least_squares_cg_q(const imp_csr *C, float *X, const float *Y, const float *A0, int f, int cg_steps) {
