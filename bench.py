@@ -84,7 +84,7 @@ def class_bytes_per_iteration(Cui, Ciu, f):
 # substring of the kernel function name -> (schedule class, dispatches per half sweep as a function of cg_steps)
 PMC_KERNELS = {"als_cg_group_kernel": ("short", lambda s: 1), "als_cg_team_kernel": ("mid", lambda s: 1),
                "als_cg_qgroup_kernel": ("short", lambda s: 1), "als_cg_qteam_kernel": ("mid", lambda s: 1),
-               "cg_long_partial_kernel": ("long", lambda s: 1 + s), "cg_long_combine_kernel": ("long", lambda s: 1 + s)}
+               "cg_long_partial": ("long", lambda s: 1 + s), "cg_long_combine_kernel": ("long", lambda s: 1 + s)}
 
 
 def pmc_traffic_per_half_sweep(cg_steps):
@@ -104,7 +104,7 @@ def pmc_traffic_per_half_sweep(cg_steps):
             if sub in kname and "hbm_read_bytes_per_dispatch_corrected" in d:
                 # cg_long_partial has two instantiations (first pass / later passes): 1 and cg_steps dispatches
                 n = per_sweep(cg_steps)
-                if sub == "cg_long_partial_kernel":
+                if sub == "cg_long_partial":
                     n = 1 if kname.rstrip(">").endswith("true") else cg_steps
                 out[cls] = out.get(cls, 0.0) + n * (d["hbm_read_bytes_per_dispatch_corrected"] +
                                                      d.get("hbm_write_bytes_per_dispatch", 0.0))

@@ -23,6 +23,7 @@
 //   * any other f <= 512 runs a generic lane-strided variant of the same structure.
 #include "common.h"
 #include "wave_ops.h"
+#include "als_qtile.h"
 #include "als_tile.h"
 
 namespace imp {
@@ -199,6 +200,43 @@ __global__ __launch_bounds__(256) void cg_long_partial_kernel(const LongPlanDev 
   }
 }
 
+// Quarter-layout variant of the partial kernel (f = 64, 128): same segments, ~half the VALU work per tile pass.
+// The operand vector is read from memory directly in expanded form; the partial result is stored by factor index,
+// so cg_long_combine_kernel is unchanged.
+template <int F, bool FIRST>
+__global__ __launch_bounds__(256) void cg_long_partial_q_kernel(const LongPlanDev plan, const int32_t *__restrict__ indices,
+                                                                const float *__restrict__ data, const float *__restrict__ X,
+                                                                const float *__restrict__ Y, float *__restrict__ partial,
+                                                                const float *__restrict__ pvec, const float *__restrict__ scal) {
+  constexpr int FE = F / 16, FC = F / 64, LD = F;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int s = wave; s < plan.n_seg; s += nwaves) {
+    const int li = __builtin_amdgcn_readfirstlane(plan.seg_row[s]);
+    if (!FIRST && scal[2 * li + 1] != 0.f) continue;  // row finished (early exit)
+    const int begin = __builtin_amdgcn_readfirstlane(plan.seg_begin[s]);
+    const int end = __builtin_amdgcn_readfirstlane(plan.seg_end[s]);
+    const float *vsrc = (FIRST ? X + (size_t)plan.rows[li] * F : pvec + (size_t)li * LD) + 4 * (lane & 15);
+    float ve[FE], ae[FE];
+#pragma unroll
+    for (int e = 0; e < FE; e += 4) {
+      const float4 v = *reinterpret_cast<const float4 *>(vsrc + 16 * e);
+      ve[e] = v.x, ve[e + 1] = v.y, ve[e + 2] = v.z, ve[e + 3] = v.w;
+      ae[e] = ae[e + 1] = ae[e + 2] = ae[e + 3] = 0.f;
+    }
+    for (int k0 = begin; k0 < end; k0 += 32) {
+      QTile<F> tile;
+      float cpos[QL<F>::EQ];
+      load_qtile<F>(tile, cpos, indices, data, Y, lane, k0, end);
+      qtile_apply<F, FIRST>(tile, cpos, ve, ae);
+    }
+    float ac[FC];
+    reduce_expanded<F>(ae, ac);
+    store_compact<F>(partial + (size_t)s * LD, lane, ac);
+  }
+}
+
 // PHASE 0: r = sum(partials) - A0 x ; p = r ; rsold = r.r ; done = rsold < 1e-20
 // PHASE 1: Ap = sum(partials) + A0 p ; alpha ; x += alpha p ; r -= alpha Ap ; rsnew ; done |= rsnew < 1e-20 ; p = r + beta p
 template <int VPL, bool VEC, int BLOCK, bool A_LDS, int PHASE>
@@ -345,8 +383,12 @@ static void launch_long(const imp_csr *C, float *X, const float *Y, const float 
   int grid_comb = std::min((n_long + BLOCK / 64 - 1) / (BLOCK / 64), ctx().num_cus * 2);
   {
     IMP_PROF("als_cg_long_partial");
-    cg_long_partial_kernel<VPL, VEC, true>
-        <<<grid_part, 256, 0, stream()>>>(plan, C->indices.data(), C->data.data(), X, Y, f, partial, pvec, scal);
+    if constexpr (VEC && (VPL == 1 || VPL == 2))
+      cg_long_partial_q_kernel<64 * VPL, true>
+          <<<grid_part, 256, 0, stream()>>>(plan, C->indices.data(), C->data.data(), X, Y, partial, pvec, scal);
+    else
+      cg_long_partial_kernel<VPL, VEC, true>
+          <<<grid_part, 256, 0, stream()>>>(plan, C->indices.data(), C->data.data(), X, Y, f, partial, pvec, scal);
     IMP_CHECK_HIP(hipGetLastError());
   }
   {
@@ -357,8 +399,12 @@ static void launch_long(const imp_csr *C, float *X, const float *Y, const float 
   for (int it = 0; it < cg_steps; ++it) {
     {
       IMP_PROF("als_cg_long_partial");
-      cg_long_partial_kernel<VPL, VEC, false>
-          <<<grid_part, 256, 0, stream()>>>(plan, C->indices.data(), C->data.data(), X, Y, f, partial, pvec, scal);
+      if constexpr (VEC && (VPL == 1 || VPL == 2))
+        cg_long_partial_q_kernel<64 * VPL, false>
+            <<<grid_part, 256, 0, stream()>>>(plan, C->indices.data(), C->data.data(), X, Y, partial, pvec, scal);
+      else
+        cg_long_partial_kernel<VPL, VEC, false>
+            <<<grid_part, 256, 0, stream()>>>(plan, C->indices.data(), C->data.data(), X, Y, f, partial, pvec, scal);
       IMP_CHECK_HIP(hipGetLastError());
     }
     {
