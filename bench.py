@@ -117,8 +117,11 @@ def cpu_baseline(Cui, Ciu, X0, Y0, seconds):
     from oracle import ref
 
     als_ref, _ = ref.load()
-    # OpenBLAS (reached by the reference from every OpenMP thread) supports at most 128 concurrent callers
-    cores = min(os.cpu_count() or 1, 64)
+    # OpenBLAS (reached by the reference from every OpenMP thread) supports at most 128 concurrent callers, and the
+    # reference's dynamic OpenMP schedule does not scale across sockets: the thread count is probed (below) and the
+    # fastest is used -- `cores` reports the threads actually used
+    max_threads = min(os.cpu_count() or 1, 64)
+    cores = max_threads
     kind = "reference" if als_ref is not None else "port"
     limiter = None
     if als_ref is not None:
@@ -152,7 +155,13 @@ def cpu_baseline(Cui, Ciu, X0, Y0, seconds):
         Mi, Ai = sample(Ciu, Y0, ni)
         return run(Mu, Au, Y0) + run(Mi, Ai, X0), Mu.shape[0], Mi.shape[0], int(Mu.nnz + Mi.nnz)
 
-    t_probe, pu, pi, _ = timed(2000, 2000)
+    best = None
+    for cand in sorted({c for c in (8, 16, 32, max_threads) if c <= max_threads}):
+        cores = cand
+        t_c, pu, pi, _ = timed(4000, 4000)
+        if best is None or t_c < best[0]:
+            best = (t_c, cand, pu, pi)
+    t_probe, cores, pu, pi = best
     rate = (pu + pi) / max(t_probe, 1e-6)
     frac = min(1.0, seconds * rate / (Cui.shape[0] + Ciu.shape[0]))
     t, su, si, nnz = timed(max(2000, int(Cui.shape[0] * frac)), max(2000, int(Ciu.shape[0] * frac)))

@@ -349,7 +349,7 @@ __global__ void coo_count_kernel(const int32_t *__restrict__ row, size_t nnz, in
 // k are written.  Rows that overflow the candidate buffer, have too few tiles, or show an exact tie at the k-th score
 // (the reference heap's arrival-order rule then needs the whole row) raise `fallback[row]` and are redone by
 // select_kernel.
-constexpr int kCandCap = 2048;
+constexpr int kCandCap = 4096;  // 32 KiB of LDS; heavy users (many liked items lower tau) need the headroom
 
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void select_pruned_kernel(const float *__restrict__ S, const float *__restrict__ tile_max,
