@@ -336,6 +336,36 @@ __global__ __launch_bounds__(256) void score_gemm_direct_kernel(const float *__r
     }
 }
 
+// After the filter scatters: recompute the maximum of every 64-item tile a filter touched (one thread per filter entry;
+// several entries of one tile write the same value).  Keeps tau = the k-th largest tile maximum a valid AND tight lower
+// bound without any slack for filtered entries.
+__device__ __forceinline__ void refresh_tile_max(const float *__restrict__ S, float *__restrict__ tile_max, size_t row, int col,
+                                                 int ni, int n_tiles) {
+  const int tile = col / kTileItems;
+  const int c0 = tile * kTileItems, c1 = min(ni, c0 + kTileItems);
+  float m = -FLT_MAX;
+  for (int c = c0; c < c1; ++c) m = fmaxf(m, S[row * ni + c]);
+  tile_max[row * n_tiles + tile] = m;
+}
+
+__global__ void item_filter_refresh_kernel(const float *__restrict__ S, float *__restrict__ tile_max, int rows, int ni, int n_tiles,
+                                           const int32_t *__restrict__ items, int n_items) {
+  size_t total = (size_t)rows * n_items;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int col = items[i % n_items];
+    if (col >= 0 && col < ni) refresh_tile_max(S, tile_max, i / n_items, col, ni, n_tiles);
+  }
+}
+
+__global__ void coo_filter_refresh_kernel(const float *__restrict__ S, float *__restrict__ tile_max, int start, int end, int ni,
+                                          int n_tiles, const int32_t *__restrict__ row, const int32_t *__restrict__ col,
+                                          size_t nnz) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nnz; i += (size_t)gridDim.x * blockDim.x) {
+    int r = row[i], c = col[i];
+    if (r >= start && r < end && c >= 0 && c < ni) refresh_tile_max(S, tile_max, (size_t)(r - start), c, ni, n_tiles);
+  }
+}
+
 __global__ void coo_count_kernel(const int32_t *__restrict__ row, size_t nnz, int start, int end, int *__restrict__ counts) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nnz; i += (size_t)gridDim.x * blockDim.x) {
     int r = row[i];
@@ -343,8 +373,8 @@ __global__ void coo_count_kernel(const int32_t *__restrict__ row, size_t nnz, in
   }
 }
 
-// Pruned select: tau = the m-th largest tile maximum, m = k + (number of entries the filters may have removed), is a
-// lower bound of the k-th best surviving score (m distinct tiles hold a score >= tau, at most m - k of them filtered).
+// Pruned select: tau = the k-th largest tile maximum (maxima refreshed after the filters) is a lower bound of the k-th
+// best surviving score: k distinct tiles each hold a surviving score >= tau.
 // ONE pass over the row collects every score >= tau (a few hundred) into LDS, a bitonic sort orders them and the best
 // k are written.  Rows that overflow the candidate buffer, have too few tiles, or show an exact tie at the k-th score
 // (the reference heap's arrival-order rule then needs the whole row) raise `fallback[row]` and are redone by
@@ -550,11 +580,12 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
     const int n_tiles = (int)((ni + kTileItems - 1) / kTileItems);
     float *tile_max = fast ? imp_knn::ensure(knn->tile_max, batch * (size_t)n_tiles) : nullptr;
     int *fallback = fast ? imp_knn::ensure(knn->fallback, batch) : nullptr;
-    int *counts = (fast && query_filter && query_filter->nnz) ? imp_knn::ensure(knn->counts, batch) : nullptr;
-    const int extra = item_filter ? (int)item_filter->size : 0;
+    int *counts = nullptr;  // tile maxima are refreshed after the filters: no slack for filtered entries is needed
+    const int extra = 0;
 
     for (size_t start = 0; start < nq; start += batch) {
       size_t end = std::min(nq, start + batch), rows = end - start;
+      bool filters_applied = false;
       if (fast) {
         IMP_PROF("score_gemm");
         dim3 grid((unsigned)((ni + 127) / 128), (unsigned)((rows + 127) / 128));
@@ -575,16 +606,30 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
         int grid = (int)std::min<size_t>((total + 255) / 256, (size_t)ctx().num_cus * 8);
         item_filter_kernel<<<grid, 256, 0, stream()>>>(scores, (int)rows, (int)ni, item_filter->v.data(), (int)item_filter->size);
         IMP_CHECK_HIP(hipGetLastError());
+        filters_applied = true;
       }
       if (query_filter && query_filter->nnz) {
         IMP_PROF("coo_filter");
         int grid = (int)std::min<size_t>(((size_t)query_filter->nnz + 255) / 256, (size_t)ctx().num_cus * 8);
         coo_filter_kernel<<<grid, 256, 0, stream()>>>(scores, (int)start, (int)end, (int)ni, query_filter->row.data(),
                                                       query_filter->col.data(), (size_t)query_filter->nnz);
-        if (counts) {
-          IMP_CHECK_HIP(hipMemsetAsync(counts, 0, rows * sizeof(int), stream()));
-          coo_count_kernel<<<grid, 256, 0, stream()>>>(query_filter->row.data(), (size_t)query_filter->nnz, (int)start, (int)end,
-                                                       counts);
+        IMP_CHECK_HIP(hipGetLastError());
+        filters_applied = true;
+      }
+      if (fast && filters_applied) {
+        // second phase (all filter writes are done): refresh the maxima of the touched tiles
+        IMP_PROF("filter_tile_refresh");
+        if (item_filter && item_filter->size) {
+          size_t total = rows * item_filter->size;
+          int grid = (int)std::min<size_t>((total + 255) / 256, (size_t)ctx().num_cus * 8);
+          item_filter_refresh_kernel<<<grid, 256, 0, stream()>>>(scores, tile_max, (int)rows, (int)ni, n_tiles,
+                                                                 item_filter->v.data(), (int)item_filter->size);
+        }
+        if (query_filter && query_filter->nnz) {
+          int grid = (int)std::min<size_t>(((size_t)query_filter->nnz + 255) / 256, (size_t)ctx().num_cus * 8);
+          coo_filter_refresh_kernel<<<grid, 256, 0, stream()>>>(scores, tile_max, (int)start, (int)end, (int)ni, n_tiles,
+                                                                query_filter->row.data(), query_filter->col.data(),
+                                                                (size_t)query_filter->nnz);
         }
         IMP_CHECK_HIP(hipGetLastError());
       }
