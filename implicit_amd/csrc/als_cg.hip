@@ -227,9 +227,8 @@ __global__ __launch_bounds__(256) void cg_long_partial_q_kernel(const LongPlanDe
     }
     for (int k0 = begin; k0 < end; k0 += 32) {
       QTile<F> tile;
-      float cpos[QL<F>::EQ];
-      load_qtile<F>(tile, cpos, indices, data, Y, lane, k0, end);
-      qtile_apply<F, FIRST>(tile, cpos, ve, ae);
+      load_qtile<F>(tile, indices, data, Y, lane, k0, end);
+      qtile_apply<F, FIRST>(tile, ve, ae);
     }
     float ac[FC];
     reduce_expanded<F>(ae, ac);

@@ -98,8 +98,7 @@ __global__ __launch_bounds__(1024) void als_cg_qgroup_kernel(const int32_t *__re
     for (int c = 0; c < FC; ++c) x[c] = 0.f;
     if (valid) load_compact<F>(xrow, lane, x);
     QTile<F> tile;
-    float cpos[QL<F>::EQ];
-    load_qtile<F>(tile, cpos, indices, data, Y, lane, row_begin, row_end);
+    load_qtile<F>(tile, indices, data, Y, lane, row_begin, row_end);
     fetch_meta(g + gridDim.x, u_next, rb_next, re_next);  // overlaps with the gathers above
 
     float ve[FE], ae[FE];
@@ -108,7 +107,7 @@ __global__ __launch_bounds__(1024) void als_cg_qgroup_kernel(const int32_t *__re
     expand_vector<F>(x, ve);
 #pragma unroll
     for (int e = 0; e < FE; ++e) ae[e] = 0.f;
-    qtile_apply<F, true>(tile, cpos, ve, ae);
+    qtile_apply<F, true>(tile, ve, ae);
     reduce_expanded<F>(ae, sp);
 #pragma unroll
     for (int c = 0; c < FC; ++c) p[c] = r[c] = sp[c] - Ap[c];
@@ -122,7 +121,7 @@ __global__ __launch_bounds__(1024) void als_cg_qgroup_kernel(const int32_t *__re
         expand_vector<F>(p, ve);
 #pragma unroll
         for (int e = 0; e < FE; ++e) ae[e] = 0.f;
-        qtile_apply<F, false>(tile, cpos, ve, ae);
+        qtile_apply<F, false>(tile, ve, ae);
         reduce_expanded<F>(ae, sp);
 #pragma unroll
         for (int c = 0; c < FC; ++c) Ap[c] += sp[c];
@@ -148,84 +147,131 @@ __global__ __launch_bounds__(1024) void als_cg_qgroup_kernel(const int32_t *__re
 }
 
 // ---- mid rows: a team of WPR wavefronts per row, the whole row resident -----------------------------------------------
-template <int F, int WPR, int BLOCK>
+// STATS (debug, IMP_CG_STATS=1): s_memtime ticks (10 ns) summed over waves per phase --
+//   [0] row start -> tile resident (gathers drained)  [1] operand vector to LDS + expand  [2] dense part
+//   [3] tile entries  [4] reduce-scatter  [5] combine (barriers included)  [6] dots / CG update  [7] wave-rows
+template <int F, int WPR, int BLOCK, bool STATS = false>
 __global__ __launch_bounds__(BLOCK, 4) void als_cg_qteam_kernel(const int32_t *__restrict__ order, int first, int count,
                                                                 const int32_t *__restrict__ indptr,
                                                                 const int32_t *__restrict__ indices,
                                                                 const float *__restrict__ data, float *__restrict__ X,
                                                                 const float *__restrict__ Y, const float *__restrict__ A0,
-                                                                int cg_steps) {
+                                                                int cg_steps, unsigned long long *__restrict__ stats = nullptr) {
+  unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = 0;
+  auto tick = [&](int slot) {  // charge the time since the previous tick to `slot`
+    if constexpr (STATS) {
+      __builtin_amdgcn_sched_barrier(0);
+      unsigned long long now = __builtin_amdgcn_s_memtime();
+      if (slot >= 0) tk[slot] += now - t_last;
+      t_last = now;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   constexpr int FC = F / 64, FE = F / 16, T = 32, WAVES = BLOCK / 64, TEAMS = WAVES / WPR;
   static_assert(WPR <= WAVES && (F / WPR) % 4 == 0, "team width");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *A0s = smem;                        // [F][F]
-  float *scratch = A0s + (size_t)F * F;     // [WAVES][F]  partial vectors of the combine
-  float *vecs = scratch + (size_t)WAVES * F;  // [WAVES][F]  wave-private copy of the operand vector (natural order)
+  float *A0s = smem;                             // [F][F]
+  float *scratch = A0s + (size_t)F * F;          // [2][WAVES][F]  partial vectors of the combine, double-buffered
+  float *vecs = scratch + (size_t)2 * WAVES * F;  // [WAVES][F]  wave-private copy of the operand vector (natural order)
+  unsigned *arrivals = reinterpret_cast<unsigned *>(vecs + (size_t)WAVES * F);  // [TEAMS] monotonic team-barrier counters
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int team = wave / WPR, sub = wave % WPR;
   for (int e = threadIdx.x; e < F * F; e += BLOCK) A0s[e] = A0[e];
-  __syncthreads();
-  const int j_begin = F * sub / WPR, j_end = F * (sub + 1) / WPR;
+  if (threadIdx.x < TEAMS) arrivals[threadIdx.x] = 0u;
+  __syncthreads();  // the only workgroup-wide barrier: from here on the teams run their rows independently
+  const int j_begin = F * sub / WPR;
   float *myvec = vecs + (size_t)wave * F;
 
-  // sum of the team's WPR partial vectors (fixed order); every wave of the team gets the same bits
+  // Team-local barrier.  s_barrier is workgroup-wide, which would hold the TEAMS rows of a workgroup in lock step --
+  // every wave of the CU gathering at once, then every wave hammering the LDS at once.  The waves of a workgroup
+  // are co-resident, so a team can meet on a monotonic LDS counter instead (each wave keeps its own target); teams then
+  // drift apart and one team's gather latency hides under the others' arithmetic.
+  unsigned arrive_target = 0;
+  auto team_sync = [&]() {
+    if constexpr (WPR == WAVES) {
+      __syncthreads();
+    } else {
+      arrive_target += WPR;
+      if (lane == 0) __hip_atomic_fetch_add(&arrivals[team], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      while (__builtin_amdgcn_readfirstlane(
+                 __hip_atomic_load(&arrivals[team], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < arrive_target)
+        __builtin_amdgcn_s_sleep(1);
+    }
+  };
+  // sum of the team's WPR partial vectors (fixed order); every wave of the team gets the same bits.  The partials
+  // alternate between two buffers, so one meeting per combine is enough: a wave can only overwrite a buffer two
+  // combines later, which it cannot reach before its team mates have passed the combine in between.
+  int parity = 0;
   auto combine = [&](float (&acc)[FC]) {
-    if constexpr (WPR == 1) return;  // independent waves: nothing to combine, no barrier
+    if constexpr (WPR == 1) return;  // independent waves: nothing to combine
+    float *buf = scratch + (size_t)parity * WAVES * F;
+    parity ^= 1;
 #pragma unroll
-    for (int c = 0; c < FC; ++c) scratch[wave * F + QL<F>::cfactor(lane, c)] = acc[c];
-    __syncthreads();
+    for (int c = 0; c < FC; ++c) buf[wave * F + QL<F>::cfactor(lane, c)] = acc[c];
+    team_sync();
 #pragma unroll
     for (int c = 0; c < FC; ++c) {
       float s = 0.f;
 #pragma unroll
-      for (int w = 0; w < WPR; ++w) s += scratch[(team * WPR + w) * F + QL<F>::cfactor(lane, c)];
+      for (int w = 0; w < WPR; ++w) s += buf[(team * WPR + w) * F + QL<F>::cfactor(lane, c)];
       acc[c] = s;
     }
-    __syncthreads();
+    tick(5);
   };
   // one pass: acc (compact) = [A0 rows of this wave] . v + [tile entries of this wave] weights
-  auto pass = [&](auto first_tag, const QTile<F> &tile, const float (&cpos)[QL<F>::EQ], const float (&v)[FC], float (&acc)[FC],
-                  bool work) {
+  auto pass = [&](auto first_tag, const QTile<F> &tile, const float (&v)[FC], float (&acc)[FC], bool work) {
     float ve[FE], ae[FE];
 #pragma unroll
     for (int e = 0; e < FE; ++e) ae[e] = 0.f;
+    tick(6);
     if (work) {  // wave-uniform, identical across the team
 #pragma unroll
       for (int c = 0; c < FC; ++c) myvec[QL<F>::cfactor(lane, c)] = v[c];  // wave-private: no barrier needed
+      // the dense part runs before the operand is expanded: with the tile resident the register file is full, and
+      // every register not live here is one more LDS read the loop below can keep in flight
+      gram_matvec_q<F, F / WPR / 4>(A0s, F, myvec, lane, j_begin, ae);
+      __builtin_amdgcn_sched_barrier(0);
+      tick(2);
       expand_vector<F>(v, ve);
-      gram_matvec_q<F>(A0s, F, myvec, lane, j_begin, j_end, ae);
-      qtile_apply<F, decltype(first_tag)::value>(tile, cpos, ve, ae);
+      tick(1);
+      qtile_apply<F, decltype(first_tag)::value>(tile, ve, ae);
+      tick(3);
     }
     reduce_expanded<F>(ae, acc);
+    tick(4);
   };
 
-  const int groups = (count + TEAMS - 1) / TEAMS;
-  // row metadata (schedule entry -> row id -> nnz range: two dependent scalar loads) is fetched one group ahead
-  auto fetch_meta = [&](int g, int &u, int &rb, int &re) {
-    const int i = g * TEAMS + team;
-    u = rb = re = 0;
-    if (g < groups && i < count) {
-      u = __builtin_amdgcn_readfirstlane(order[first + i]);
-      rb = __builtin_amdgcn_readfirstlane(indptr[u]);
-      re = __builtin_amdgcn_readfirstlane(indptr[u + 1]);
-    }
+  // this team's rows: i = (blockIdx.x + k gridDim.x) TEAMS + team.  The pipeline runs two rows deep: while row i is
+  // solved, the entries (column, confidence) of row i + step are in flight and the metadata (schedule entry -> row
+  // id -> nnz range, two dependent loads) of row i + step has just been read.  Rows past the end re-read the last row.
+  auto fetch_meta = [&](int i, int &u, int &rb, int &re) {
+    u = __builtin_amdgcn_readfirstlane(order[first + min(i, count - 1)]);
+    rb = __builtin_amdgcn_readfirstlane(indptr[u]);
+    re = __builtin_amdgcn_readfirstlane(indptr[u + 1]);
   };
-  int u_next, rb_next, re_next;
-  fetch_meta(blockIdx.x, u_next, rb_next, re_next);
-  for (int g = blockIdx.x; g < groups; g += gridDim.x) {
-    const bool valid = g * TEAMS + team < count;
+  const int i_step = gridDim.x * TEAMS;
+  int u_next, rb_next, re_next, col_next;
+  float c_next;
+  fetch_meta(blockIdx.x * TEAMS + team, u_next, rb_next, re_next);
+  fetch_entries(indices, data, lane, min(rb_next + T * sub, re_next), re_next, col_next, c_next);
+  for (int i = blockIdx.x * TEAMS + team; i < count; i += i_step) {
+    constexpr bool valid = true;
     const int u = u_next, row_begin = rb_next, row_end = re_next;
     float *xrow = X + (size_t)u * F;
     float x[FC], r[FC], p[FC], Ap[FC];
-#pragma unroll
-    for (int c = 0; c < FC; ++c) x[c] = 0.f;
-    if (valid) load_compact<F>(xrow, lane, x);
+    tick(-1);
     const int k0 = min(row_begin + T * sub, row_end);  // this wave's slice of the row (may be empty)
     QTile<F> tile;
-    float cpos[QL<F>::EQ];
-    load_qtile<F>(tile, cpos, indices, data, Y, lane, k0, row_end);
-    fetch_meta(g + gridDim.x, u_next, rb_next, re_next);  // overlaps with the gathers above
+    load_compact<F>(xrow, lane, x);  // first in the queue: the dense part of the first pass only needs x
+    load_qtile_staged<F>(tile, col_next, c_next, Y, lane, min(T, row_end - k0));
+    fetch_meta(i + i_step, u_next, rb_next, re_next);  // overlaps with the gathers above
+    fetch_entries(indices, data, lane, min(rb_next + T * sub, re_next), re_next, col_next, c_next);
+    if constexpr (STATS) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      tick(0);
+      tk[7] += 1;
+    }
 
     // r = -(A0 x) + sum_k (c+ - (|c|-1) y.x) y        (_als.pyx:187-201): the dense part enters with a minus sign
     {
@@ -234,12 +280,17 @@ __global__ __launch_bounds__(BLOCK, 4) void als_cg_qteam_kernel(const int32_t *_
       for (int e = 0; e < FE; ++e) ae[e] = 0.f;
 #pragma unroll
       for (int c = 0; c < FC; ++c) myvec[QL<F>::cfactor(lane, c)] = x[c];
-      expand_vector<F>(x, ve);
-      gram_matvec_q<F>(A0s, F, myvec, lane, j_begin, j_end, ae);
+      gram_matvec_q<F, F / WPR / 4>(A0s, F, myvec, lane, j_begin, ae);
 #pragma unroll
       for (int e = 0; e < FE; ++e) ae[e] = -ae[e];
-      qtile_apply<F, true>(tile, cpos, ve, ae);
+      __builtin_amdgcn_sched_barrier(0);
+      tick(2);
+      expand_vector<F>(x, ve);
+      tick(1);
+      qtile_apply<F, true>(tile, ve, ae);
+      tick(3);
       reduce_expanded<F>(ae, r);
+      tick(4);
     }
     combine(r);
 #pragma unroll
@@ -249,7 +300,7 @@ __global__ __launch_bounds__(BLOCK, 4) void als_cg_qteam_kernel(const int32_t *_
     const bool store = active && sub == 0;
 
     for (int it = 0; it < cg_steps; ++it) {
-      pass(std::false_type{}, tile, cpos, p, Ap, active);
+      pass(std::false_type{}, tile, p, Ap, active);
       combine(Ap);
       if (active) {
         float alpha = rsold / dot_compact<F>(p, Ap);
@@ -260,7 +311,7 @@ __global__ __launch_bounds__(BLOCK, 4) void als_cg_qteam_kernel(const int32_t *_
         }
         float rsnew = dot_compact<F>(r, r);
         if (rsnew < 1e-20f) {
-          active = false;  // the oracle breaks here (_als.pyx:235); keep taking the barriers
+          active = false;  // the oracle breaks here (_als.pyx:235); the whole team takes the same branch
         } else {
           float beta = rsnew / rsold;
 #pragma unroll
@@ -270,6 +321,11 @@ __global__ __launch_bounds__(BLOCK, 4) void als_cg_qteam_kernel(const int32_t *_
       }
     }
     if (store) store_compact<F>(xrow, lane, x);
+    tick(6);
+  }
+  if constexpr (STATS) {
+    if (lane == 0)
+      for (int i = 0; i < 8; ++i) atomicAdd(&stats[i], tk[i]);
   }
 }
 
@@ -292,14 +348,33 @@ static void launch_qteam(const imp_csr *C, int first, int count, float *X, const
                          const char *name) {
   if (count <= 0) return;
   constexpr int WAVES = BLOCK / 64, TEAMS = WAVES / WPR;
-  size_t lds = ((size_t)F * F + 2 * WAVES * F) * sizeof(float);
+  size_t lds = ((size_t)F * F + 3 * WAVES * F + TEAMS) * sizeof(float);
   auto kern = als_cg_qteam_kernel<F, WPR, BLOCK>;
   IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / BLOCK, (160 * 1024) / lds));
   int grid = std::min((count + TEAMS - 1) / TEAMS, ctx().num_cus * per_cu);
+  static const bool want_stats = getenv("IMP_CG_STATS") != nullptr;
+  if (want_stats) {  // debug: per-phase tick sums of this launch, printed to stderr
+    static unsigned long long *stats = nullptr;
+    if (!stats) IMP_CHECK_HIP(hipMalloc(&stats, 8 * sizeof(unsigned long long)));
+    IMP_CHECK_HIP(hipMemsetAsync(stats, 0, 8 * sizeof(unsigned long long), stream()));
+    auto skern = als_cg_qteam_kernel<F, WPR, BLOCK, true>;
+    IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(skern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    skern<<<grid, BLOCK, lds, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(), C->data.data(), X,
+                                         Y, A0, cg_steps, stats);
+    unsigned long long h[8];
+    IMP_CHECK_HIP(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, stream()));
+    IMP_CHECK_HIP(hipStreamSynchronize(stream()));
+    const double n = h[7] ? (double)h[7] : 1.0;
+    fprintf(stderr,
+            "[cg-stats] %s rows=%d wave-rows=%.0f  ticks(10ns)/wave-row: gather %.1f vec+expand %.1f dense %.1f entries %.1f "
+            "reduce %.1f combine %.1f update %.1f\n",
+            name, count, n, h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n, h[6] / n);
+    return;
+  }
   IMP_PROF(name);
   kern<<<grid, BLOCK, lds, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(), C->data.data(), X, Y,
-                                      A0, cg_steps);
+                                      A0, cg_steps, nullptr);
   IMP_CHECK_HIP(hipGetLastError());
 }
 

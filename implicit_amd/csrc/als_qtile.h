@@ -85,13 +85,13 @@ template <int F> __device__ __forceinline__ void reduce_expanded(const float (&a
 
 template <int F> struct QTile {
   float y[QL<F>::EQ][QL<F>::FE];  // this lane's slice of its group's 8 entries
-  float cm1[QL<F>::EQ];           // |c| - 1 (0 when the entry is beyond the row)
+  float c[QL<F>::EQ];             // raw confidence; entries beyond the row carry -1, whose weights |c| - 1 and c+ are both 0
   int cnt;                        // valid entries of the whole 32-entry tile (wave-uniform)
 };
 
 // entry t = 4 q + g of the tile covers nnz k0 + t; lanes past the end repeat the last valid entry with weight 0
 template <int F>
-__device__ __forceinline__ void load_qtile(QTile<F> &tile, float (&cpos)[QL<F>::EQ], const int32_t *__restrict__ indices,
+__device__ __forceinline__ void load_qtile(QTile<F> &tile, const int32_t *__restrict__ indices,
                                            const float *__restrict__ data, const float *__restrict__ Y, int lane, int k0,
                                            int end) {
   constexpr int FE = QL<F>::FE, EQ = QL<F>::EQ;
@@ -105,9 +105,7 @@ __device__ __forceinline__ void load_qtile(QTile<F> &tile, float (&cpos)[QL<F>::
     const bool ok = t < cnt;
     const int k = k0 + (cnt > 0 ? min(t, cnt - 1) : 0);
     col[q] = cnt > 0 ? (unsigned)indices[k] : 0u;
-    const float c = ok ? data[k] : 0.f;
-    tile.cm1[q] = ok ? fabsf(c) - 1.f : 0.f;
-    cpos[q] = c > 0.f ? c : 0.f;
+    tile.c[q] = ok ? data[k] : -1.f;
   }
   // gathers back to back, in two wave-uniform halves (q < 4 covers tile entries 0..15); few branches keep the
   // compiler's vmcnt bookkeeping exact so that all loads of a half are in flight together
@@ -137,46 +135,119 @@ __device__ __forceinline__ void load_qtile(QTile<F> &tile, float (&cpos)[QL<F>::
   }
 }
 
-// ae += sum over this group's entries of w y, with the dots against the expanded vector ve
-//   FIRST: w = c+ - (|c|-1) d    else: w = (|c|-1) d      (_als.pyx:190-201, 214-222)
-template <int F, bool FIRST>
-__device__ __forceinline__ void qtile_apply(const QTile<F> &tile, const float (&cpos)[QL<F>::EQ], const float (&ve)[F / 16],
-                                            float (&ae)[F / 16]) {
+// Staged variant for the resident kernels: the (column, confidence) pairs of a tile are fetched one row AHEAD, one entry
+// per lane (lanes l and l + 32 both hold entry min(l, cnt - 1) of the slice) -- two registers that stay in flight
+// during the previous row's CG passes -- so that a row starts with its gather addresses already in hand (one HBM
+// round trip per row on the critical path instead of two).  `end` > 0 and [end - 1] must be a valid entry.
+__device__ __forceinline__ void fetch_entries(const int32_t *__restrict__ indices, const float *__restrict__ data, int lane,
+                                              int k0, int end, int &col, float &c) {
+  const int k = min(k0 + (lane & 31), end - 1);
+  col = indices[k];
+  c = data[k];
+}
+
+template <int F>
+__device__ __forceinline__ void load_qtile_staged(QTile<F> &tile, int col_reg, float c_reg, const float *__restrict__ Y,
+                                                  int lane, int cnt) {
   constexpr int FE = QL<F>::FE, EQ = QL<F>::EQ;
+  tile.cnt = cnt;
+  const int g = lane >> 4;
+  unsigned col[EQ];
+  int src = 4 * g;  // byte address of the source lane; kept opaque so that the 8 addresses are re-derived per row
+  asm volatile("" : "+v"(src));  // (hoisted out of the row loop they would cost 8 registers the kernel does not have)
 #pragma unroll
   for (int q = 0; q < EQ; ++q) {
-    if (4 * q < tile.cnt) {  // wave-uniform
-      float part = 0.f;
+    const int t = 4 * q + g;  // entry t lives in lane t
+    col[q] = (unsigned)__builtin_amdgcn_ds_bpermute(src + 16 * q, col_reg);
+    const float cv = __int_as_float(__builtin_amdgcn_ds_bpermute(src + 16 * q, __float_as_int(c_reg)));
+    tile.c[q] = t < cnt ? cv : -1.f;
+  }
+  auto gather = [&](int q) {
+    const float *src = Y + (size_t)col[q] * F + 4 * (lane & 15);
 #pragma unroll
-      for (int e = 0; e < FE; ++e) part = fmaf(tile.y[q][e], ve[e], part);
-      const float d = row_allsum(part);
-      const float w = FIRST ? cpos[q] - tile.cm1[q] * d : tile.cm1[q] * d;
-#pragma unroll
-      for (int e = 0; e < FE; ++e) ae[e] = fmaf(w, tile.y[q][e], ae[e]);
+    for (int e = 0; e < FE; e += 4) {
+      float4 v = *reinterpret_cast<const float4 *>(src + 16 * e);
+      tile.y[q][e] = v.x, tile.y[q][e + 1] = v.y, tile.y[q][e + 2] = v.z, tile.y[q][e + 3] = v.w;
     }
+  };
+  auto clear = [&](int q) {
+#pragma unroll
+    for (int e = 0; e < FE; ++e) tile.y[q][e] = 0.f;
+  };
+  if (cnt > 16) {
+#pragma unroll
+    for (int q = 0; q < EQ; ++q) gather(q);
+  } else if (cnt > 0) {
+#pragma unroll
+    for (int q = 0; q < EQ / 2; ++q) gather(q);
+#pragma unroll
+    for (int q = EQ / 2; q < EQ; ++q) clear(q);
+  } else {
+#pragma unroll
+    for (int q = 0; q < EQ; ++q) clear(q);
   }
 }
 
-// Dense part split over the groups: group g adds A0[j][.] * v[j] for j = j_begin + 4 s + g.  `vec_lds` is this wave's
-// private LDS copy of the operand vector in natural factor order (wave-synchronous: written by the caller, no barrier).
-template <int F>
-__device__ __forceinline__ void gram_matvec_q(const float *A0s, int lda, const float *vec_lds, int lane, int j_begin, int j_end,
-                                              float (&ae)[F / 16]) {
-  constexpr int FE = QL<F>::FE;
-  const int g = lane >> 4;
-#pragma unroll 4
-  for (int j0 = j_begin; j0 < j_end; j0 += 4) {
-    const int j = j0 + g;
-    const float vj = vec_lds[j];
-    const float *row = A0s + (size_t)j * lda + 4 * (lane & 15);
+// ae += sum over this group's entries of w y, with the dots against the expanded vector ve
+//   FIRST: w = c+ - (|c|-1) d    else: w = (|c|-1) d      (_als.pyx:190-201, 214-222)
+template <int F, bool FIRST>
+__device__ __forceinline__ void qtile_apply(const QTile<F> &tile, const float (&ve)[F / 16], float (&ae)[F / 16]) {
+  constexpr int FE = QL<F>::FE, EQ = QL<F>::EQ;
+  // this lane's share of y_q . v with two running sums (even / odd slots): maps onto v_pk_fma_f32
+  auto partial = [&](int q) {
+    float lo = 0.f, hi = 0.f;
 #pragma unroll
-    for (int e = 0; e < FE; e += 4) {
-      const float4 a = *reinterpret_cast<const float4 *>(row + 16 * e);
-      ae[e] = fmaf(vj, a.x, ae[e]);
-      ae[e + 1] = fmaf(vj, a.y, ae[e + 1]);
-      ae[e + 2] = fmaf(vj, a.z, ae[e + 2]);
-      ae[e + 3] = fmaf(vj, a.w, ae[e + 3]);
+    for (int e = 0; e < FE; e += 2) {
+      lo = fmaf(tile.y[q][e], ve[e], lo);
+      hi = fmaf(tile.y[q][e + 1], ve[e + 1], hi);
     }
+    return lo + hi;
+  };
+  auto axpy = [&](int q, float d) {
+    const float c = tile.c[q], cm1 = fabsf(c) - 1.f;  // two VALU ops per step instead of 8 more live registers
+    const float w = FIRST ? (c > 0.f ? c : 0.f) - cm1 * d : cm1 * d;
+#pragma unroll
+    for (int e = 0; e < FE; ++e) ae[e] = fmaf(w, tile.y[q][e], ae[e]);
+  };
+#pragma unroll
+  for (int q = 0; q < EQ; ++q) {
+    if (4 * q < tile.cnt) axpy(q, row_allsum(partial(q)));  // wave-uniform skip of whole steps
+  }
+}
+
+// Dense part split over the groups: group g adds A0[j][.] * v[j] for j = j_begin + 4 s + g, s = 0..NJ-1.  `vec_lds` is
+// this wave's private LDS copy of the operand vector in natural factor order (wave-synchronous: written by the caller,
+// no barrier).  With a tile resident the compiler is at its register limit and would issue the LDS reads one at a
+// time, each waiting out the full LDS latency; the loop is therefore staged by hand -- the reads of B steps are issued
+// back to back into their own registers, then consumed.
+template <int F, int NJ>
+__device__ __forceinline__ void gram_matvec_q(const float *A0s, int lda, const float *vec_lds, int lane, int j_begin,
+                                              float (&ae)[F / 16]) {
+  constexpr int FE = QL<F>::FE, B = NJ % 4 == 0 ? 4 : (NJ % 2 == 0 ? 2 : 1);
+  const int g = lane >> 4;
+  const float *vp = vec_lds + j_begin + g;
+  const float *row = A0s + (size_t)(j_begin + g) * lda + 4 * (lane & 15);
+#pragma unroll 1
+  for (int s0 = 0; s0 < NJ; s0 += B) {
+    float vj[B];
+    float4 a[B][FE / 4];
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      vj[b] = vp[4 * (s0 + b)];
+#pragma unroll
+      for (int e = 0; e < FE / 4; ++e) a[b][e] = *reinterpret_cast<const float4 *>(row + (size_t)4 * (s0 + b) * lda + 64 * e);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+#pragma unroll
+      for (int e = 0; e < FE / 4; ++e) {
+        ae[4 * e] = fmaf(vj[b], a[b][e].x, ae[4 * e]);
+        ae[4 * e + 1] = fmaf(vj[b], a[b][e].y, ae[4 * e + 1]);
+        ae[4 * e + 2] = fmaf(vj[b], a[b][e].z, ae[4 * e + 2]);
+        ae[4 * e + 3] = fmaf(vj[b], a[b][e].w, ae[4 * e + 3]);
+      }
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
