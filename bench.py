@@ -243,7 +243,7 @@ def main():
     for _ in range(args.warmup):
         step()
     gpu.synchronize()
-    gpu.Profiler.enable(True)
+    gpu.Profiler.enable(os.environ.get("IMP_BENCH_NO_PROF") is None)  # debug switch: cost of the event pairs
     gpu.Profiler.reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):

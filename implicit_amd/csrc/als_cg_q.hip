@@ -78,28 +78,28 @@ __global__ __launch_bounds__(1024) void als_cg_qgroup_kernel(const int32_t *__re
   __syncthreads();
 
   const int groups = (count + 15) / 16;
-  auto fetch_meta = [&](int g, int &u, int &rb, int &re) {  // one group ahead (two dependent scalar loads)
-    const int i = g * 16 + wave;
-    u = rb = re = 0;
-    if (g < groups && i < count) {
-      u = __builtin_amdgcn_readfirstlane(order[first + i]);
-      rb = __builtin_amdgcn_readfirstlane(indptr[u]);
-      re = __builtin_amdgcn_readfirstlane(indptr[u + 1]);
-    }
+  // two groups deep, as in the team kernel below: entries (column, confidence) of the next group's row in flight during
+  // this group's passes, its metadata (schedule entry -> row id -> nnz range) read just before; rows past the end
+  // re-read the last row and are masked by `valid`
+  auto fetch_meta = [&](int g, int &u, int &rb, int &re) {
+    u = __builtin_amdgcn_readfirstlane(order[first + min(g * 16 + wave, count - 1)]);
+    rb = __builtin_amdgcn_readfirstlane(indptr[u]);
+    re = __builtin_amdgcn_readfirstlane(indptr[u + 1]);
   };
-  int u_next, rb_next, re_next;
+  int u_next, rb_next, re_next, col_next;
+  float c_next;
   fetch_meta(blockIdx.x, u_next, rb_next, re_next);
+  fetch_entries(indices, data, lane, rb_next, re_next, col_next, c_next);
   for (int g = blockIdx.x; g < groups; g += gridDim.x) {
     const bool valid = g * 16 + wave < count;
     const int u = u_next, row_begin = rb_next, row_end = re_next;
     float *xrow = X + (size_t)u * F;
     float x[FC], r[FC], p[FC], Ap[FC], sp[FC];
-#pragma unroll
-    for (int c = 0; c < FC; ++c) x[c] = 0.f;
-    if (valid) load_compact<F>(xrow, lane, x);
+    load_compact<F>(xrow, lane, x);
     QTile<F> tile;
-    load_qtile<F>(tile, indices, data, Y, lane, row_begin, row_end);
+    load_qtile_staged<F>(tile, col_next, c_next, Y, lane, valid ? row_end - row_begin : 0);
     fetch_meta(g + gridDim.x, u_next, rb_next, re_next);  // overlaps with the gathers above
+    fetch_entries(indices, data, lane, rb_next, re_next, col_next, c_next);
 
     float ve[FE], ae[FE];
     // r = -(A0 x) + sum_k (c+ - (|c|-1) y.x) y        (_als.pyx:187-201)
