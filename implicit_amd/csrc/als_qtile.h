@@ -209,6 +209,27 @@ __device__ __forceinline__ void qtile_apply(const QTile<F> &tile, const float (&
 #pragma unroll
     for (int e = 0; e < FE; ++e) ae[e] = fmaf(w, tile.y[q][e], ae[e]);
   };
+  if (tile.cnt == 4 * EQ) {
+    // full tile (most wave-tiles of the mid and long rows): no per-step branches, so the four independent
+    // dot -> DPP-reduce -> axpy chains of a half can be interleaved by the scheduler instead of running back to back
+#pragma unroll
+    for (int h = 0; h < EQ; h += 4) {
+      float d[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) d[q] = partial(h + q);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) d[q] += dpp_mov<0x128>(d[q]);  // row_ror:8
+#pragma unroll
+      for (int q = 0; q < 4; ++q) d[q] += dpp_mov<0x124>(d[q]);  // row_ror:4
+#pragma unroll
+      for (int q = 0; q < 4; ++q) d[q] += dpp_mov<0x122>(d[q]);  // row_ror:2
+#pragma unroll
+      for (int q = 0; q < 4; ++q) d[q] += dpp_mov<0x121>(d[q]);  // row_ror:1
+#pragma unroll
+      for (int q = 0; q < 4; ++q) axpy(h + q, d[q]);
+    }
+    return;
+  }
 #pragma unroll
   for (int q = 0; q < EQ; ++q) {
     if (4 * q < tile.cnt) axpy(q, row_allsum(partial(q)));  // wave-uniform skip of whole steps
