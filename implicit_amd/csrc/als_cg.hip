@@ -177,9 +177,13 @@ __global__ __launch_bounds__(256) void cg_long_partial_kernel(const LongPlanDev 
                                                               const float *__restrict__ pvec, const float *__restrict__ scal) {
   constexpr int LD = 64 * VPL;
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-  const int nwaves = (gridDim.x * blockDim.x) >> 6;
-  for (int s = wave; s < plan.n_seg; s += nwaves) {
+  // the workgroups with blockIdx % 8 == x run on XCD x (observed placement; a speed matter only) and sweep that
+  // XCD's part of the execution order (imp_csr_create: column stripes dealt to the XCDs)
+  const int xcd = blockIdx.x & 7;
+  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x >> 3) * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+  const int nwaves = (gridDim.x >> 3) * (blockDim.x >> 6);
+  for (int i = plan.xcd_start[xcd] + wave; i < plan.xcd_start[xcd + 1]; i += nwaves) {
+    const int s = __builtin_amdgcn_readfirstlane(plan.seg_exec[i]);
     const int li = __builtin_amdgcn_readfirstlane(plan.seg_row[s]);
     if (!FIRST && scal[2 * li + 1] != 0.f) continue;  // row finished (early exit)
     const int begin = __builtin_amdgcn_readfirstlane(plan.seg_begin[s]);
@@ -210,13 +214,31 @@ __global__ __launch_bounds__(256) void cg_long_partial_q_kernel(const LongPlanDe
                                                                 const float *__restrict__ pvec, const float *__restrict__ scal) {
   constexpr int FE = F / 16, FC = F / 64, LD = F;
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-  const int nwaves = (gridDim.x * blockDim.x) >> 6;
-  for (int s = wave; s < plan.n_seg; s += nwaves) {
-    const int li = __builtin_amdgcn_readfirstlane(plan.seg_row[s]);
-    if (!FIRST && scal[2 * li + 1] != 0.f) continue;  // row finished (early exit)
-    const int begin = __builtin_amdgcn_readfirstlane(plan.seg_begin[s]);
-    const int end = __builtin_amdgcn_readfirstlane(plan.seg_end[s]);
+  const int xcd = blockIdx.x & 7;  // see cg_long_partial_kernel
+  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x >> 3) * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+  const int nwaves = (gridDim.x >> 3) * (blockDim.x >> 6);
+  const int stop = plan.xcd_start[xcd + 1];
+  int i = plan.xcd_start[xcd] + wave;
+  if (i >= stop) return;
+  // Striped plans have many short segments (a few entries of one row inside one column stripe), so the loop is
+  // pipelined like the row loop of the resident kernels: segment descriptors are read two segments ahead (scalar
+  // loads), the (column, confidence) pairs of the next tile -- of this segment or of the next one -- one tile ahead.
+  auto descriptor = [&](int at, int &s, int &li, int &begin, int &end) {
+    s = plan.seg_exec[min(at, stop - 1)];
+    li = plan.seg_row[s];
+    begin = plan.seg_begin[s];
+    end = plan.seg_end[s];
+  };
+  int s1, li1, b1, e1, s2, li2, b2, e2, col_next;
+  float c_next;
+  descriptor(i, s1, li1, b1, e1);
+  descriptor(i + nwaves, s2, li2, b2, e2);
+  fetch_entries(indices, data, lane, b1, e1, col_next, c_next);
+  for (; i < stop; i += nwaves) {
+    const int s = s1, li = li1, begin = b1, end = e1;
+    s1 = s2, li1 = li2, b1 = b2, e1 = e2;
+    descriptor(i + 2 * nwaves, s2, li2, b2, e2);
+    const bool skip = !FIRST && scal[2 * li + 1] != 0.f;  // row finished (early exit): no arithmetic, no partial
     const float *vsrc = (FIRST ? X + (size_t)plan.rows[li] * F : pvec + (size_t)li * LD) + 4 * (lane & 15);
     float ve[FE], ae[FE];
 #pragma unroll
@@ -227,12 +249,16 @@ __global__ __launch_bounds__(256) void cg_long_partial_q_kernel(const LongPlanDe
     }
     for (int k0 = begin; k0 < end; k0 += 32) {
       QTile<F> tile;
-      load_qtile<F>(tile, indices, data, Y, lane, k0, end);
+      load_qtile_staged<F>(tile, col_next, c_next, Y, lane, skip ? 0 : min(32, end - k0));
+      const bool last = k0 + 32 >= end;  // wave-uniform: the next tile belongs to the next segment
+      fetch_entries(indices, data, lane, last ? b1 : k0 + 32, last ? e1 : end, col_next, c_next);
       qtile_apply<F, FIRST>(tile, ve, ae);
     }
-    float ac[FC];
-    reduce_expanded<F>(ae, ac);
-    store_compact<F>(partial + (size_t)s * LD, lane, ac);
+    if (!skip) {
+      float ac[FC];
+      reduce_expanded<F>(ae, ac);
+      store_compact<F>(partial + (size_t)s * LD, lane, ac);
+    }
   }
 }
 
@@ -255,14 +281,37 @@ __global__ __launch_bounds__(BLOCK) void cg_long_combine_kernel(const LongPlanDe
     if (PHASE == 1 && scal[2 * li + 1] != 0.f) continue;
     float *xrow = X + (size_t)plan.rows[li] * f;
     float acc[VPL];
-#pragma unroll
-    for (int v = 0; v < VPL; ++v) acc[v] = 0.f;
     const int s0 = plan.row_seg[li], s1 = plan.row_seg[li + 1];
-    for (int s = s0; s < s1; ++s) {  // fixed order
-      float t[VPL];
-      load_row<VPL, VEC>(partial + (size_t)s * LD, vld, lane, t);
+    {  // fixed association: NS interleaved running sums, folded pairwise (a 147 K-nnz row has 288 segment partials;
+       // one dependent chain of loads + adds would make that row the launch's critical path)
+      constexpr int NS = 8;
+      float a8[NS][VPL];
 #pragma unroll
-      for (int v = 0; v < VPL; ++v) acc[v] += t[v];
+      for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) a8[i][v] = 0.f;
+      int s = s0;
+      for (; s + NS <= s1; s += NS) {
+        float t[NS][VPL];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) load_row<VPL, VEC>(partial + (size_t)(s + i) * LD, vld, lane, t[i]);
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
+#pragma unroll
+          for (int v = 0; v < VPL; ++v) a8[i][v] += t[i][v];
+      }
+      for (int i = 0; s < s1; ++s, ++i) {  // at most NS - 1 left: one more (partial) trip
+        float t[VPL];
+        load_row<VPL, VEC>(partial + (size_t)s * LD, vld, lane, t);
+#pragma unroll
+        for (int j = 0; j < NS; ++j)
+          if (j == i)
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) a8[j][v] += t[v];
+      }
+#pragma unroll
+      for (int v = 0; v < VPL; ++v)
+        acc[v] = ((a8[0][v] + a8[1][v]) + (a8[2][v] + a8[3][v])) + ((a8[4][v] + a8[5][v]) + (a8[6][v] + a8[7][v]));
     }
     float x[VPL], dense[VPL];
     load_row<VPL, VEC>(xrow, f, lane, x);
@@ -378,7 +427,7 @@ static void launch_long(const imp_csr *C, float *X, const float *Y, const float 
                                     (int)std::max<size_t>(lds, 16)));
   IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(comb1), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)std::max<size_t>(lds, 16)));
-  int grid_part = std::min((n_seg + 3) / 4, ctx().num_cus * 8);
+  int grid_part = std::min(((n_seg + 3) / 4 + 7) / 8 * 8, ctx().num_cus * 8);  // a multiple of 8: blockIdx % 8 = XCD
   int grid_comb = std::min((n_long + BLOCK / 64 - 1) / (BLOCK / 64), ctx().num_cus * 2);
   {
     IMP_PROF("als_cg_long_partial");

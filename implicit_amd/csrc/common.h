@@ -125,13 +125,16 @@ struct LongPlanDev {
   const int32_t *seg_row;    // [n_seg]    long-row index of each segment
   const int32_t *seg_begin;  // [n_seg]    nnz range of each segment
   const int32_t *seg_end;    // [n_seg]
+  const int32_t *seg_exec;   // [n_seg]    execution order of the partial kernel: segment ids grouped by XCD
+  int xcd_start[9];          // seg_exec[xcd_start[x] .. xcd_start[x+1]) is swept by the workgroups with blockIdx % 8 == x
 };
 
 // Rows are scheduled in length classes so that the work per wavefront is even and the longest rows
 // start first (SURVEY section 7 "load imbalance"): `order` = row ids sorted by descending nnz;
 // class b covers order[bin_start[b] .. bin_start[b+1]) and holds the rows with
 // kClassMax[b+1] < nnz <= kClassMax[b]:
-//   0 long  (> 512 nnz): cut into segments of <= kSegment nnz, segment-parallel CG passes
+//   0 long  (> 512 nnz): cut into segments of <= kSegment nnz (column-striped when the rows re-use the gathered
+//        matrix enough, see imp_csr_create), segment-parallel CG passes
 //   1..4 mid (256,512], (128,256], (64,128], (32,64]: a TEAM of 16/8/4/2 wavefronts per row, every
 //        wavefront keeps one 32-row gathered tile in registers for all passes
 //   5 short (16,32] and 6 short (0,16]: one wavefront per row, resident tile of 32 / 16 entries, 16 rows per
@@ -152,9 +155,14 @@ struct imp_csr {
   int32_t max_row = 0;
   // long-row plan
   int32_t n_long = 0, n_seg = 0;
-  imp::DeviceArray<int32_t> row_seg, seg_row, seg_begin, seg_end;
+  imp::DeviceArray<int32_t> row_seg, seg_row, seg_begin, seg_end, seg_exec;
+  int32_t xcd_start[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int32_t stripe = 0;  // column-stripe width of the long-row plan (0: rows cut into plain kSegment runs)
   LongPlanDev long_plan_dev() const {
-    return LongPlanDev{n_long, n_seg, order.data(), row_seg.data(), seg_row.data(), seg_begin.data(), seg_end.data()};
+    LongPlanDev d{n_long,           n_seg,          order.data(),    row_seg.data(), seg_row.data(),
+                  seg_begin.data(), seg_end.data(), seg_exec.data(), {0}};
+    for (int x = 0; x < 9; ++x) d.xcd_start[x] = xcd_start[x];
+    return d;
   }
   int32_t nonempty() const { return bin_start[kBins - 1]; }
   int32_t first_empty() const { return bin_start[kBins - 1]; }

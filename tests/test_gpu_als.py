@@ -102,6 +102,42 @@ def test_cg_long_rows_and_edge_cases(gpu, oracle):
     assert empty.any() and not got[empty].any()
 
 
+@pytest.mark.parametrize("stripe", ["0", "256", "1024", None])
+@pytest.mark.parametrize("f", [64, 128, 96])
+def test_cg_long_rows_striped_plan(gpu, oracle, monkeypatch, stripe, f):
+    """Long rows that re-use the gathered matrix >= 4x are cut at column-stripe boundaries and swept per XCD
+    (imp_csr_create); plain plan (IMP_STRIPE=0), narrow stripes (many short segments) and the default must agree
+    with the oracle, and an unsorted row falls back to the plain plan."""
+    if stripe is None:
+        monkeypatch.delenv("IMP_STRIPE", raising=False)
+    else:
+        monkeypatch.setenv("IMP_STRIPE", stripe)
+    rng = np.random.default_rng(11)
+    users, items = 200, 3000
+    dense_rows = sp.random(14, items, density=0.45, format="csr", dtype=np.float32, random_state=2)
+    dense_rows.data = 1 + 9 * dense_rows.data
+    dense_rows.data[::13] *= -1  # negative confidence (dislikes)
+    rest = synthetic_csr(users - 14, items, 9_000, seed=4, neg_frac=0.1, empty_frac=0.05)
+    C = sp.vstack([rest[:50], dense_rows, rest[50:]]).tocsr().astype(np.float32)
+    C.sort_indices()
+    lens = np.diff(C.indptr)
+    assert lens.max() > 1024 and lens[lens > 512].sum() >= 4 * items  # the striping condition holds
+    X0 = rng.random((users, f), dtype=np.float32) * 0.1 - 0.05
+    Y0 = rng.random((items, f), dtype=np.float32) * 0.1 - 0.05
+    want = X0.copy()
+    oracle.least_squares_cg(C, want, Y0, 0.05)
+    got, _ = _gpu_cg(gpu, C, X0.copy(), Y0, 0.05, 3)
+    assert rel(got, want) < TOL
+    # same matrix with one long row's entries reversed (unsorted indices): plain plan, same answer
+    U = C.copy()
+    r = int(np.argmax(lens))
+    lo, hi = U.indptr[r], U.indptr[r + 1]
+    U.indices[lo:hi] = U.indices[lo:hi][::-1].copy()
+    U.data[lo:hi] = U.data[lo:hi][::-1].copy()
+    got_u, _ = _gpu_cg(gpu, U, X0.copy(), Y0, 0.05, 3)
+    assert rel(got_u, want) < TOL
+
+
 @pytest.mark.parametrize("f", [6, 32, 64, 100, 128])
 def test_cholesky_sweep(gpu, oracle, f):
     C, X0, Y0 = _problem(2000, 800, 60_000, f)
