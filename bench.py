@@ -243,17 +243,30 @@ def main():
     for _ in range(args.warmup):
         step()
     gpu.synchronize()
-    gpu.Profiler.enable(os.environ.get("IMP_BENCH_NO_PROF") is None)  # debug switch: cost of the event pairs
+    # HIP-event pairs cost stream time (~0.2 ms per iteration for all ~30 launches), so the timed region carries them
+    # only for the dominant kernel family -- the mid-row team kernels of the CG sweep -- which is what `roofline`
+    # reports; the per-kernel breakdown comes from a separate, untimed pass below.
+    timed_filter = "als_cg_team" if (args.solver == "cg" and FACTORS in (64, 128)) else None
     gpu.Profiler.reset()
+    gpu.Profiler.enable(os.environ.get("IMP_BENCH_NO_PROF") is None, only=timed_filter)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     gpu.synchronize()
     elapsed = time.perf_counter() - t0
     gpu.Profiler.enable(False)
+    timed = {name: gpu.Profiler.get(name) for name in gpu.Profiler.names()}
 
     ms_per_step = 1e3 * elapsed / args.steps
     value = (users + items) / (elapsed / args.steps)
+
+    detail_steps = min(args.steps, 3)
+    gpu.Profiler.reset()
+    gpu.Profiler.enable(True)
+    for _ in range(detail_steps):
+        step()
+    gpu.synchronize()
+    gpu.Profiler.enable(False)
 
     # ---- roofline of the dominant kernel ----------------------------------------------------------
     cbytes = class_bytes_per_iteration(Cui, Ciu, FACTORS)
@@ -266,26 +279,36 @@ def main():
         ms = sum(kernels.get(k, {"total_ms": 0})["total_ms"] for k in knames)
         launches = sum(kernels.get(k, {"launches": 0})["launches"] for k in knames)
         if ms > 0:
-            classes[cname] = {"ms_per_step": ms / args.steps, "launches_per_step": launches / args.steps,
+            classes[cname] = {"ms_per_step": ms / detail_steps, "launches_per_step": launches / detail_steps,
                               "algorithmic_GB_per_step": cbytes[cname] / 1e9,
-                              "achieved_GBps": cbytes[cname] * args.steps / (ms * 1e-3) / 1e9}
+                              "achieved_GBps": cbytes[cname] * detail_steps / (ms * 1e-3) / 1e9}
     roofline = None
     if classes:
-        dom = max(classes, key=lambda c: classes[c]["ms_per_step"])
-        d = classes[dom]
-        sweeps = 2 * args.steps  # the class runs once per half sweep (mid: one launch per team width)
-        total_ms = d["ms_per_step"] * args.steps
+        # timed-region measurement when the filter covered the class, else the detail pass
+        dom = "mid" if timed_filter and "mid" in classes else max(classes, key=lambda c: classes[c]["ms_per_step"])
+        live = {k: timed[k] for k in CLASS_KERNELS[dom] if k in timed and timed[k][1] > 0}
+        if live:
+            total_ms, n_steps = sum(v[0] for v in live.values()), args.steps
+            first_launches = live.get(CLASS_KERNELS[dom][0], next(iter(live.values())))[1]
+            source = "HIP events inside the timed region"
+        else:
+            total_ms, n_steps = classes[dom]["ms_per_step"] * detail_steps, detail_steps
+            first_launches = kernels[CLASS_KERNELS[dom][0]]["launches"]
+            source = "HIP events, separate pass after the timed region"
+        sweeps = 2 * n_steps  # the class runs once per half sweep (mid: one launch per team width)
         bytes_per_sweep = cbytes[dom] / 2.0
+        achieved = bytes_per_sweep * sweeps / (total_ms * 1e-3) / 1e9
         traffic, traffic_src = (None, None)
         if (args.shape, args.scale, args.solver, FACTORS) == ("lastfm360k", 1.0, "cg", 128):
             traffic, traffic_src = pmc_traffic_per_half_sweep(CG_STEPS)
         roofline = {"bound": "hbm", "kernel": "+".join(CLASS_KERNELS[dom]), "row_class": dom,
-                    "achieved": d["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": d["achieved_GBps"] / HBM_PEAK_GBS,
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic.get(dom) if traffic else None, "traffic_source": traffic_src,
-                    "avg_launch_ms": total_ms / max(1, kernels[CLASS_KERNELS[dom][0]]["launches"]),
+                    "avg_launch_ms": total_ms / max(1, first_launches),
                     "avg_ms_per_half_sweep": total_ms / sweeps,
                     "algorithmic_bytes_per_half_sweep": bytes_per_sweep,
+                    "timing_source": source,
                     "note": "achieved = algorithmic bytes of this row class per half sweep / HIP-event time of its "
                             "launch(es) in that half sweep; whole-iteration figure in `iteration_roofline`"}
     total_bytes = sum(cbytes.values())
@@ -317,7 +340,8 @@ def main():
         "roofline": roofline,
         "iteration_roofline": iteration_roofline,
         "row_classes": classes,
-        "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in kernels.items()},
+        "kernels_ms_per_step": {k: v["total_ms"] / detail_steps for k, v in kernels.items()},
+        "kernels_note": f"per-kernel HIP-event times from {detail_steps} extra iterations after the timed region",
         "setup_s": {"generate": t_gen, "upload": t_upload},
     }
 

@@ -50,6 +50,7 @@ struct ProfPending {
   hipEvent_t start, stop;
 };
 static bool g_prof_on = false;
+static std::string g_prof_filter;
 static std::map<std::string, ProfEntry> g_prof;
 static std::vector<ProfPending> g_prof_pending;
 static std::vector<hipEvent_t> g_event_pool;
@@ -69,6 +70,7 @@ static hipEvent_t get_event() {
 
 ProfScope::ProfScope(const char *n) : name(n) {
   if (!g_prof_on) return;
+  if (!g_prof_filter.empty() && !strstr(n, g_prof_filter.c_str())) return;
   start = get_event();
   stop = get_event();
   IMP_CHECK_HIP(hipEventRecord(start, stream()));
@@ -578,6 +580,12 @@ int imp_prof_enable(int on) {
   return guarded([&] {
     prof_flush();
     g_prof_on = on != 0;
+  });
+}
+int imp_prof_filter(const char *substr) {
+  return guarded([&] {
+    prof_flush();
+    g_prof_filter = substr ? substr : "";
   });
 }
 int imp_prof_reset(void) {

@@ -362,7 +362,9 @@ class Profiler:
     """Per-kernel HIP-event timing on the library stream (imp_prof_*), for bench.py's roofline leg."""
 
     @staticmethod
-    def enable(on=True):
+    def enable(on=True, only=None):
+        """`only`: time just the kernels whose name contains this substring (an event pair costs stream time)."""
+        check(lib().imp_prof_filter((only or "").encode()))
         check(lib().imp_prof_enable(1 if on else 0))
 
     @staticmethod

@@ -71,6 +71,7 @@ _SIGNATURES = {
     "imp_comm_allgather_rows": [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)],
     "imp_comm_barrier": [ctypes.c_void_p],
     "imp_prof_enable": [ctypes.c_int],
+    "imp_prof_filter": [ctypes.c_char_p],
     "imp_prof_reset": [],
     "imp_prof_get": [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)],
     "imp_prof_names": [ctypes.c_char_p, ctypes.c_size_t],

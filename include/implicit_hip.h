@@ -157,6 +157,9 @@ int imp_comm_barrier(imp_comm *c);
 /* When enabled every kernel launch is bracketed by HIP events on the library stream; totals are
  * accumulated per kernel name.  imp_prof_get returns 0 launches for unknown names. */
 int imp_prof_enable(int on);
+/* Restrict the event pairs to kernels whose name contains `substr` (NULL or "" = every kernel): an event pair costs a few
+ * microseconds of stream time, so a timed region that only needs one kernel family should not pay for all of them. */
+int imp_prof_filter(const char *substr);
 int imp_prof_reset(void);
 int imp_prof_get(const char *kernel, double *total_ms, int64_t *launches);
 /* '\n'-separated list of kernel names seen so far, copied into buf (truncated to buflen). */
