@@ -206,7 +206,21 @@ def main():
     if world > 1 or os.environ.get("IMP_FORCE_SHARDED"):  # the env knob exercises the N>1 code path with one rank
         from implicit_amd.gpu import sharded
 
-        result = sharded.bench(args, gpu, users, items, nnz_target, gamma, FACTORS, REG, CG_STEPS)
+        def rank0_roofline(Cui, Ciu, timed, steps):
+            """Same definition as the single-GPU line, on rank 0's shard: algorithmic bytes of its mid-row class per
+            half sweep / HIP-event time of the team kernels in the timed region."""
+            live = {k: v for k, v in timed.items() if k in CLASS_KERNELS["mid"] and v[1] > 0}
+            if not live:
+                return None
+            total_ms = sum(v[0] for v in live.values())
+            per_sweep = class_bytes_per_iteration(Cui, Ciu, FACTORS)["mid"] / 2.0
+            achieved = per_sweep * 2 * steps / (total_ms * 1e-3) / 1e9
+            return {"bound": "hbm", "kernel": "+".join(CLASS_KERNELS["mid"]), "row_class": "mid", "achieved": achieved,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "avg_ms_per_half_sweep": total_ms / (2 * steps), "algorithmic_bytes_per_half_sweep": per_sweep,
+                    "timing_source": "HIP events inside the timed region, rank 0"}
+
+        result = sharded.bench(args, gpu, users, items, nnz_target, gamma, FACTORS, REG, CG_STEPS, rank0_roofline)
         if rank == 0:
             print(json.dumps(result))
         return

@@ -106,7 +106,7 @@ def weak_scaling_shards(rank, nranks, users, items, nnz, gamma, seed=42):
     return mine, item_rows, total_nnz
 
 
-def bench(args, gpu, users, items, nnz_target, gamma, factors, reg, cg_steps):
+def bench(args, gpu, users, items, nnz_target, gamma, factors, reg, cg_steps, roofline_fn=None):
     """Weak-scaling benchmark body for WORLD_SIZE > 1 (launched by torch.distributed.run).  torch is
     used ONLY for rendezvous (RCCL unique id), the barrier around the timed region and the max over
     ranks; the data path is RCCL inside libimplicit_hip.so."""
@@ -150,8 +150,10 @@ def bench(args, gpu, users, items, nnz_target, gamma, factors, reg, cg_steps):
     for _ in range(args.warmup):
         step()
     fence()
-    gpu.Profiler.enable(True)
+    # event pairs only for the dominant kernel family inside the timed region (they cost stream time), as in bench.py
+    timed_filter = "als_cg_team" if factors in (64, 128) else None
     gpu.Profiler.reset()
+    gpu.Profiler.enable(True, only=timed_filter)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -188,7 +190,8 @@ def bench(args, gpu, users, items, nnz_target, gamma, factors, reg, cg_steps):
             "parallelism": f"row-sharded x{world}, RCCL all-reduce(f x f) + all-gather(factor shards)",
         },
         "nnz_visits_per_s": 2 * int(total_nnz) / step_s,
-        "roofline": None,
+        "roofline": roofline_fn(Cui, Ciu, {k: gpu.Profiler.get(k) for k in gpu.Profiler.names()}, args.steps)
+        if (roofline_fn and rank == 0) else None,
         "kernels_ms_per_step_rank0": kernels,
         "setup_s": {"generate": t_gen},
     }
