@@ -20,6 +20,11 @@
 struct imp_comm {
   ncclComm_t comm = nullptr;
   int nranks = 1, rank = 0;
+  // pipelined exchange (allgather_rows_begin / _end): collectives are queued on their own stream behind an event of
+  // the compute stream, so the solve of the next row chunk overlaps the broadcast of the previous one
+  hipStream_t xchg_stream = nullptr;
+  hipEvent_t solved = nullptr, exchanged = nullptr;
+  bool pending = false;
 };
 
 using namespace imp;
@@ -47,13 +52,20 @@ int imp_comm_init_rank(const void *id_bytes, int nranks, int rank, imp_comm **ou
     ncclUniqueId id;
     std::memcpy(&id, id_bytes, sizeof(id));
     IMP_CHECK_NCCL(ncclCommInitRank(&c->comm, nranks, id, rank));
+    IMP_CHECK_HIP(hipStreamCreateWithFlags(&c->xchg_stream, hipStreamNonBlocking));
+    IMP_CHECK_HIP(hipEventCreateWithFlags(&c->solved, hipEventDisableTiming));
+    IMP_CHECK_HIP(hipEventCreateWithFlags(&c->exchanged, hipEventDisableTiming));
     *out = c.release();
   });
 }
 
 int imp_comm_destroy(imp_comm *c) {
   return guarded([&] {
+    if (c && c->xchg_stream) (void)hipStreamSynchronize(c->xchg_stream);
     if (c && c->comm) (void)ncclCommDestroy(c->comm);
+    if (c && c->solved) (void)hipEventDestroy(c->solved);
+    if (c && c->exchanged) (void)hipEventDestroy(c->exchanged);
+    if (c && c->xchg_stream) (void)hipStreamDestroy(c->xchg_stream);
     delete c;
   });
 }
@@ -83,6 +95,38 @@ int imp_comm_allgather_rows(imp_comm *c, imp_matrix *full, const int64_t *row_of
     }
     IMP_CHECK_NCCL(ncclGroupEnd());
     sync();
+  });
+}
+
+// Rows [row_lo[r], row_hi[r]) of `full` are owned by rank r.  Everything the library stream has queued so far (the
+// solve that produced this rank's rows) is ordered before the exchange; the call returns without waiting.
+int imp_comm_allgather_rows_begin(imp_comm *c, imp_matrix *full, const int64_t *row_lo, const int64_t *row_hi) {
+  return guarded([&] {
+    const size_t row_bytes = full->cols * full->itemsize;
+    for (int r = 0; r < c->nranks; ++r)
+      if (row_lo[r] < 0 || row_hi[r] < row_lo[r] || (size_t)row_hi[r] > full->rows)
+        throw std::invalid_argument("row range outside the matrix in allgather_rows_begin");
+    IMP_CHECK_HIP(hipEventRecord(c->solved, stream()));
+    IMP_CHECK_HIP(hipStreamWaitEvent(c->xchg_stream, c->solved, 0));
+    IMP_CHECK_NCCL(ncclGroupStart());
+    for (int r = 0; r < c->nranks; ++r) {
+      size_t bytes = (size_t)(row_hi[r] - row_lo[r]) * row_bytes;
+      if (!bytes) continue;
+      char *p = reinterpret_cast<char *>(full->data) + (size_t)row_lo[r] * row_bytes;
+      IMP_CHECK_NCCL(ncclBroadcast(p, p, bytes, ncclChar, r, c->comm, c->xchg_stream));
+    }
+    IMP_CHECK_NCCL(ncclGroupEnd());
+    c->pending = true;
+  });
+}
+
+// Orders everything queued by _begin before whatever the library stream runs next (no host wait).
+int imp_comm_allgather_rows_end(imp_comm *c) {
+  return guarded([&] {
+    if (!c->pending) return;
+    IMP_CHECK_HIP(hipEventRecord(c->exchanged, c->xchg_stream));
+    IMP_CHECK_HIP(hipStreamWaitEvent(stream(), c->exchanged, 0));
+    c->pending = false;
   });
 }
 

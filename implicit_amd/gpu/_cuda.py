@@ -341,6 +341,16 @@ class Comm:
         offs = (ctypes.c_int64 * (self.nranks + 1))(*[int(o) for o in row_offsets])
         check(lib().imp_comm_allgather_rows(self._h, full._h, offs))
 
+    def allgather_rows_begin(self, full, row_lo, row_hi):
+        """Queue the exchange of rows [row_lo[r], row_hi[r]) (owner: rank r) behind the work queued so far; returns
+        immediately.  Pair with allgather_rows_end()."""
+        lo = (ctypes.c_int64 * self.nranks)(*[int(o) for o in row_lo])
+        hi = (ctypes.c_int64 * self.nranks)(*[int(o) for o in row_hi])
+        check(lib().imp_comm_allgather_rows_begin(self._h, full._h, lo, hi))
+
+    def allgather_rows_end(self):
+        check(lib().imp_comm_allgather_rows_end(self._h))
+
     def barrier(self):
         check(lib().imp_comm_barrier(self._h))
 

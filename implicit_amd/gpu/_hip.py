@@ -69,6 +69,9 @@ _SIGNATURES = {
     "imp_comm_destroy": [ctypes.c_void_p],
     "imp_comm_allreduce_sum": [ctypes.c_void_p, ctypes.c_void_p],
     "imp_comm_allgather_rows": [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)],
+    "imp_comm_allgather_rows_begin": [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64),
+                                      ctypes.POINTER(ctypes.c_int64)],
+    "imp_comm_allgather_rows_end": [ctypes.c_void_p],
     "imp_comm_barrier": [ctypes.c_void_p],
     "imp_prof_enable": [ctypes.c_int],
     "imp_prof_filter": [ctypes.c_char_p],

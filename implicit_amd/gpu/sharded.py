@@ -19,6 +19,7 @@ order, views) is exercised on CPU by tests/test_sharded_gloo.py with a gloo comm
 oracle as the per-shard solver:
 
   comm    : .nranks .rank .allreduce_sum(M) .allgather_rows(M, row_offsets) .barrier()
+            .allgather_rows_begin(M, row_lo, row_hi) .allgather_rows_end()   (pipelined form)
   backend : .calculate_yty(F_rows, gram, reg) .least_squares(C, X_rows, gram, Y, cg_steps)
             .rows(M, start, stop) -> view sharing storage
 """
@@ -59,16 +60,43 @@ class GpuBackend:
         return M[int(start):int(stop)]
 
 
+def chunk_offsets(offsets, chunks):
+    """Cut every rank's row range [offsets[r], offsets[r+1]) into `chunks` pieces by row count; every rank computes
+    the same (nranks, chunks+1) table, which is what keeps the grouped broadcasts of a chunk matched across ranks."""
+    offsets = np.asarray(offsets, dtype=np.int64)
+    lens = np.diff(offsets)
+    k = np.arange(chunks + 1, dtype=np.int64)
+    return offsets[:-1, None] + (lens[:, None] * k[None, :]) // chunks
+
+
+def split_rows(C_shard, chunks):
+    """This rank's CSR rows cut the same way (scipy CSR in, list of scipy CSR out)."""
+    cuts = chunk_offsets([0, C_shard.shape[0]], chunks)[0]
+    return [C_shard[int(cuts[k]):int(cuts[k + 1])] for k in range(chunks)]
+
+
 def half_sweep(backend, comm, C_shard, X_full, x_offsets, Y_full, y_offsets, gram, reg, cg_steps):
-    """Solve this rank's rows of X given the replica of Y; leaves every rank with the full new X."""
+    """Solve this rank's rows of X given the replica of Y; leaves every rank with the full new X.
+
+    `C_shard` is either one CSR handle (solve, then one blocking all-gather) or a list of K handles for the row
+    chunks of `split_rows`: chunk k's freshly solved rows are queued for exchange (RCCL on a second stream) while
+    chunk k+1 is being solved; the half sweep ends by ordering all exchanges before the next kernels."""
     r = comm.rank
     y_mine = backend.rows(Y_full, y_offsets[r], y_offsets[r + 1])
     # regularisation is added exactly once across the ranks
     backend.calculate_yty(y_mine, gram, reg if r == 0 else 0.0)
     comm.allreduce_sum(gram)
-    x_mine = backend.rows(X_full, x_offsets[r], x_offsets[r + 1])
-    backend.least_squares(C_shard, x_mine, gram, Y_full, cg_steps)
-    comm.allgather_rows(X_full, x_offsets)
+    if not isinstance(C_shard, (list, tuple)):
+        x_mine = backend.rows(X_full, x_offsets[r], x_offsets[r + 1])
+        backend.least_squares(C_shard, x_mine, gram, Y_full, cg_steps)
+        comm.allgather_rows(X_full, x_offsets)
+        return
+    cuts = chunk_offsets(x_offsets, len(C_shard))
+    for k, C_k in enumerate(C_shard):
+        x_k = backend.rows(X_full, cuts[r, k], cuts[r, k + 1])
+        backend.least_squares(C_k, x_k, gram, Y_full, cg_steps)
+        comm.allgather_rows_begin(X_full, cuts[:, k], cuts[:, k + 1])
+    comm.allgather_rows_end()
 
 
 def iteration(backend, comm, Cui_shard, Ciu_shard, X_full, Y_full, u_offsets, i_offsets, gram, reg, cg_steps):
@@ -133,7 +161,14 @@ def bench(args, gpu, users, items, nnz_target, gamma, factors, reg, cg_steps, ro
     t_gen = time.time() - t0
 
     backend = GpuBackend(gpu)
-    Cui_d, Ciu_d = gpu.CSRMatrix(Cui), gpu.CSRMatrix(Ciu)
+    # K row chunks per half sweep: chunk k is exchanged over xGMI while chunk k+1 is solved (one chunk = blocking form)
+    pipelined = world > 1 or os.environ.get("IMP_FORCE_SHARDED")
+    chunks = max(1, int(os.environ.get("IMP_SHARD_CHUNKS", "4"))) if pipelined else 1
+    if chunks > 1:
+        Cui_d = [gpu.CSRMatrix(c) for c in split_rows(Cui, chunks)]
+        Ciu_d = [gpu.CSRMatrix(c) for c in split_rows(Ciu, chunks)]
+    else:
+        Cui_d, Ciu_d = gpu.CSRMatrix(Cui), gpu.CSRMatrix(Ciu)
     X, Y = gpu.Matrix(X0), gpu.Matrix(Y0)
     del X0, Y0
     gram = gpu.Matrix.zeros(factors, factors)
@@ -187,7 +222,8 @@ def bench(args, gpu, users, items, nnz_target, gamma, factors, reg, cg_steps, ro
                         f"global {world * users} users x {world * items} items, ALS CG cg_steps={cg_steps}",
             "users": world * users, "items": world * items, "nnz": int(total_nnz), "factors": factors,
             "regularization": reg, "solver": "cg", "cg_steps": cg_steps,
-            "parallelism": f"row-sharded x{world}, RCCL all-reduce(f x f) + all-gather(factor shards)",
+            "parallelism": f"row-sharded x{world}, RCCL all-reduce(f x f) + all-gather(factor shards) pipelined in "
+                           f"{chunks} row chunk(s) per half sweep",
         },
         "nnz_visits_per_s": 2 * int(total_nnz) / step_s,
         "roofline": roofline_fn(Cui, Ciu, {k: gpu.Profiler.get(k) for k in gpu.Profiler.names()}, args.steps)

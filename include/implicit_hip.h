@@ -151,6 +151,12 @@ int imp_comm_allreduce_sum(imp_comm *c, imp_matrix *m);
 /* all-gather of row shards: rank r contributes rows [row_offsets[r], row_offsets[r+1]) of `full`
  * (already in place in its own copy); afterwards every rank holds all rows. */
 int imp_comm_allgather_rows(imp_comm *c, imp_matrix *full, const int64_t *row_offsets);
+/* Pipelined form of the all-gather: rows [row_lo[r], row_hi[r]) are owned by rank r (nranks entries each).  _begin
+ * queues the exchange on a second stream behind the work already queued on the library stream and returns; _end makes
+ * the library stream wait for all exchanges queued since (no host wait).  A half sweep solved in K row chunks calls
+ * _begin after each chunk and _end once, so chunk k travels over xGMI while chunk k+1 is being solved. */
+int imp_comm_allgather_rows_begin(imp_comm *c, imp_matrix *full, const int64_t *row_lo, const int64_t *row_hi);
+int imp_comm_allgather_rows_end(imp_comm *c);
 int imp_comm_barrier(imp_comm *c);
 
 /* ---- NEW: measurement hooks (bench.py's roofline leg) -------------------------------------------- */

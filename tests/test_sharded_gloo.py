@@ -46,11 +46,19 @@ class GlooComm:
             part = self.torch.from_numpy(M[int(offs[r]):int(offs[r + 1])])
             self.dist.broadcast(part, src=r)
 
+    def allgather_rows_begin(self, M, lo, hi):  # the pipelined form, executed eagerly here
+        for r in range(self.nranks):
+            part = self.torch.from_numpy(M[int(lo[r]):int(hi[r])])
+            self.dist.broadcast(part, src=r)
+
+    def allgather_rows_end(self):
+        pass
+
     def barrier(self):
         self.dist.barrier()
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, chunks):
     sys.path.insert(0, ROOT)
     os.environ.setdefault("OPENBLAS_NUM_THREADS", "4")
     import torch
@@ -72,6 +80,8 @@ def _worker(rank, world, port, out_dir):
     Y = rng.random((400, f), dtype=np.float32) * 0.1 - 0.05
     Cui_shard = C[u_off[rank]:u_off[rank + 1]]
     Ciu_shard = Ct[i_off[rank]:i_off[rank + 1]]
+    if chunks > 1:  # pipelined exchange: K row chunks per half sweep
+        Cui_shard, Ciu_shard = sharded.split_rows(Cui_shard, chunks), sharded.split_rows(Ciu_shard, chunks)
     gram = np.zeros((f, f), dtype=np.float32)
     comm = GlooComm(dist, torch)
     backend = NumpyBackend(oracle)
@@ -90,13 +100,14 @@ def _free_port():
     return port
 
 
-def test_two_rank_gloo_matches_single_process(tmp_path, oracle):
+@pytest.mark.parametrize("chunks", [1, 3])
+def test_two_rank_gloo_matches_single_process(tmp_path, oracle, chunks):
     import torch.multiprocessing as mp
 
     from implicit_amd.synthetic import synthetic_csr
 
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), chunks), nprocs=world, join=True)
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     np.testing.assert_array_equal(r0["X"], r1["X"])  # replicas identical bit for bit
     np.testing.assert_array_equal(r0["Y"], r1["Y"])
@@ -109,6 +120,17 @@ def test_two_rank_gloo_matches_single_process(tmp_path, oracle):
     Xs, Ys = oracle.fit(C, 32, regularization=0.05, iterations=3, user_factors=X, item_factors=Y)
     rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)  # noqa: E731
     assert rel(r0["X"], Xs) < 1e-5 and rel(r0["Y"], Ys) < 1e-5
+
+
+def test_chunk_offsets_cover_every_shard():
+    from implicit_amd.gpu.sharded import chunk_offsets
+
+    offs = np.array([0, 10, 10, 25], dtype=np.int64)  # an empty shard in the middle
+    cuts = chunk_offsets(offs, 4)
+    assert cuts.shape == (3, 5)
+    assert (cuts[:, 0] == offs[:-1]).all() and (cuts[:, -1] == offs[1:]).all()
+    assert (np.diff(cuts, axis=1) >= 0).all()
+    assert list(cuts[2]) == [10, 13, 17, 21, 25]
 
 
 def test_shard_offsets_balance_by_weight():
