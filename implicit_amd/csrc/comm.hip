@@ -21,7 +21,7 @@ struct imp_comm {
   ncclComm_t comm = nullptr;
   int nranks = 1, rank = 0;
   // pipelined exchange (allgather_rows_begin / _end): collectives are queued on their own stream behind an event of
-  // the compute stream, so the solve of the next row chunk overlaps the broadcast of the previous one
+  // the compute stream, so the solve of the next row chunk overlaps the exchange of the previous one
   hipStream_t xchg_stream = nullptr;
   hipEvent_t solved = nullptr, exchanged = nullptr;
   bool pending = false;
@@ -70,6 +70,24 @@ int imp_comm_destroy(imp_comm *c) {
   });
 }
 
+// All-gather of ragged row ranges as ONE group of point-to-point transfers: this rank's rows go to every peer and
+// every peer's rows come in.  xGMI is a full mesh of point-to-point links (7 per GPU), so the direct exchange puts each
+// shard on each link exactly once and all links work at the same time -- a ring would pipe every shard through the
+// neighbours' links instead.
+static void exchange_rows(imp_comm *c, imp_matrix *full, const int64_t *row_lo, const int64_t *row_hi, hipStream_t on) {
+  const size_t row_bytes = full->cols * full->itemsize;
+  char *base = reinterpret_cast<char *>(full->data);
+  const size_t mine = (size_t)(row_hi[c->rank] - row_lo[c->rank]) * row_bytes;
+  IMP_CHECK_NCCL(ncclGroupStart());
+  for (int peer = 0; peer < c->nranks; ++peer) {
+    if (peer == c->rank) continue;
+    const size_t theirs = (size_t)(row_hi[peer] - row_lo[peer]) * row_bytes;
+    if (mine) IMP_CHECK_NCCL(ncclSend(base + (size_t)row_lo[c->rank] * row_bytes, mine, ncclChar, peer, c->comm, on));
+    if (theirs) IMP_CHECK_NCCL(ncclRecv(base + (size_t)row_lo[peer] * row_bytes, theirs, ncclChar, peer, c->comm, on));
+  }
+  IMP_CHECK_NCCL(ncclGroupEnd());
+}
+
 int imp_comm_allreduce_sum(imp_comm *c, imp_matrix *m) {
   return guarded([&] {
     if (m->itemsize != 4) throw std::invalid_argument("allreduce_sum needs a float32 matrix");
@@ -84,16 +102,7 @@ int imp_comm_allgather_rows(imp_comm *c, imp_matrix *full, const int64_t *row_of
     if (row_offsets[0] != 0 || (size_t)row_offsets[c->nranks] != full->rows)
       throw std::invalid_argument("row_offsets must span [0, rows] for allgather_rows");
     IMP_PROF("rccl_allgather_rows");
-    // shards may be ragged: grouped broadcasts, one per owning rank (RCCL fuses the group)
-    const size_t row_bytes = full->cols * full->itemsize;
-    IMP_CHECK_NCCL(ncclGroupStart());
-    for (int r = 0; r < c->nranks; ++r) {
-      size_t bytes = (size_t)(row_offsets[r + 1] - row_offsets[r]) * row_bytes;
-      if (!bytes) continue;
-      char *p = reinterpret_cast<char *>(full->data) + (size_t)row_offsets[r] * row_bytes;
-      IMP_CHECK_NCCL(ncclBroadcast(p, p, bytes, ncclChar, r, c->comm, stream()));
-    }
-    IMP_CHECK_NCCL(ncclGroupEnd());
+    exchange_rows(c, full, row_offsets, row_offsets + 1, stream());  // shards may be ragged
     sync();
   });
 }
@@ -102,20 +111,12 @@ int imp_comm_allgather_rows(imp_comm *c, imp_matrix *full, const int64_t *row_of
 // solve that produced this rank's rows) is ordered before the exchange; the call returns without waiting.
 int imp_comm_allgather_rows_begin(imp_comm *c, imp_matrix *full, const int64_t *row_lo, const int64_t *row_hi) {
   return guarded([&] {
-    const size_t row_bytes = full->cols * full->itemsize;
     for (int r = 0; r < c->nranks; ++r)
       if (row_lo[r] < 0 || row_hi[r] < row_lo[r] || (size_t)row_hi[r] > full->rows)
         throw std::invalid_argument("row range outside the matrix in allgather_rows_begin");
     IMP_CHECK_HIP(hipEventRecord(c->solved, stream()));
     IMP_CHECK_HIP(hipStreamWaitEvent(c->xchg_stream, c->solved, 0));
-    IMP_CHECK_NCCL(ncclGroupStart());
-    for (int r = 0; r < c->nranks; ++r) {
-      size_t bytes = (size_t)(row_hi[r] - row_lo[r]) * row_bytes;
-      if (!bytes) continue;
-      char *p = reinterpret_cast<char *>(full->data) + (size_t)row_lo[r] * row_bytes;
-      IMP_CHECK_NCCL(ncclBroadcast(p, p, bytes, ncclChar, r, c->comm, c->xchg_stream));
-    }
-    IMP_CHECK_NCCL(ncclGroupEnd());
+    exchange_rows(c, full, row_lo, row_hi, c->xchg_stream);
     c->pending = true;
   });
 }

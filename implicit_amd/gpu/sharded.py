@@ -62,7 +62,7 @@ class GpuBackend:
 
 def chunk_offsets(offsets, chunks):
     """Cut every rank's row range [offsets[r], offsets[r+1]) into `chunks` pieces by row count; every rank computes
-    the same (nranks, chunks+1) table, which is what keeps the grouped broadcasts of a chunk matched across ranks."""
+    the same (nranks, chunks+1) table, which is what keeps the grouped send/recv of a chunk matched across ranks."""
     offsets = np.asarray(offsets, dtype=np.int64)
     lens = np.diff(offsets)
     k = np.arange(chunks + 1, dtype=np.int64)
