@@ -287,14 +287,17 @@ __global__ __launch_bounds__(256) void score_gemm_direct_kernel(const float *__r
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-#pragma unroll 2
-  for (int k0 = 0; k0 < f; k0 += 8) {
-    float4 a[2], b[2];
+  // 8 factors per step; the operands of step s + 1 are requested before the 16 MFMAs of step s (two register sets), so
+  // the L2 round trip of a step hides under the matrix work of the previous one
+  float4 a0[2], b0[2], a1[2], b1[2];
+  auto fetch = [&](float4 (&a)[2], float4 (&b)[2], int k0) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       a[t] = *reinterpret_cast<const float4 *>(qp[t] + k0);
       b[t] = *reinterpret_cast<const float4 *>(ip[t] + k0);
     }
+  };
+  auto multiply = [&](const float4 (&a)[2], const float4 (&b)[2]) {
 #pragma unroll
     for (int tq = 0; tq < 2; ++tq)
 #pragma unroll
@@ -304,7 +307,17 @@ __global__ __launch_bounds__(256) void score_gemm_direct_kernel(const float *__r
         acc[tq][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tq].z, b[ti].z, acc[tq][ti], 0, 0, 0);
         acc[tq][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tq].w, b[ti].w, acc[tq][ti], 0, 0, 0);
       }
+  };
+  const int steps = f / 8;
+  fetch(a0, b0, 0);
+  int s = 0;
+  for (; s + 2 <= steps; s += 2) {
+    fetch(a1, b1, 8 * (s + 1));
+    multiply(a0, b0);
+    fetch(a0, b0, 8 * min(s + 2, steps - 1));  // past the end: re-reads the last step, unused
+    multiply(a1, b1);
   }
+  if (s < steps) multiply(a0, b0);
   // C/D layout: column (item) = lane & 31, row (query) = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
   float nrm[2];
 #pragma unroll
@@ -313,6 +326,25 @@ __global__ __launch_bounds__(256) void score_gemm_direct_kernel(const float *__r
     nrm[ti] = (norms && item < ni) ? norms[item] : 1.f;
   }
   const int tile = i_base / kTileItems;
+  if (q_base + 64 <= nq && i_base + 64 <= ni) {
+    // interior tile (wave-uniform): no per-element guards, so the 64 stores of a lane are queued back to back
+#pragma unroll
+    for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int q = q_base + 32 * tq + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        float sc0 = acc[tq][0][e], sc1 = acc[tq][1][e];
+        if (norms) sc0 = sc0 / nrm[0], sc1 = sc1 / nrm[1];
+        float *row = S + (size_t)q * ni + i_base + r;
+        row[0] = sc0;
+        row[32] = sc1;
+        float m = fmaxf(sc0, sc1);
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        if (r == 0) tile_max[(size_t)q * n_tiles + tile] = m;
+      }
+    return;
+  }
 #pragma unroll
   for (int tq = 0; tq < 2; ++tq)
 #pragma unroll
