@@ -398,13 +398,6 @@ __global__ void coo_filter_refresh_kernel(const float *__restrict__ S, float *__
   }
 }
 
-__global__ void coo_count_kernel(const int32_t *__restrict__ row, size_t nnz, int start, int end, int *__restrict__ counts) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nnz; i += (size_t)gridDim.x * blockDim.x) {
-    int r = row[i];
-    if (r >= start && r < end) atomicAdd(&counts[r - start], 1);
-  }
-}
-
 // Pruned select: tau = the k-th largest tile maximum (maxima refreshed after the filters) is a lower bound of the k-th
 // best surviving score: k distinct tiles each hold a surviving score >= tau.
 // ONE pass over the row collects every score >= tau (a few hundred) into LDS, a bitonic sort orders them and the best
