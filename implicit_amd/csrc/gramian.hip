@@ -36,26 +36,53 @@ __global__ __launch_bounds__(256) void gramian_partial_kernel(const float *__res
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
   if (ti < n_tiles) {
-    const bool a_ok = i_col < f;
-    for (long r0 = r_begin; r0 < r_end; r0 += 8) {
-      // 4 k-steps (8 rows) per trip so that 4*(1+TJ) loads are in flight
-      float a[4], b[4][TJ];
+    // 4 k-steps (8 rows) per trip, two register sets: the 4 (1 + TJ) loads of trip t + 1 are in flight during the MFMAs
+    // of trip t.  Everything is branch-free -- out-of-range rows / columns load a clamped address and are zeroed by an
+    // AND with an all-ones / all-zeros word, applied only when the operand is consumed: a select is turned back into a
+    // guarded load (and branches make the compiler drain vmcnt to 0 at every join), an AND right after the load would
+    // wait for the load it is supposed to hide.
+    const int ca = min(i_col, f - 1), mask_a = -(int)(i_col < f);
+    int cb[TJ], mask_b[TJ];
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) {
+      const int c = 32 * (tj0 + t) + (lane & 31);
+      mask_b[t] = -(int)(c < f);
+      cb[t] = min(c, f - 1);
+    }
+    float a[2][4], b[2][4][TJ];
+    int mask_r[2][4];
+    auto fetch = [&](int buf, long r0) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        long r = r0 + 2 * s + khalf;
-        bool r_ok = r < r_end;
-        const float *row = Y + r * (long)f;
-        a[s] = (r_ok && a_ok) ? row[i_col] : 0.f;
+        const long r = r0 + 2 * s + khalf;
+        mask_r[buf][s] = -(int)(r < r_end);
+        const float *row = Y + min(r, n_rows - 1) * (long)f;
+        a[buf][s] = row[ca];
 #pragma unroll
-        for (int t = 0; t < TJ; ++t) {
-          int c = 32 * (tj0 + t) + (lane & 31);
-          b[s][t] = (r_ok && c < f) ? row[c] : 0.f;
-        }
+        for (int t = 0; t < TJ; ++t) b[buf][s][t] = row[cb[t]];
       }
+    };
+    auto masked = [](float v, int m) { return __int_as_float(__float_as_int(v) & m); };
+    auto multiply = [&](int buf) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+      for (int s = 0; s < 4; ++s) {
+        const float av = masked(a[buf][s], mask_r[buf][s] & mask_a);
 #pragma unroll
-        for (int t = 0; t < TJ; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s][t], acc[t], 0, 0, 0);
+        for (int t = 0; t < TJ; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, masked(b[buf][s][t], mask_r[buf][s] & mask_b[t]), acc[t], 0, 0, 0);
+      }
+    };
+    fetch(0, r_begin);
+    for (long r0 = r_begin; r0 < r_end; r0 += 16) {
+      // the scheduling fences keep the machine scheduler from sinking the loads back down to their uses
+      fetch(1, r0 + 8);  // rows past r_end read the last row and are masked to zero
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(0);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(0, r0 + 16);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(1);
+      __builtin_amdgcn_sched_barrier(0);
     }
     // C/D layout of the 32x32 tile: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
     float *out = ws + (size_t)blockIdx.x * f * f;
