@@ -78,28 +78,28 @@ __global__ __launch_bounds__(1024) void als_cg_qgroup_kernel(const int32_t *__re
   __syncthreads();
 
   const int groups = (count + 15) / 16;
-  // two groups deep, as in the team kernel below: entries (column, confidence) of the next group's row in flight during
-  // this group's passes, its metadata (schedule entry -> row id -> nnz range) read just before; rows past the end
-  // re-read the last row and are masked by `valid`
-  auto fetch_meta = [&](int g, int &u, int &rb, int &re) {
-    u = __builtin_amdgcn_readfirstlane(order[first + min(g * 16 + wave, count - 1)]);
-    rb = __builtin_amdgcn_readfirstlane(indptr[u]);
-    re = __builtin_amdgcn_readfirstlane(indptr[u + 1]);
-  };
-  int u_next, rb_next, re_next, col_next;
+  // groups past the end re-read the last row and are masked by `valid`
+  // schedule entry -> row id -> nnz range -> entries are four dependent loads; each stage runs one group further ahead
+  // than the next, so none of them is waited for when it is issued: row ids 3 groups ahead, nnz ranges 2, entries 1
+  auto row_id = [&](int g) { return order[first + min(g * 16 + wave, count - 1)]; };  // uniform address: scalar load
+  const int g_step = gridDim.x;
+  int u1 = row_id(blockIdx.x), u2 = row_id(blockIdx.x + g_step), u3 = row_id(blockIdx.x + 2 * g_step);
+  int rb1 = indptr[u1], re1 = indptr[u1 + 1], rb2 = indptr[u2], re2 = indptr[u2 + 1];
+  int col_next;
   float c_next;
-  fetch_meta(blockIdx.x, u_next, rb_next, re_next);
-  fetch_entries(indices, data, lane, rb_next, re_next, col_next, c_next);
-  for (int g = blockIdx.x; g < groups; g += gridDim.x) {
+  fetch_entries(indices, data, lane, rb1, re1, col_next, c_next);
+  for (int g = blockIdx.x; g < groups; g += g_step) {
     const bool valid = g * 16 + wave < count;
-    const int u = u_next, row_begin = rb_next, row_end = re_next;
+    const int u = u1, row_begin = rb1, row_end = re1;
+    u1 = u2, rb1 = rb2, re1 = re2;                    // group g + 1: complete
+    u2 = u3, rb2 = indptr[u2], re2 = indptr[u2 + 1];  // group g + 2: row id known -> its range
+    u3 = row_id(g + 3 * g_step);                      // group g + 3: row id
     float *xrow = X + (size_t)u * F;
     float x[FC], r[FC], p[FC], Ap[FC], sp[FC];
     load_compact<F>(xrow, lane, x);
     QTile<F> tile;
     load_qtile_staged<F>(tile, col_next, c_next, Y, lane, valid ? row_end - row_begin : 0);
-    fetch_meta(g + gridDim.x, u_next, rb_next, re_next);  // overlaps with the gathers above
-    fetch_entries(indices, data, lane, rb_next, re_next, col_next, c_next);
+    fetch_entries(indices, data, lane, rb1, re1, col_next, c_next);  // entries of group g + 1
 
     float ve[FE], ae[FE];
     // r = -(A0 x) + sum_k (c+ - (|c|-1) y.x) y        (_als.pyx:187-201)
@@ -242,22 +242,24 @@ __global__ __launch_bounds__(BLOCK, 4) void als_cg_qteam_kernel(const int32_t *_
     tick(4);
   };
 
-  // this team's rows: i = (blockIdx.x + k gridDim.x) TEAMS + team.  The pipeline runs two rows deep: while row i is
-  // solved, the entries (column, confidence) of row i + step are in flight and the metadata (schedule entry -> row
-  // id -> nnz range, two dependent loads) of row i + step has just been read.  Rows past the end re-read the last row.
-  auto fetch_meta = [&](int i, int &u, int &rb, int &re) {
-    u = __builtin_amdgcn_readfirstlane(order[first + min(i, count - 1)]);
-    rb = __builtin_amdgcn_readfirstlane(indptr[u]);
-    re = __builtin_amdgcn_readfirstlane(indptr[u + 1]);
-  };
-  const int i_step = gridDim.x * TEAMS;
-  int u_next, rb_next, re_next, col_next;
+  // this team's rows: i = (blockIdx.x + k gridDim.x) TEAMS + team; rows past the end re-read the last row
+  auto row_id = [&](int i) { return order[first + min(i, count - 1)]; };  // uniform address: scalar load
+  const int i_step = gridDim.x * TEAMS, i_first = blockIdx.x * TEAMS + team;
+  // four dependent loads per row (schedule entry -> row id -> nnz range -> entries), each stage one row further ahead
+  // than the next: row ids 3 rows ahead, nnz ranges 2, entries 1 -- nothing is waited for at the point of issue
+  int u1 = row_id(i_first), u2 = row_id(i_first + i_step), u3 = row_id(i_first + 2 * i_step);
+  int rb1 = indptr[u1], re1 = indptr[u1 + 1], rb2 = indptr[u2], re2 = indptr[u2 + 1];
+  int col_next;
   float c_next;
-  fetch_meta(blockIdx.x * TEAMS + team, u_next, rb_next, re_next);
-  fetch_entries(indices, data, lane, min(rb_next + T * sub, re_next), re_next, col_next, c_next);
-  for (int i = blockIdx.x * TEAMS + team; i < count; i += i_step) {
+  fetch_entries(indices, data, lane, min(rb1 + T * sub, re1), re1, col_next, c_next);
+  for (int i = i_first; i < count; i += i_step) {
     constexpr bool valid = true;
-    const int u = u_next, row_begin = rb_next, row_end = re_next;
+    const int u = u1, row_begin = rb1, row_end = re1;
+    // scalar stages first (they share lgkmcnt with the LDS: the first LDS wait of the row also waits for them, and by
+    // then the gathers below have covered their latency)
+    u1 = u2, rb1 = rb2, re1 = re2;                    // row i + step: complete
+    u2 = u3, rb2 = indptr[u2], re2 = indptr[u2 + 1];  // row i + 2 step: row id known -> its range
+    u3 = row_id(i + 3 * i_step);                      // row i + 3 step: row id
     float *xrow = X + (size_t)u * F;
     float x[FC], r[FC], p[FC], Ap[FC];
     tick(-1);
@@ -265,8 +267,7 @@ __global__ __launch_bounds__(BLOCK, 4) void als_cg_qteam_kernel(const int32_t *_
     QTile<F> tile;
     load_compact<F>(xrow, lane, x);  // first in the queue: the dense part of the first pass only needs x
     load_qtile_staged<F>(tile, col_next, c_next, Y, lane, min(T, row_end - k0));
-    fetch_meta(i + i_step, u_next, rb_next, re_next);  // overlaps with the gathers above
-    fetch_entries(indices, data, lane, min(rb_next + T * sub, re_next), re_next, col_next, c_next);
+    fetch_entries(indices, data, lane, min(rb1 + T * sub, re1), re1, col_next, c_next);  // entries of row i + step
     if constexpr (STATS) {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       tick(0);
