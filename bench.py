@@ -375,20 +375,25 @@ def bench_topk(gpu, Cui, X, Y, k=10, queries=20_000, batch=1000):
     views = [X[s:min(s + batch, queries)] for s in range(0, queries, batch)]
     knn.topk(Y, views[0], k, query_filter=filt[0])  # warm-up
     gpu.synchronize()
-    gpu.Profiler.reset()
-    gpu.Profiler.enable(True)
+    gpu.Profiler.enable(False)  # the HIP-event pairs cost ~0.4 ms per call here: timed without them
     t0 = time.perf_counter()
     for v, fl in zip(views, filt):
         knn.topk(Y, v, k, query_filter=fl)
     gpu.synchronize()
     t = time.perf_counter() - t0
+    gpu.Profiler.reset()  # per-kernel times from a second, untimed pass
+    gpu.Profiler.enable(True)
+    for v, fl in zip(views, filt):
+        knn.topk(Y, v, k, query_filter=fl)
+    gpu.synchronize()
     gpu.Profiler.enable(False)
     kernels = {name: gpu.Profiler.get(name)[0] / len(views) for name in gpu.Profiler.names()}
     flops = 2.0 * queries * Y.shape[0] * Y.shape[1]
     return {"metric": "top-k recs/sec", "value": queries / t, "unit": "recs/s", "k": k, "queries": queries,
             "kernels_ms_per_batch": kernels, "scoring_TFLOPs": flops / t / 1e12,
             "batch": batch, "items": Y.shape[0], "filter_already_liked_items": True,
-            "note": "ids/scores returned to host memory per batch (PCIe D2H included)"}
+            "note": "ids/scores returned to host memory per batch (PCIe D2H included); kernel times from a separate "
+                    "profiled pass"}
 
 
 if __name__ == "__main__":

@@ -68,9 +68,29 @@ static hipEvent_t get_event() {
   return e;
 }
 
+static void prof_account(const ProfPending &p) {
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
+    auto &e = g_prof[p.name];
+    e.total_ms += ms;
+    e.launches += 1;
+  }
+  g_event_pool.push_back(p.start);
+  g_event_pool.push_back(p.stop);
+}
+
+// Recycle the event pairs whose kernels have finished (no waiting): creating fresh events for every launch of a long
+// timed loop costs far more stream time than recording them.
+static void prof_collect_finished() {
+  size_t done = 0;
+  while (done < g_prof_pending.size() && hipEventQuery(g_prof_pending[done].stop) == hipSuccess) prof_account(g_prof_pending[done++]);
+  if (done) g_prof_pending.erase(g_prof_pending.begin(), g_prof_pending.begin() + (long)done);
+}
+
 ProfScope::ProfScope(const char *n) : name(n) {
   if (!g_prof_on) return;
   if (!g_prof_filter.empty() && !strstr(n, g_prof_filter.c_str())) return;
+  if (g_event_pool.size() < 2 && g_prof_pending.size() >= 32) prof_collect_finished();
   start = get_event();
   stop = get_event();
   IMP_CHECK_HIP(hipEventRecord(start, stream()));
@@ -85,16 +105,7 @@ ProfScope::~ProfScope() {
 static void prof_flush() {
   if (g_prof_pending.empty()) return;
   sync();
-  for (auto &p : g_prof_pending) {
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
-      auto &e = g_prof[p.name];
-      e.total_ms += ms;
-      e.launches += 1;
-    }
-    g_event_pool.push_back(p.start);
-    g_event_pool.push_back(p.stop);
-  }
+  for (auto &p : g_prof_pending) prof_account(p);
   g_prof_pending.clear();
 }
 
