@@ -400,8 +400,8 @@ __global__ void coo_filter_refresh_kernel(const float *__restrict__ S, float *__
 
 // Pruned select: tau = the k-th largest tile maximum (maxima refreshed after the filters) is a lower bound of the k-th
 // best surviving score: k distinct tiles each hold a surviving score >= tau.
-// ONE pass over the row collects every score >= tau (a few hundred) into LDS, a bitonic sort orders them and the best
-// k are written.  Rows that overflow the candidate buffer, have too few tiles, or show an exact tie at the k-th score
+// The tiles whose maximum reaches tau (about m of them) are scanned for scores >= tau (tens to a few hundred), which
+// go to LDS; a bitonic sort orders them and the best k are written.  Rows that overflow the candidate buffer, have too few tiles, or show an exact tie at the k-th score
 // (the reference heap's arrival-order rule then needs the whole row) raise `fallback[row]` and are redone by
 // select_kernel.
 constexpr int kCandCap = 4096;  // 32 KiB of LDS; heavy users (many liked items lower tau) need the headroom
@@ -456,11 +456,25 @@ __global__ __launch_bounds__(BLOCK) void select_pruned_kernel(const float *__res
 
   if (tid == 0) sh_count = 0;
   __syncthreads();
-  for (int i = tid; i < ni; i += BLOCK) {
-    const float sc = row[i];
-    if (ordered(sc) >= tau) {
-      unsigned int slot = atomicAdd(&sh_count, 1u);
-      if (slot < (unsigned)kCandCap) cand[slot] = make_key(sc, i);
+  // every score >= tau lives in a tile whose maximum is >= tau (the maxima are exact: the GEMM epilogue writes them
+  // and the filter kernels refresh the tiles they touch), so only those tiles -- about m of the n_tiles -- are read
+  // from the score row: each wave tests 64 maxima at a time and visits the hits one tile (64 scores) per step
+  {
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int base = wave * 64; base < n_tiles; base += (BLOCK / 64) * 64) {
+      const int t = base + lane;
+      unsigned long long hits = __ballot(t < n_tiles && ordered(tm[t]) >= tau);
+      while (hits) {
+        const int item = (base + __builtin_ctzll(hits)) * kTileItems + lane;
+        hits &= hits - 1;
+        if (item < ni) {
+          const float sc = row[item];
+          if (ordered(sc) >= tau) {
+            unsigned int slot = atomicAdd(&sh_count, 1u);
+            if (slot < (unsigned)kCandCap) cand[slot] = make_key(sc, item);
+          }
+        }
+      }
     }
   }
   __syncthreads();
