@@ -147,7 +147,7 @@ __global__ __launch_bounds__(1024) void als_cg_qgroup_kernel(const int32_t *__re
 }
 
 // ---- mid rows: a team of WPR wavefronts per row, the whole row resident -----------------------------------------------
-// STATS (debug, IMP_CG_STATS=1): s_memtime ticks (10 ns) summed over waves per phase --
+// STATS (debug, IMP_CG_STATS=1): s_memtime ticks (shader-clock cycles on gfx950) summed over waves per phase --
 //   [0] row start -> tile resident (gathers drained)  [1] operand vector to LDS + expand  [2] dense part
 //   [3] tile entries  [4] reduce-scatter  [5] combine (barriers included)  [6] dots / CG update  [7] wave-rows
 template <int F, int WPR, int BLOCK, bool STATS = false>
@@ -368,7 +368,7 @@ static void launch_qteam(const imp_csr *C, int first, int count, float *X, const
     IMP_CHECK_HIP(hipStreamSynchronize(stream()));
     const double n = h[7] ? (double)h[7] : 1.0;
     fprintf(stderr,
-            "[cg-stats] %s rows=%d wave-rows=%.0f  ticks(10ns)/wave-row: gather %.1f vec+expand %.1f dense %.1f entries %.1f "
+            "[cg-stats] %s rows=%d wave-rows=%.0f  cycles/wave-row: gather %.1f vec+expand %.1f dense %.1f entries %.1f "
             "reduce %.1f combine %.1f update %.1f\n",
             name, count, n, h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n, h[6] / n);
     return;
