@@ -463,7 +463,10 @@ int imp_csr_create(int32_t rows, int32_t cols, int64_t nnz, const int32_t *indpt
     // fetched into that XCD's L2 and hit by every long row (measured: partial kernel 2.6x faster with fully
     // L2-resident gathers; 1.3x with the real plan, whose segments are short).  Segments stay in row-major order (the combine kernel sums a row's partials in that fixed
     // order); `seg_exec` is the execution order.
-    int32_t stripe = 12288;  // 6 MB of factor rows at f = 128: best of {2048 .. 32768} on C3 (narrower = more, shorter segments)
+    // width: 12288 columns (6 MB of factor rows at f = 128) was the best of {2048 .. 32768} on C3 (359 K columns; narrower
+    // = more, shorter segments), 6144 the best of {2048 .. 12288} on the ml-20m shape (138 K columns: the 8 XCDs need
+    // enough stripes to balance) -- hence about 24 stripes, between 4096 and 12288 columns
+    int32_t stripe = std::min(12288, std::max(4096, (cols / 24 + 1023) / 1024 * 1024));
     if (const char *e = getenv("IMP_STRIPE")) stripe = std::max(0, atoi(e));
     int64_t long_nnz = 0;
     bool sorted = true;
