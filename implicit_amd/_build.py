@@ -18,6 +18,7 @@ SOURCES = ["containers.hip", "als_cg.hip", "als_cg_group.hip", "als_cg_q.hip", "
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result", "-Wno-pass-failed", "-ffp-contract=off"]
+EXTRA_FLAGS = {}  # per-file additions
 
 
 def _deps():
@@ -31,7 +32,7 @@ def _compile(src, force, hdr_mtime):
     path = os.path.join(CSRC, src)
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), hdr_mtime):
         return obj, False
-    subprocess.check_call([HIPCC, *FLAGS, "-c", path, "-o", obj])
+    subprocess.check_call([HIPCC, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", path, "-o", obj])
     return obj, True
 
 

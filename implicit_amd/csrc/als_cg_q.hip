@@ -251,10 +251,20 @@ __global__ __launch_bounds__(BLOCK, 4) void als_cg_qteam_kernel(const int32_t *_
   int rb1 = indptr[u1], re1 = indptr[u1 + 1], rb2 = indptr[u2], re2 = indptr[u2 + 1];
   int col_next;
   float c_next;
-  fetch_entries(indices, data, lane, min(rb1 + T * sub, re1), re1, col_next, c_next);
+  // A row's entries are dealt to the team in EVEN shares (rounded up to whole 4-entry tile steps), not 32 at a time:
+  // with 32-entry slices the first waves of a team carried full tiles and the last ones little or nothing, and since
+  // wave w of a workgroup sits on SIMD (w mod 4) the full-tile waves of every team shared the same SIMDs.
+  auto slice = [&](int rb, int re, int &k0, int &cnt) {
+    const int chunk = min(T, (((re - rb) + WPR - 1) / WPR + 3) & ~3);
+    k0 = min(rb + chunk * sub, re);
+    cnt = min(chunk, re - k0);
+  };
+  int k0_next, cnt_next;
+  slice(rb1, re1, k0_next, cnt_next);
+  fetch_entries(indices, data, lane, k0_next, max(k0_next + cnt_next, rb1 + 1), col_next, c_next);
   for (int i = i_first; i < count; i += i_step) {
     constexpr bool valid = true;
-    const int u = u1, row_begin = rb1, row_end = re1;
+    const int u = u1;
     // scalar stages first (they share lgkmcnt with the LDS: the first LDS wait of the row also waits for them, and by
     // then the gathers below have covered their latency)
     u1 = u2, rb1 = rb2, re1 = re2;                    // row i + step: complete
@@ -263,11 +273,12 @@ __global__ __launch_bounds__(BLOCK, 4) void als_cg_qteam_kernel(const int32_t *_
     float *xrow = X + (size_t)u * F;
     float x[FC], r[FC], p[FC], Ap[FC];
     tick(-1);
-    const int k0 = min(row_begin + T * sub, row_end);  // this wave's slice of the row (may be empty)
+    const int cnt = cnt_next;  // this wave's slice of the row (may be empty)
     QTile<F> tile;
     load_compact<F>(xrow, lane, x);  // first in the queue: the dense part of the first pass only needs x
-    load_qtile_staged<F>(tile, col_next, c_next, Y, lane, min(T, row_end - k0));
-    fetch_entries(indices, data, lane, min(rb1 + T * sub, re1), re1, col_next, c_next);  // entries of row i + step
+    load_qtile_staged<F>(tile, col_next, c_next, Y, lane, cnt);
+    slice(rb1, re1, k0_next, cnt_next);
+    fetch_entries(indices, data, lane, k0_next, max(k0_next + cnt_next, rb1 + 1), col_next, c_next);  // entries of row i + step
     if constexpr (STATS) {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       tick(0);
@@ -385,11 +396,14 @@ template <int F> static void run_classes_q(const imp_csr *C, float *X, const flo
   launch_qteam<F, 8, 512>(C, b[2], b[3] - b[2], X, Y, A0, cg_steps, "als_cg_team8_rows");
   launch_qteam<F, 4, 512>(C, b[3], b[4] - b[3], X, Y, A0, cg_steps, "als_cg_team4_rows");
   launch_qteam<F, 2, 512>(C, b[4], b[5] - b[4], X, Y, A0, cg_steps, "als_cg_team2_rows");
-  static const bool short_team1 = getenv("IMP_SHORT_TEAM1") != nullptr;  // A/B: independent waves, VALU gramian product
-  if (short_team1)
-    launch_qteam<F, 1, 512>(C, b[5], b[7] - b[5], X, Y, A0, cg_steps, "als_cg_short_rows");
-  else
-    launch_qgroup<F>(C, b[5], b[7] - b[5], X, Y, A0, cg_steps, "als_cg_short_rows");  // tile steps beyond cnt are skipped
+  // short rows.  f = 128: 16 rows per workgroup in lock step with the gramian product on fp32 MFMA (measured 1.16 ms per
+  // C3 iteration against 1.38 ms for independent waves with the VALU product -- at f = 128 the product is 57 % of a short
+  // row's arithmetic); f = 64: independent waves win (C2: 0.84 against 0.94 ms), the product is a quarter of the size
+  // and the lock step costs more than the matrix pipe saves.  IMP_SHORT_TEAM1=0/1 forces one or the other (A/B).
+  static const int short_team1 = getenv("IMP_SHORT_TEAM1") ? atoi(getenv("IMP_SHORT_TEAM1")) : -1;
+  const bool team1 = short_team1 >= 0 ? short_team1 != 0 : F == 64;
+  if (team1) launch_qteam<F, 1, 512>(C, b[5], b[7] - b[5], X, Y, A0, cg_steps, "als_cg_short_rows");
+  else launch_qgroup<F>(C, b[5], b[7] - b[5], X, Y, A0, cg_steps, "als_cg_short_rows");  // tile steps beyond cnt are skipped
 }
 
 void least_squares_cg_q(const imp_csr *C, float *X, const float *Y, const float *A0, int f, int cg_steps) {

@@ -230,9 +230,19 @@ __device__ __forceinline__ void qtile_apply(const QTile<F> &tile, const float (&
     }
     return;
   }
+  // partial tile: steps in pairs (two interleaved chains), pairs beyond the row's count skipped (wave-uniform); the
+  // second step of the last pair may be all padding, whose weights are 0
 #pragma unroll
-  for (int q = 0; q < EQ; ++q) {
-    if (4 * q < tile.cnt) axpy(q, row_allsum(partial(q)));  // wave-uniform skip of whole steps
+  for (int q = 0; q < EQ; q += 2) {
+    if (4 * q < tile.cnt) {
+      float d0 = partial(q), d1 = partial(q + 1);
+      d0 += dpp_mov<0x128>(d0), d1 += dpp_mov<0x128>(d1);
+      d0 += dpp_mov<0x124>(d0), d1 += dpp_mov<0x124>(d1);
+      d0 += dpp_mov<0x122>(d0), d1 += dpp_mov<0x122>(d1);
+      d0 += dpp_mov<0x121>(d0), d1 += dpp_mov<0x121>(d1);
+      axpy(q, d0);
+      axpy(q + 1, d1);
+    }
   }
 }
 
