@@ -28,7 +28,6 @@
 
 namespace imp {
 
-void least_squares_cg_group(const imp_csr *C, float *X, const float *Y, const float *A0, int f, int cg_steps);  // als_cg_group.hip
 void least_squares_cg_q(const imp_csr *C, float *X, const float *Y, const float *A0, int f, int cg_steps);      // als_cg_q.hip
 
 // ---- generic per-nnz pass (any f): 4 gathers in flight, one DPP all-reduce per dot -------------------
@@ -382,11 +381,6 @@ void zero_rows(const int32_t *order, int first, int count, float *X, int f) {
   IMP_CHECK_HIP(hipGetLastError());
 }
 
-static DeviceArray<float> &long_workspace() {
-  static DeviceArray<float> *ws = new DeviceArray<float>;  // leaked on purpose (no hipFree at exit)
-  return *ws;
-}
-
 template <int VPL, bool VEC, bool A_LDS, bool RESIDENT>
 static void launch_fused(const imp_csr *C, int first, int count, float *X, const float *Y, const float *A0, int f,
                          int cg_steps, const char *name) {
@@ -412,7 +406,7 @@ static void launch_long(const imp_csr *C, float *X, const float *Y, const float 
   constexpr int BLOCK = 512;
   constexpr int LD = 64 * VPL;
   size_t need = ((size_t)n_seg + 2 * (size_t)n_long) * LD + 2 * (size_t)n_long;
-  auto &ws = long_workspace();
+  auto &ws = ctx().long_ws;
   if (ws.size < need) ws.alloc(need);
   float *partial = ws.data();
   float *rvec = partial + (size_t)n_seg * LD;
@@ -468,12 +462,8 @@ static void launch_all(const imp_csr *C, float *X, const float *Y, const float *
   // schedule classes (imp_csr): 0 long (segment-split), 1..4 mid, 5..6 short, 7 empty
   const int32_t *b = C->bin_start;
   launch_long<VPL, VEC, A_LDS>(C, X, Y, A0, f, cg_steps);
-  static const bool no_group = getenv("IMP_NO_GROUP") != nullptr;  // A/B switch: generic one-wave-per-row kernels
-  static const bool use_q = getenv("IMP_NO_Q") == nullptr;  // default: quarter-layout tiles (als_cg_q.hip); IMP_NO_Q=1 -> als_cg_group.hip
-  if (VEC && A_LDS && (f == 64 || f == 128) && !no_group && use_q) {
-    least_squares_cg_q(C, X, Y, A0, f, cg_steps);
-  } else if (VEC && A_LDS && (f == 64 || f == 128) && !no_group) {
-    least_squares_cg_group(C, X, Y, A0, f, cg_steps);  // wave teams with resident tiles + MFMA gramian product
+  if (VEC && A_LDS && (f == 64 || f == 128)) {
+    least_squares_cg_q(C, X, Y, A0, f, cg_steps);  // quarter-layout register tiles, wave teams (als_cg_q.hip)
   } else {
     bool resident_ok = false;
     if constexpr (VEC) resident_ok = tile_size<VPL>() >= imp_csr::kShortRow;

@@ -1,8 +1,8 @@
 // K1q: the CG half sweep for f = 64 / 128 on quarter-layout register tiles (als_qtile.h).
 //
-// Same arithmetic contract (oracle: implicit/cpu/_als.pyx:152-248) and the same schedule as als_cg_group.hip --
-// short rows: one wavefront per row, 16 rows per workgroup in lock step, gramian product on fp32 MFMA;
-// mid rows: a team of 2/4/8/16 wavefronts per row with the whole row resident -- but the per-pass work of a wave is
+// Arithmetic contract: the oracle's CG (implicit/cpu/_als.pyx:152-248).  Schedule --
+// short rows: one wavefront per row (f = 128: 16 rows per workgroup in lock step, gramian product on fp32 MFMA);
+// mid rows: a team of 2/4/8/16 wavefronts per row with the whole row resident.  The per-pass work of a wave is
 // organised around the four 16-lane DPP rows instead of the whole wave: dots reduce inside one DPP row, weights
 // need no broadcast, and accumulators return to the compact CG-state layout through two permlane-swap levels.
 #include <type_traits>

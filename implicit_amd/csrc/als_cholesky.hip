@@ -10,6 +10,8 @@
 // z = L^-1 b in the last row for free, and the back substitution L^T x = z is done by one wavefront
 // with readlane broadcasts (no block barriers).  Gathered factor rows are staged through LDS in
 // tiles of TILE rows, each a fully coalesced read.
+#include <type_traits>
+
 #include "common.h"
 
 namespace imp {
@@ -215,128 +217,241 @@ __global__ __launch_bounds__(256) void als_cholesky_wave_kernel(const int32_t *_
   }
 }
 
-// ---- f <= 64, f even: MFMA A-build + register Cholesky, one wavefront per row (ALL row lengths) ---------------------
+// ---- f = 64 (BASELINE configs[1]): MFMA A-build + left-looking Cholesky, one wavefront per row (ALL row lengths) --------
 // A_u = YtY + reg I + sum_k (|c_k|-1) y_k y_k^T is a SYRK: with v_mfma_f32_32x32x2_f32 two nonzeros are one k-step.  Lane
 // (r = l & 31, h = l >> 5) loads ONE float2 = factors (2r, 2r+1) of nonzero 2s + h (32 lanes cover the whole 64-factor
 // row), so the factor set splits into EVEN and ODD factors and three 32x32 accumulator tiles cover the symmetric matrix:
 //   T_ee += (w y_e) y_e^T,  T_oe += (w y_o) y_e^T,  T_oo += (w y_o) y_o^T        (T_eo = T_oe^T)
-// i.e. 96 matrix-pipe cycles per nonzero instead of ~250 VALU cycles, off the VALU.  The tiles (+ YtY + reg I) go through
-// a wave-private LDS image [64][65] to reach the row-per-lane layout of the register factorisation (als_cholesky_wave_kernel).
+// i.e. 96 matrix-pipe cycles per nonzero instead of ~250 VALU cycles, off the VALU.  The gathers of trip t + 1 are in
+// flight during the MFMAs of trip t, the (column, confidence) pairs of the next 64 nonzeros during the current 64.
+//
+// The tiles go through a wave-private LDS image to the row-per-lane layout (lane i owns row i).  Only the LOWER triangle is
+// kept, row i padded to a multiple of 4 floats at offset 4 (a+1)(2a+b), i = 4a+b (8.7 KB per wave instead of 17 KB), and
+// G = YtY + reg I is staged once per workgroup: 52 KB of LDS per workgroup = 3 workgroups (12 waves) per CU.
+//
+// Factorisation: LEFT-looking, column by column.  Lane i keeps row i of L in registers; at step k every lane forms
+//   s_i = A[i][k] - sum_{j<k} L[i][j] L[k][j]
+// with its own registers and row k of L read from the image as BROADCAST ds_read_b128 (all lanes, same address; issued
+// back to back, then consumed), 4 independent accumulators; the pivot travels by one v_readlane, L[i][k] = s_i / sqrt(s_k)
+// is stored to the image, and the forward substitution rides along (one FMA per step).
+//
+// History (configs[1], ms per iteration): round 1 was right-looking with the column broadcast lane by lane (v_readlane +
+// FMA per element: 12.7 K straight-line instructions per row, 76 KB of code) and read YtY row-wise: 46-57 ms.  Per-phase
+// cycle counters (IMP_CHOL_STATS=1) then showed where a 50-nonzero row's 120 K cycles went: 77 K in the conversion phase
+// (the row-invariant YtY loads were hoisted out of the row loop, spilled, and came back from scratch memory one dependent
+// round trip at a time; the 128 lane masks likewise, through v_writelane / v_readlane), 24 K factorisation, 14 K SYRK.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(256) void als_cholesky_mfma_kernel(const int32_t *__restrict__ order, int first, int count,
-                                                                const int32_t *__restrict__ indptr,
-                                                                const int32_t *__restrict__ indices,
-                                                                const float *__restrict__ data, float *__restrict__ X,
-                                                                const float *__restrict__ Y, const float *__restrict__ YtY,
-                                                                int f, float reg, unsigned long long *failed_row) {
-  constexpr int FMAX = 64, LDA = 65, KS = 4;
+// compile-time loop: body(std::integral_constant<int, i>{}) for i = 0 .. N-1.  The factorisation indexes 64 registers by
+// the column number: `#pragma unroll` gave up on the nested loops once and put the row into scratch memory (353 K cycles).
+template <int N, int I = 0, typename Body> __device__ __forceinline__ void static_for(Body &&body) {
+  if constexpr (I < N) {
+    body(std::integral_constant<int, I>{});
+    static_for<N, I + 1>(body);
+  }
+}
+
+__host__ __device__ constexpr int chol_rowoff(int i) { return 4 * ((i >> 2) + 1) * (2 * (i >> 2) + (i & 3)); }
+constexpr int kCholTri = chol_rowoff(63) + 64;  // 2176 floats
+
+template <bool STATS>
+__global__ __launch_bounds__(256, 2) void als_cholesky_f64_kernel(const int32_t *__restrict__ order, int first, int count,
+                                                                  const int32_t *__restrict__ indptr,
+                                                                  const int32_t *__restrict__ indices,
+                                                                  const float *__restrict__ data, float *__restrict__ X,
+                                                                  const float *__restrict__ Y, const float *__restrict__ YtY,
+                                                                  float reg, unsigned long long *failed_row,
+                                                                  unsigned long long *stats) {
+  constexpr int F = 64, KS = 4, GLD = 68;
+  // STATS (debug, IMP_CHOL_STATS=1): s_memtime ticks per phase summed over waves -- [1] SYRK loop (entries + gathers + MFMA)
+  // [2] tiles -> LDS image -> row registers  [3] factorisation  [4] back substitution + store  [7] rows
+  unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = 0;
+  auto tick = [&](int slot) {
+    if constexpr (STATS) {
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      unsigned long long now = __builtin_amdgcn_s_memtime();
+      if (slot >= 0) tk[slot] += now - t_last;
+      t_last = now;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *Gs = smem;  // [64][GLD]  YtY + reg I
   const int lane = threadIdx.x & 63;
   const int wslot = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float *As = smem + (size_t)wslot * FMAX * LDA;  // wave-private
+  float *As = smem + F * GLD + (size_t)wslot * kCholTri;  // wave-private lower-triangular image
+  for (int e = threadIdx.x; e < F * F; e += 256) {
+    const int rr = e >> 6, cc = e & 63;
+    Gs[rr * GLD + cc] = YtY[e] + (rr == cc ? reg : 0.f);
+  }
+  __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const bool pair_ok = 2 * r < f;  // f even: both factors of the pair exist or neither
-  const bool row_ok = lane < f;
+  const int my_off = chol_rowoff(lane);
 
   for (int ri = wave; ri < count; ri += nwaves) {
     const int u = __builtin_amdgcn_readfirstlane(order[first + ri]);
     const int row_begin = __builtin_amdgcn_readfirstlane(indptr[u]);
     const int row_end = __builtin_amdgcn_readfirstlane(indptr[u + 1]);
+    // lane ids are kept opaque per row: every lane mask below (lane == k, lane >= k, ...) is row-invariant, and hoisted out of
+    // the row loop they are more SGPR pairs than exist
+    int lane_v = lane;
+    asm volatile("" : "+v"(lane_v));
     f32x16 Tee, Toe, Too;
 #pragma unroll
     for (int e = 0; e < 16; ++e) Tee[e] = Toe[e] = Too[e] = 0.f;
     float be = 0.f, bo = 0.f;  // b partials of this lane's half: factors 2r and 2r+1
+    tick(-1);
 
-    for (int k0 = row_begin; k0 < row_end; k0 += 64) {
-      const int cnt = min(64, row_end - k0);
-      const int my_idx = indices[k0 + min(lane, cnt - 1)];
-      const float my_c = lane < cnt ? data[k0 + lane] : 1.f;  // confidence 1 -> weight 0, c+ masked below
-      for (int s0 = 0; s0 < cnt; s0 += 2 * KS) {  // KS k-steps (2 KS nonzeros) per trip: KS gathers in flight
-        float2 y[KS];
-        float w[KS], cp[KS];
+    // one trip = KS k-steps = 2 KS nonzeros; lane (r, h) handles nonzero 2 q + h of every k-step q
+    float2 y[2][KS];
+    float w[2][KS], cp[2][KS];
+    auto fetch = [&](int buf, int my_idx, float my_c, int s0, int cnt) {
 #pragma unroll
-        for (int q = 0; q < KS; ++q) {
-          const int t = s0 + 2 * q + h;  // this half's nonzero of k-step q
-          const int tc = min(t, cnt - 1);
-          const unsigned col = (unsigned)__shfl(my_idx, tc, 64);
-          const float c = __shfl(my_c, tc, 64);
-          const bool ok = t < cnt;
-          w[q] = ok ? fabsf(c) - 1.f : 0.f;
-          cp[q] = (ok && c > 0.f) ? c : 0.f;
-          y[q] = pair_ok ? *reinterpret_cast<const float2 *>(Y + (size_t)col * f + 2 * r) : make_float2(0.f, 0.f);
+      for (int q = 0; q < KS; ++q) {
+        const int t = s0 + 2 * q + h;
+        const int tc = min(t, cnt - 1);
+        const unsigned col = (unsigned)__shfl(my_idx, tc, 64);
+        const float c = __shfl(my_c, tc, 64);
+        const bool ok = t < cnt;
+        w[buf][q] = ok ? fabsf(c) - 1.f : 0.f;
+        cp[buf][q] = (ok && c > 0.f) ? c : 0.f;
+        y[buf][q] = *reinterpret_cast<const float2 *>(Y + (size_t)col * F + 2 * r);
+      }
+    };
+    auto multiply = [&](int buf) {
+#pragma unroll
+      for (int q = 0; q < KS; ++q) {
+        const float ae = w[buf][q] * y[buf][q].x, ao = w[buf][q] * y[buf][q].y;
+        Tee = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, y[buf][q].x, Tee, 0, 0, 0);
+        Toe = __builtin_amdgcn_mfma_f32_32x32x2f32(ao, y[buf][q].x, Toe, 0, 0, 0);
+        Too = __builtin_amdgcn_mfma_f32_32x32x2f32(ao, y[buf][q].y, Too, 0, 0, 0);
+        be = fmaf(cp[buf][q], y[buf][q].x, be);
+        bo = fmaf(cp[buf][q], y[buf][q].y, bo);
+      }
+    };
+    if (row_begin < row_end) {
+      int idx_next = indices[row_begin + min(lane, row_end - row_begin - 1)];
+      float c_next = row_begin + lane < row_end ? data[row_begin + lane] : 1.f;  // confidence 1 -> weight 0, c+ masked
+      for (int k0 = row_begin; k0 < row_end; k0 += 64) {
+        const int cnt = min(64, row_end - k0);
+        const int my_idx = idx_next;
+        const float my_c = c_next;
+        if (k0 + 64 < row_end) {  // entries of the next 64 nonzeros
+          idx_next = indices[k0 + 64 + min(lane, row_end - k0 - 65)];
+          c_next = k0 + 64 + lane < row_end ? data[k0 + 64 + lane] : 1.f;
         }
-#pragma unroll
-        for (int q = 0; q < KS; ++q) {
-          const float ae = w[q] * y[q].x, ao = w[q] * y[q].y;
-          Tee = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, y[q].x, Tee, 0, 0, 0);
-          Toe = __builtin_amdgcn_mfma_f32_32x32x2f32(ao, y[q].x, Toe, 0, 0, 0);
-          Too = __builtin_amdgcn_mfma_f32_32x32x2f32(ao, y[q].y, Too, 0, 0, 0);
-          be = fmaf(cp[q], y[q].x, be);
-          bo = fmaf(cp[q], y[q].y, bo);
+        fetch(0, my_idx, my_c, 0, cnt);
+        for (int s0 = 0; s0 < cnt; s0 += 4 * KS) {  // two trips per round: the other buffer's gathers fly during the MFMAs
+          if (s0 + 2 * KS < cnt) fetch(1, my_idx, my_c, s0 + 2 * KS, cnt);
+          multiply(0);
+          if (s0 + 2 * KS < cnt) {
+            if (s0 + 4 * KS < cnt) fetch(0, my_idx, my_c, s0 + 4 * KS, cnt);
+            multiply(1);
+          }
         }
       }
     }
-    // tiles -> wave-private LDS image of the full symmetric A (C/D layout: col j' = lane & 31, row i' = (e&3)+8(e>>2)+4h)
+    tick(1);
+    // tiles -> lower triangle of the image (C/D layout: col j' = lane & 31, row i' = (e&3) + 8 (e>>2) + 4 h)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int ip = (e & 3) + 8 * (e >> 2) + 4 * h, jp = r;
-      As[(2 * ip) * LDA + 2 * jp] = Tee[e];          // A[2i'][2j']      (T_ee is itself symmetric: every (i',j') written)
-      As[(2 * ip + 1) * LDA + 2 * jp + 1] = Too[e];  // A[2i'+1][2j'+1]
-      As[(2 * ip + 1) * LDA + 2 * jp] = Toe[e];      // A[2i'+1][2j']
-      As[(2 * jp) * LDA + 2 * ip + 1] = Toe[e];      // and its mirror A[2j'][2i'+1]
+      const int ip = (e & 3) + 8 * (e >> 2) + 4 * (lane_v >> 5), jp = lane_v & 31;
+      const int off_e = chol_rowoff(2 * ip), off_o = chol_rowoff(2 * ip + 1);
+      if (ip >= jp) {
+        As[off_e + 2 * jp] = Tee[e];      // A[2i'][2j']
+        As[off_o + 2 * jp + 1] = Too[e];  // A[2i'+1][2j'+1]
+        As[off_o + 2 * jp] = Toe[e];      // A[2i'+1][2j']
+      } else {
+        As[chol_rowoff(2 * jp) + 2 * ip + 1] = Toe[e];  // its mirror A[2j'][2i'+1] (T_oe covers odd rows x even columns)
+      }
     }
     // b: sum the two halves, then lane i needs b[i]: factor 2r (even) / 2r+1 (odd) live in lanes r and r+32
     be += __shfl_xor(be, 32, 64);
     bo += __shfl_xor(bo, 32, 64);
     const float b_even_src = __shfl(be, lane >> 1, 64), b_odd_src = __shfl(bo, lane >> 1, 64);
-    float b = (lane & 1) ? b_odd_src : b_even_src;  // b[lane]
-    if (!row_ok) b = 0.f;
-    // row-per-lane registers: A[lane][j] + YtY + reg I (identity padding beyond f keeps the unrolled factorisation finite)
-    float A[FMAX];
+    float b = (lane_v & 1) ? b_odd_src : b_even_src;  // b[lane]
+    // row-per-lane registers: A[lane][j] = image + G for j <= lane (beyond: other rows' words, never used)
+    float A[F];
 #pragma unroll
-    for (int j = 0; j < FMAX; ++j) {
-      const float g0 = (row_ok && j < f) ? YtY[(size_t)lane * f + j] + As[lane * LDA + j] : 0.f;
-      A[j] = g0 + ((j == lane) ? (j < f ? reg : 1.f) : 0.f);
+    for (int j = 0; j < F; j += 4) {
+      const float4 t = *reinterpret_cast<const float4 *>(As + my_off + j);
+      const float4 g = *reinterpret_cast<const float4 *>(Gs + lane * GLD + j);
+      A[j] = t.x + g.x, A[j + 1] = t.y + g.y, A[j + 2] = t.z + g.z, A[j + 3] = t.w + g.w;
     }
+    tick(2);
     bool ok = true;
+    float dinv = 0.f;  // lane k keeps 1 / L[k][k] for the back substitution
+    // Row k of L (columns 0..k-1) is read from the image as broadcast ds_read_b128 (same address in every lane).  Software
+    // pipeline: the chunks of row k+1 that do not contain column k are already final, so their reads are issued right
+    // after step k's dot product and fly during its pivot chain (v_readlane -> v_rsq -> Newton -> column scale -> store);
+    // only the chunk holding column k is read after the store.  lrow is free by then: no extra registers.
+    float4 lrow[F / 4];
+    static_for<F>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      // s = A[lane][k] - sum_{j<k} L[lane][j] L[k][j], 4 independent accumulators
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
-    for (int k = 0; k < FMAX; ++k) {
-      const float d = bcast_lane(A[k], k);  // pivot
+      for (int j = 0; j < k; j += 4) {
+        const float4 l = lrow[j / 4];
+        s0 = fmaf(A[j], l.x, s0);
+        if (j + 1 < k) s1 = fmaf(A[j + 1], l.y, s1);  // compile-time conditions: the last chunk of a row is partial
+        if (j + 2 < k) s2 = fmaf(A[j + 2], l.z, s2);
+        if (j + 3 < k) s3 = fmaf(A[j + 3], l.w, s3);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (k + 1 < F) {  // row k+1, chunks below the one that holds column k
+#pragma unroll
+        for (int c = 0; c < k / 4; ++c) lrow[c] = *reinterpret_cast<const float4 *>(As + chol_rowoff(k + 1) + 4 * c);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const float s = A[k] - ((s0 + s1) + (s2 + s3));
+      const float d = bcast_lane(s, k);  // pivot
       if (!(d > 0.f)) ok = false;
-      const float sd = sqrtf(d);
-      const float lik = lane == k ? sd : A[k] / sd;  // L[i][k] for i >= k (rows above k hold garbage, unused)
+      // 1 / sqrt(d): v_rsq_f32 (1 ulp) + one Newton step -- as accurate as sqrt followed by a true division (two roundings)
+      // at a fifth of the instructions (reg = 0 systems are badly conditioned: no raw approximations).  The column and the
+      // forward substitution multiply by it; L[k][k] itself comes out as d * inv and is only used through `inv`.
+      const float r0 = __builtin_amdgcn_rsqf(d);
+      const float inv = fmaf(r0, fmaf(-0.5f * d * r0, r0, 0.5f), r0);  // r0 + r0 (1/2 - d r0^2 / 2)
+      const float lik = s * inv;  // L[i][k] for i >= k
       A[k] = lik;
-      const float zk = bcast_lane(b, k) / sd;  // z_k = b_k / L_kk
-      b = lane == k ? zk : fmaf(-lik, zk, b);
-#pragma unroll
-      for (int j = k + 1; j < FMAX; ++j) A[j] = fmaf(-lik, bcast_lane(lik, j), A[j]);
-    }
+      if (lane_v >= k) As[my_off + k] = lik;  // rows above k have no column k in the triangular image
+      if constexpr (k + 1 < F) lrow[k / 4] = *reinterpret_cast<const float4 *>(As + chol_rowoff(k + 1) + 4 * (k / 4));
+      const float zk = bcast_lane(b, k) * inv;  // z_k = b_k / L_kk; the forward substitution rides along
+      // rows above k are finished (z_i final) and their column-k value is not a matrix element in the triangular image
+      b = lane_v == k ? zk : (lane_v > k ? fmaf(-lik, zk, b) : b);
+      dinv = lane_v == k ? inv : dinv;
+    });
+    tick(3);
     if (!ok) {
       if (lane == 0) atomicMin(failed_row, (unsigned long long)u);
       continue;
     }
-    // back substitution L^T x = z, column oriented: after x_k is known every lane i < k does z_i -= L[k][i] x_k.  L[k][i] is
-    // row k of L (lane k's registers), so L goes through the wave-private LDS image once to get its transpose per lane:
-    // one FMA per unknown instead of one wave reduction per unknown.
+    // back substitution L^T x = z, column oriented: after x_k is known every lane i < k does z_i -= L[k][i] x_k; L[k][i] is
+    // row k of the image read ACROSS the lanes (contiguous, conflict-free) -- one FMA per unknown.  The 64 reads do not
+    // depend on the chain: they are all issued first (into the registers the row of L no longer needs).
 #pragma unroll
-    for (int j = 0; j < FMAX; ++j) As[lane * LDA + j] = A[j];
-#pragma unroll
-    for (int k = 0; k < FMAX; ++k) A[k] = As[k * LDA + lane];  // A[k] = L[k][lane] (valid for k >= lane)
-#pragma unroll
-    for (int k = FMAX - 1; k >= 0; --k) {
-      const float xk = bcast_lane(b, k) / bcast_lane(A[k], k);  // lane k holds z_k (fully updated) and L[k][k]
-      b = lane == k ? xk : (lane < k ? fmaf(-A[k], xk, b) : b);
-    }
-    if (row_ok) X[(size_t)u * f + lane] = b;
+    for (int k = 0; k < F; ++k) A[k] = As[chol_rowoff(k) + lane];  // L[k][lane] (meaningful for lane < k; beyond: other rows' words)
+    __builtin_amdgcn_sched_barrier(0);
+    b *= dinv;  // lane k now holds z_k / L[k][k]; the pending corrections are scaled the same way as they arrive
+    static_for<F>([&](auto kc) {
+      constexpr int k = F - 1 - decltype(kc)::value;
+      const float xk = bcast_lane(b, k);  // x_k: lane k's value is final once all x_j, j > k, have been applied
+      b = lane_v < k ? fmaf(-A[k] * dinv, xk, b) : b;
+    });
+    X[(size_t)u * F + lane] = b;
+    tick(4);
+    if constexpr (STATS) tk[7] += 1;
+  }
+  if constexpr (STATS) {
+    if (lane == 0)
+      for (int i = 0; i < 8; ++i) atomicAdd(&stats[i], tk[i]);
   }
 }
 
 void zero_rows(const int32_t *order, int first, int count, float *X, int f);  // als_cg.hip
-
-static unsigned long long *g_failed = nullptr;
 
 // returns -1, or the smallest failing row
 int64_t least_squares_cholesky(const imp_csr *C, imp_matrix *X, const imp_matrix *YtY, const imp_matrix *Y, double reg) {
@@ -344,22 +459,39 @@ int64_t least_squares_cholesky(const imp_csr *C, imp_matrix *X, const imp_matrix
   if (f > 160) throw std::invalid_argument("least_squares_cholesky: factors must be <= 160 in this build");
   int lda = (f + 1) | 1;  // odd
   size_t lds = ((size_t)(f + 1) * lda + (size_t)kCholTile * f + (size_t)kCholTile * (f + 1)) * sizeof(float);
-  if (!g_failed) IMP_CHECK_HIP(hipMalloc(&g_failed, sizeof(unsigned long long)));
+  auto &failb = ctx().chol_failed;
+  if (failb.size < 1) failb.alloc(1);
+  unsigned long long *g_failed = failb.data();
   IMP_CHECK_HIP(hipMemsetAsync(g_failed, 0xFF, sizeof(unsigned long long), stream()));
   int nonempty = C->nonempty();
   static const bool no_wave = getenv("IMP_CHOL_NO_WAVE") != nullptr;
   static const bool no_mfma = getenv("IMP_CHOL_NO_MFMA") != nullptr;
-  if (nonempty > 0 && f <= 64 && f % 2 == 0 && !no_mfma && !no_wave) {
-    // every non-empty row: MFMA A-build + register Cholesky, one wavefront per row
-    size_t lds_m = (size_t)4 * 64 * 65 * sizeof(float);
-    IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(als_cholesky_mfma_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
-    int grid = std::min((nonempty + 3) / 4, ctx().num_cus * 2);
-    {
+  if (nonempty > 0 && f == 64 && !no_mfma && !no_wave) {
+    // every non-empty row: MFMA A-build + left-looking Cholesky, one wavefront per row
+    const size_t lds_m = ((size_t)64 * 68 + 4 * kCholTri) * sizeof(float);  // 52 KB: 3 workgroups per CU
+    const int grid = std::min((nonempty + 3) / 4, ctx().num_cus * 2);  // ~190 VGPRs: 2 waves per SIMD
+    static const bool want_stats = getenv("IMP_CHOL_STATS") != nullptr;
+    if (want_stats) {  // debug: per-phase tick sums of this launch, printed to stderr
+      IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(als_cholesky_f64_kernel<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+      DeviceArray<unsigned long long> st;
+      st.alloc(8, true);
+      als_cholesky_f64_kernel<true><<<grid, 256, lds_m, stream()>>>(C->order.data(), 0, nonempty, C->indptr.data(), C->indices.data(),
+                                                                    C->data.data(), X->f32(), Y->f32(), YtY->f32(), (float)reg,
+                                                                    g_failed, st.data());
+      unsigned long long h[8];
+      IMP_CHECK_HIP(hipMemcpyAsync(h, st.data(), sizeof(h), hipMemcpyDeviceToHost, stream()));
+      sync();
+      const double n = h[7] ? (double)h[7] : 1.0;
+      fprintf(stderr, "[chol-stats] rows=%d cycles/row: SYRK %.0f  image+rows %.0f  factorise %.0f  back-subst %.0f\n", nonempty, h[1] / n,
+              h[2] / n, h[3] / n, h[4] / n);
+    } else {
+      IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(als_cholesky_f64_kernel<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
       IMP_PROF("als_cholesky_mfma_rows");
-      als_cholesky_mfma_kernel<<<grid, 256, lds_m, stream()>>>(C->order.data(), 0, nonempty, C->indptr.data(), C->indices.data(),
-                                                               C->data.data(), X->f32(), Y->f32(), YtY->f32(), f, (float)reg,
-                                                               g_failed);
+      als_cholesky_f64_kernel<false><<<grid, 256, lds_m, stream()>>>(C->order.data(), 0, nonempty, C->indptr.data(), C->indices.data(),
+                                                                     C->data.data(), X->f32(), Y->f32(), YtY->f32(), (float)reg,
+                                                                     g_failed, nullptr);
       IMP_CHECK_HIP(hipGetLastError());
     }
     zero_rows(C->order.data(), C->first_empty(), C->n_empty(), X->f32(), f);
@@ -368,7 +500,7 @@ int64_t least_squares_cholesky(const imp_csr *C, imp_matrix *X, const imp_matrix
     sync();
     return failed_m == ~0ULL ? -1 : (int64_t)failed_m;
   }
-  // f <= 64 (odd f): rows up to 256 nnz go to the register-resident wave kernel; longer rows (and any larger f) to the
+  // other f <= 64: rows up to 256 nnz go to the register-resident wave kernel; longer rows (and any larger f) to the
   // workgroup kernel, whose 256 threads share the A-build of one row
   const int n_block = (f <= 64 && !no_wave) ? C->bin_start[2] : nonempty;
   const int n_wave = nonempty - n_block;

@@ -1,4 +1,4 @@
-// Register-tile building blocks of the CG kernels (shared by als_cg.hip and als_cg_group.hip).
+// Register-tile building blocks of the generic CG kernels (als_cg.hip; the f = 64 / 128 kernels use als_qtile.h).
 #ifndef IMPLICIT_AMD_CSRC_ALS_TILE_H_
 #define IMPLICIT_AMD_CSRC_ALS_TILE_H_
 #include "wave_ops.h"

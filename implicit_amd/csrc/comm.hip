@@ -133,8 +133,9 @@ int imp_comm_allgather_rows_end(imp_comm *c) {
 
 int imp_comm_barrier(imp_comm *c) {
   return guarded([&] {
-    static float *dummy = nullptr;
-    if (!dummy) IMP_CHECK_HIP(hipMalloc(&dummy, sizeof(float)));
+    auto &word = ctx().barrier_word;
+    if (word.size < 1) word.alloc(1, true);
+    float *dummy = word.data();
     IMP_CHECK_NCCL(ncclAllReduce(dummy, dummy, 1, ncclFloat, ncclSum, c->comm, stream()));
     sync();
   });

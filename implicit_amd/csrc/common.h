@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -32,9 +33,19 @@ void set_last_error(const std::string &msg);
     }                                                                                          \
   } while (0)
 
+// ---- per-device context: one stream, lazily created; owns every scratch buffer the kernels share ------------------
+struct Context;
+Context &ctx();  // context of the current device
+// Serialises the C-ABI calls of one device: the library stream, the profiler's pending events and the workspaces below
+// are shared by everything that runs on a device, and ctypes drops the GIL around every call -- two Python threads
+// calling into the same device would otherwise interleave kernels on the same scratch buffers (the reference allocates
+// its temporaries per call).  Calls on different devices do not block each other.
+std::unique_lock<std::recursive_mutex> lock_device();
+
 // wraps the body of every extern "C" function
 template <typename F> int guarded(F &&body) {
   try {
+    auto lock = lock_device();
     body();
     return IMP_OK;
   } catch (const std::invalid_argument &e) {
@@ -52,14 +63,7 @@ template <typename F> int guarded(F &&body) {
   }
 }
 
-// ---- per-device context: one stream, lazily created --------------------------------------------
-struct Context {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  int num_cus = 256;
-};
-Context &ctx();  // context of the current device
-inline hipStream_t stream() { return ctx().stream; }
+inline hipStream_t stream();
 void sync();  // hipStreamSynchronize on the library stream
 
 // ---- launch-time profiler (HIP events on the library stream) ------------------------------------
@@ -97,6 +101,21 @@ template <typename T> struct DeviceArray {
     if (n) IMP_CHECK_HIP(hipMemcpyAsync(data(), host, n * sizeof(T), hipMemcpyHostToDevice, stream()));
   }
 };
+
+// Scratch buffers are per DEVICE (a process may drive several devices through imp_set_device) and are only touched under
+// that device's call lock.
+struct Context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int num_cus = 256;
+  std::recursive_mutex mutex;
+  DeviceArray<float> gram_ws;     // split-K partial gramians (gramian.hip)
+  DeviceArray<float> long_ws;     // partial vectors / CG state of the long rows (als_cg.hip)
+  DeviceArray<double> loss_buf;   // 4 accumulators of the loss kernel (solver.hip)
+  DeviceArray<unsigned long long> chol_failed;  // smallest failing row of a Cholesky sweep (als_cholesky.hip)
+  DeviceArray<float> barrier_word;              // operand of the RCCL barrier (comm.hip)
+};
+inline hipStream_t stream() { return ctx().stream; }
 
 }  // namespace imp
 
@@ -164,6 +183,11 @@ struct imp_csr {
     for (int x = 0; x < 9; ++x) d.xcd_start[x] = xcd_start[x];
     return d;
   }
+  // A matrix with more than 2^31 - 1 nonzeros (imp_csr_create64) is held as consecutive row blocks, each a complete
+  // imp_csr of its own with int32 offsets; the top-level object then only carries rows / cols / nnz and the solver
+  // entry points walk the blocks (every row solve is independent of the others).
+  std::vector<std::unique_ptr<imp_csr>> parts;
+  std::vector<int32_t> part_row0;  // first row of each block
   int32_t nonempty() const { return bin_start[kBins - 1]; }
   int32_t first_empty() const { return bin_start[kBins - 1]; }
   int32_t n_empty() const { return bin_start[kBins] - bin_start[kBins - 1]; }

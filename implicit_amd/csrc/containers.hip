@@ -19,7 +19,8 @@ static thread_local std::string g_last_error;
 void set_last_error(const std::string &msg) { g_last_error = msg; }
 
 static std::mutex g_ctx_mutex;
-static std::map<int, Context> g_contexts;
+// leaked on purpose: the contexts own device buffers, and static destructors run after the HIP runtime has shut down
+static auto &g_contexts = *new std::map<int, std::unique_ptr<Context>>;
 
 Context &ctx() {
   int dev = 0;
@@ -27,15 +28,23 @@ Context &ctx() {
   std::lock_guard<std::mutex> lock(g_ctx_mutex);
   auto it = g_contexts.find(dev);
   if (it == g_contexts.end()) {
-    Context c;
-    c.device = dev;
-    IMP_CHECK_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    auto c = std::make_unique<Context>();
+    c->device = dev;
+    IMP_CHECK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     hipDeviceProp_t prop;
     IMP_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-    c.num_cus = prop.multiProcessorCount;
-    it = g_contexts.emplace(dev, c).first;
+    c->num_cus = prop.multiProcessorCount;
+    it = g_contexts.emplace(dev, std::move(c)).first;
   }
-  return it->second;
+  return *it->second;
+}
+
+std::unique_lock<std::recursive_mutex> lock_device() {
+  try {
+    return std::unique_lock<std::recursive_mutex>(ctx().mutex);
+  } catch (...) {
+    return std::unique_lock<std::recursive_mutex>();  // no usable device: the body reports the error itself
+  }
 }
 
 void sync() { IMP_CHECK_HIP(hipStreamSynchronize(stream())); }
@@ -49,6 +58,7 @@ struct ProfPending {
   const char *name;
   hipEvent_t start, stop;
 };
+static std::recursive_mutex g_prof_mutex;  // the profiler tables are process-wide; per-device call locks do not cover them
 static bool g_prof_on = false;
 static std::string g_prof_filter;
 static std::map<std::string, ProfEntry> g_prof;
@@ -89,6 +99,7 @@ static void prof_collect_finished() {
 
 ProfScope::ProfScope(const char *n) : name(n) {
   if (!g_prof_on) return;
+  std::lock_guard<std::recursive_mutex> plock(g_prof_mutex);
   if (!g_prof_filter.empty() && !strstr(n, g_prof_filter.c_str())) return;
   if (g_event_pool.size() < 2 && g_prof_pending.size() >= 32) prof_collect_finished();
   start = get_event();
@@ -98,11 +109,13 @@ ProfScope::ProfScope(const char *n) : name(n) {
 
 ProfScope::~ProfScope() {
   if (!start) return;
+  std::lock_guard<std::recursive_mutex> plock(g_prof_mutex);
   (void)hipEventRecord(stop, stream());
   g_prof_pending.push_back({name, start, stop});
 }
 
 static void prof_flush() {
+  std::lock_guard<std::recursive_mutex> plock(g_prof_mutex);
   if (g_prof_pending.empty()) return;
   sync();
   for (auto &p : g_prof_pending) prof_account(p);
@@ -419,6 +432,21 @@ int imp_csr_create(int32_t rows, int32_t cols, int64_t nnz, const int32_t *indpt
     if (rows < 0 || cols < 0 || nnz < 0) throw std::invalid_argument("negative dimension for CSRMatrix");
     if (nnz > INT32_MAX) throw std::invalid_argument("CSRMatrix with more than 2^31-1 nonzeros is not supported");
     if (rows && indptr[rows] != nnz) throw std::invalid_argument("indptr[rows] != nonzeros for CSRMatrix");
+    if (rows && indptr[0] != 0) throw std::invalid_argument("indptr[0] != 0 for CSRMatrix");
+    // a malformed matrix would turn into out-of-bounds gathers on the device: indptr must not decrease, column ids
+    // must lie in [0, cols) (scipy's check_format(full_check=True) conditions; one pass over the host arrays)
+    for (int32_t r = 0; r < rows; ++r)
+      if (indptr[r + 1] < indptr[r]) throw std::invalid_argument("indptr must be non-decreasing for CSRMatrix (row " + std::to_string(r) + ")");
+    {
+      int32_t lo = 0, hi = -1;
+      for (int64_t k = 0; k < nnz; ++k) {
+        lo = std::min(lo, indices[k]);
+        hi = std::max(hi, indices[k]);
+      }
+      if (nnz && (lo < 0 || hi >= cols))
+        throw std::invalid_argument("column index out of range for CSRMatrix (" + std::to_string(lo < 0 ? lo : hi) + " not in [0, " +
+                                    std::to_string(cols) + "))");
+    }
     auto m = std::make_unique<imp_csr>();
     m->rows = rows;
     m->cols = cols;
@@ -557,6 +585,47 @@ int imp_csr_create(int32_t rows, int32_t cols, int64_t nnz, const int32_t *indpt
   });
 }
 
+// int64 row offsets (scipy switches indptr AND indices to int64 once nnz >= 2^31; the CPU reference accepts both widths,
+// _als.pyx:76).  Up to `part_limit` nonzeros the matrix is one block; beyond that it is cut into consecutive row blocks of
+// at most that many nonzeros each -- the kernels keep their 32-bit offsets.  IMP_CSR_PART_NNZ lowers the limit (tests).
+int imp_csr_create64(int32_t rows, int32_t cols, int64_t nnz, const int64_t *indptr, const int32_t *indices, const float *data,
+                     imp_csr **out) {
+  return guarded([&] {
+    if (rows < 0 || cols < 0 || nnz < 0) throw std::invalid_argument("negative dimension for CSRMatrix");
+    if (rows && indptr[rows] != nnz) throw std::invalid_argument("indptr[rows] != nonzeros for CSRMatrix");
+    if (rows && indptr[0] != 0) throw std::invalid_argument("indptr[0] != 0 for CSRMatrix");
+    for (int32_t r = 0; r < rows; ++r)
+      if (indptr[r + 1] < indptr[r]) throw std::invalid_argument("indptr must be non-decreasing for CSRMatrix (row " + std::to_string(r) + ")");
+    int64_t part_limit = INT32_MAX;
+    if (const char *e = getenv("IMP_CSR_PART_NNZ")) part_limit = std::max<int64_t>(1, std::min<int64_t>(INT32_MAX, atoll(e)));
+    auto build = [&](int32_t r0, int32_t r1) {
+      std::vector<int32_t> local((size_t)(r1 - r0) + 1);
+      const int64_t base = indptr[r0];
+      for (int32_t r = r0; r <= r1; ++r) local[r - r0] = (int32_t)(indptr[r] - base);
+      imp_csr *part = nullptr;
+      if (imp_csr_create(r1 - r0, cols, indptr[r1] - base, local.data(), indices + base, data + base, &part) != IMP_OK)
+        throw std::invalid_argument(imp_last_error());
+      return std::unique_ptr<imp_csr>(part);
+    };
+    if (nnz <= part_limit) {
+      *out = build(0, rows).release();
+      return;
+    }
+    auto top = std::make_unique<imp_csr>();
+    top->rows = rows, top->cols = cols, top->nnz = nnz;
+    for (int32_t r0 = 0; r0 < rows;) {
+      int32_t r1 = r0;
+      while (r1 < rows && indptr[r1 + 1] - indptr[r0] <= part_limit) ++r1;
+      if (r1 == r0) throw std::invalid_argument("a single row exceeds the per-block nonzero limit of CSRMatrix");
+      top->part_row0.push_back(r0);
+      top->parts.push_back(build(r0, r1));
+      top->max_row = std::max(top->max_row, top->parts.back()->max_row);
+      r0 = r1;
+    }
+    *out = top.release();
+  });
+}
+
 int imp_csr_shape(const imp_csr *m, int32_t *rows, int32_t *cols, int64_t *nonzeros) {
   return guarded([&] {
     if (rows) *rows = m->rows;
@@ -592,24 +661,28 @@ int imp_coo_destroy(imp_coo *m) {
 // ---- profiler -------------------------------------------------------------------------------------
 int imp_prof_enable(int on) {
   return guarded([&] {
+    std::lock_guard<std::recursive_mutex> plock(g_prof_mutex);
     prof_flush();
     g_prof_on = on != 0;
   });
 }
 int imp_prof_filter(const char *substr) {
   return guarded([&] {
+    std::lock_guard<std::recursive_mutex> plock(g_prof_mutex);
     prof_flush();
     g_prof_filter = substr ? substr : "";
   });
 }
 int imp_prof_reset(void) {
   return guarded([&] {
+    std::lock_guard<std::recursive_mutex> plock(g_prof_mutex);
     prof_flush();
     g_prof.clear();
   });
 }
 int imp_prof_get(const char *kernel, double *total_ms, int64_t *launches) {
   return guarded([&] {
+    std::lock_guard<std::recursive_mutex> plock(g_prof_mutex);
     prof_flush();
     auto it = g_prof.find(kernel);
     if (total_ms) *total_ms = it == g_prof.end() ? 0.0 : it->second.total_ms;
@@ -618,6 +691,7 @@ int imp_prof_get(const char *kernel, double *total_ms, int64_t *launches) {
 }
 int imp_prof_names(char *buf, size_t buflen) {
   return guarded([&] {
+    std::lock_guard<std::recursive_mutex> plock(g_prof_mutex);
     prof_flush();
     std::string s;
     for (auto &kv : g_prof) {

@@ -120,11 +120,6 @@ __global__ void gramian_reduce_kernel(const float *__restrict__ ws, int chunks, 
   out[idx] = s;
 }
 
-struct GramWorkspace {
-  DeviceArray<float> ws;
-};
-static GramWorkspace &g_ws = *new GramWorkspace;  // leaked on purpose: no hipFree after runtime teardown
-
 // out (f x f) = Y^T Y + reg I over rows [0, n_rows) of Y
 void gramian(const float *Y, long n_rows, int f, float reg, float *out) {
   const int n_tiles = (f + 31) / 32;
@@ -132,14 +127,17 @@ void gramian(const float *Y, long n_rows, int f, float reg, float *out) {
   long target_chunks = std::max(1, ctx().num_cus * 2 / (gy * gz));
   long rows_per_chunk = std::max<long>(256, (n_rows + target_chunks - 1) / target_chunks);
   rows_per_chunk = (rows_per_chunk + 7) / 8 * 8;
-  int chunks = (int)std::max<long>(1, (n_rows + rows_per_chunk - 1) / rows_per_chunk);
-  size_t need = (size_t)chunks * f * f;
-  if (g_ws.ws.size < need) g_ws.ws.alloc(need);
-  dim3 grid(chunks, gy, gz);
-  {
+  // no rows (an empty Matrix, or an empty shard of the multi-GPU driver): the sum over zero chunks, i.e. reg * I -- what
+  // the reference's GEMM + l2_regularize pair leaves (als.cu:122-152)
+  int chunks = n_rows <= 0 ? 0 : (int)std::max<long>(1, (n_rows + rows_per_chunk - 1) / rows_per_chunk);
+  size_t need = (size_t)std::max(chunks, 1) * f * f;
+  auto &wsbuf = ctx().gram_ws;
+  if (wsbuf.size < need) wsbuf.alloc(need);
+  dim3 grid(std::max(chunks, 1), gy, gz);
+  if (chunks > 0) {
     IMP_PROF("gramian_partial");
     int tj = std::min(n_tiles, 8);
-    float *ws = g_ws.ws.data();
+    float *ws = wsbuf.data();
     switch (tj) {
       case 1: gramian_partial_kernel<1><<<grid, 256, 0, stream()>>>(Y, n_rows, f, rows_per_chunk, ws); break;
       case 2: gramian_partial_kernel<2><<<grid, 256, 0, stream()>>>(Y, n_rows, f, rows_per_chunk, ws); break;
@@ -154,7 +152,7 @@ void gramian(const float *Y, long n_rows, int f, float reg, float *out) {
   }
   {
     IMP_PROF("gramian_reduce");
-    gramian_reduce_kernel<<<(f * f + 63) / 64, 64, 0, stream()>>>(g_ws.ws.data(), chunks, f, reg, out);
+    gramian_reduce_kernel<<<(f * f + 63) / 64, 64, 0, stream()>>>(wsbuf.data(), chunks, f, reg, out);
     IMP_CHECK_HIP(hipGetLastError());
   }
 }

@@ -81,8 +81,6 @@ __global__ void sumsq_rows_kernel(const float *__restrict__ Y, size_t n, double 
   if (threadIdx.x == 0) atomicAdd(out, red[0]);
 }
 
-static double *g_loss_buf = nullptr;
-
 template <int VPL>
 static void launch_loss(const imp_csr *C, const float *X, const float *Y, const float *YtY, int f, double *buf) {
   int grid = std::min((C->rows + 3) / 4, ctx().num_cus * 8);
@@ -90,10 +88,26 @@ static void launch_loss(const imp_csr *C, const float *X, const float *Y, const 
                                                                YtY, f, buf);
 }
 
+// rows of X <-> rows of one block of a (possibly multi-block) CSR matrix
+template <typename Fn> static void for_each_part(const imp_csr *C, const imp_matrix *X, Fn &&fn) {
+  if (C->parts.empty()) {
+    fn(C, X);
+    return;
+  }
+  for (size_t i = 0; i < C->parts.size(); ++i) {
+    imp_matrix view = *X;  // row-range view sharing storage
+    view.rows = (size_t)C->parts[i]->rows;
+    view.data = reinterpret_cast<char *>(X->data) + (size_t)C->part_row0[i] * X->cols * X->itemsize;
+    fn(C->parts[i].get(), &view);
+  }
+}
+
 float calculate_loss(const imp_csr *C, const imp_matrix *X, const imp_matrix *Y, float reg) {
   const int f = (int)X->cols;
   if (f > 512) throw std::invalid_argument("calculate_loss: factors must be <= 512 in this build");
-  if (!g_loss_buf) IMP_CHECK_HIP(hipMalloc(&g_loss_buf, 4 * sizeof(double)));
+  auto &lossb = ctx().loss_buf;
+  if (lossb.size < 4) lossb.alloc(4);
+  double *g_loss_buf = lossb.data();
   IMP_CHECK_HIP(hipMemsetAsync(g_loss_buf, 0, 4 * sizeof(double), stream()));
   DeviceArray<float> yty;
   yty.alloc((size_t)f * f);
@@ -101,14 +115,16 @@ float calculate_loss(const imp_csr *C, const imp_matrix *X, const imp_matrix *Y,
   {
     IMP_PROF("als_loss_rows");
     int vpl = (f + 63) / 64;
-    switch (vpl) {
-      case 1: launch_loss<1>(C, X->f32(), Y->f32(), yty.data(), f, g_loss_buf); break;
-      case 2: launch_loss<2>(C, X->f32(), Y->f32(), yty.data(), f, g_loss_buf); break;
-      case 3: launch_loss<3>(C, X->f32(), Y->f32(), yty.data(), f, g_loss_buf); break;
-      case 4: launch_loss<4>(C, X->f32(), Y->f32(), yty.data(), f, g_loss_buf); break;
-      default: launch_loss<8>(C, X->f32(), Y->f32(), yty.data(), f, g_loss_buf); break;
-    }
-    IMP_CHECK_HIP(hipGetLastError());
+    for_each_part(C, X, [&](const imp_csr *part, const imp_matrix *x) {
+      switch (vpl) {
+        case 1: launch_loss<1>(part, x->f32(), Y->f32(), yty.data(), f, g_loss_buf); break;
+        case 2: launch_loss<2>(part, x->f32(), Y->f32(), yty.data(), f, g_loss_buf); break;
+        case 3: launch_loss<3>(part, x->f32(), Y->f32(), yty.data(), f, g_loss_buf); break;
+        case 4: launch_loss<4>(part, x->f32(), Y->f32(), yty.data(), f, g_loss_buf); break;
+        default: launch_loss<8>(part, x->f32(), Y->f32(), yty.data(), f, g_loss_buf); break;
+      }
+      IMP_CHECK_HIP(hipGetLastError());
+    });
     size_t n = Y->rows * Y->cols;
     if (n) {
       int grid = (int)std::min<size_t>((n + 255) / 256, (size_t)ctx().num_cus * 4);
@@ -128,8 +144,10 @@ static void check_solver_args(const imp_csr *C, const imp_matrix *X, const imp_m
   if (X->cols != Y->cols) throw std::invalid_argument("X and Y should have the same number of columns");
   if (X->cols != YtY->cols) throw std::invalid_argument("Columns of X don't match number of columns of YtY");
   if (YtY->rows != YtY->cols) throw std::invalid_argument("YtY must be square");
-  if ((size_t)C->rows != X->rows) throw std::invalid_argument("Dimensionality mismatch between rows of Cui and rows of X");
-  if ((size_t)C->cols != Y->rows) throw std::invalid_argument("Dimensionality mismatch between cols of Cui and rows of Y");
+  // as als.cu:162-165: Cui may be SMALLER than the factor matrices (the reference's own partial_fit_items passes a row
+  // whose column count predates users added since, tests/als_test.py:273-301); only the first Cui.rows rows of X are solved
+  if ((size_t)C->rows > X->rows) throw std::invalid_argument("Dimensionality mismatch between rows of Cui and rows of X");
+  if ((size_t)C->cols > Y->rows) throw std::invalid_argument("Dimensionality mismatch between cols of Cui and rows of Y");
   if (X->itemsize != Y->itemsize) throw std::invalid_argument("X and Y should have the same dtype");
   if (YtY->itemsize != 4) throw std::invalid_argument("YtY must be float32");
 }
@@ -199,7 +217,9 @@ int imp_solver_least_squares(imp_solver *, const imp_csr *cui, imp_matrix *X, co
     check_solver_args(cui, X, YtY, Y);
     if (cg_steps < 0) throw std::invalid_argument("cg_steps must be >= 0");
     run_with_f32(cui, X, Y, [&](imp_matrix *x, const imp_matrix *y) {
-      least_squares_cg(cui, x, YtY, y, cg_steps);
+      for_each_part(cui, x, [&](const imp_csr *part, const imp_matrix *xp) {
+        least_squares_cg(part, const_cast<imp_matrix *>(xp), YtY, y, cg_steps);
+      });
       sync();
     });
   });
@@ -210,7 +230,14 @@ int imp_solver_least_squares_cholesky(imp_solver *, const imp_csr *cui, imp_matr
   return guarded([&] {
     check_solver_args(cui, X, YtY, Y);
     int64_t failed = -1;
-    run_with_f32(cui, X, Y, [&](imp_matrix *x, const imp_matrix *y) { failed = least_squares_cholesky(cui, x, YtY, y, regularization); });
+    run_with_f32(cui, X, Y, [&](imp_matrix *x, const imp_matrix *y) {
+      size_t block = 0;
+      for_each_part(cui, x, [&](const imp_csr *part, const imp_matrix *xp) {
+        const int64_t bad = least_squares_cholesky(part, const_cast<imp_matrix *>(xp), YtY, y, regularization);
+        if (bad >= 0 && failed < 0) failed = bad + (cui->parts.empty() ? 0 : cui->part_row0[block]);
+        ++block;
+      });
+    });
     if (failed_row) *failed_row = failed;
     if (failed >= 0)
       throw std::invalid_argument("cholesky factorisation failed on row " + std::to_string(failed) +

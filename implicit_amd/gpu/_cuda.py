@@ -84,7 +84,18 @@ class Matrix:
         if cai:
             shape = cai["shape"]
             data = cai["data"][0]
-            itemsize = int(cai["typestr"][2])
+            typestr = cai["typestr"]
+            if typestr not in ("<f4", "<f2", "=f4", "=f2", "|f4", "|f2"):
+                raise ValueError(f"unhandled dtype for GPU Matrix {typestr} (float32 / float16 only)")
+            if len(shape) != 2:
+                raise ValueError("Matrix expects a 2 dimensional array")
+            itemsize = int(typestr[2])
+            strides = cai.get("strides")
+            if strides is not None and tuple(strides) != (shape[1] * itemsize, itemsize):
+                raise ValueError("Matrix can only wrap C-contiguous device arrays")
+            # the library works on its own non-blocking stream: order it after whatever the producer still has in
+            # flight (the reference runs on the legacy default stream, which is implicitly ordered)
+            synchronize()
             check(lib().imp_matrix_wrap_device(shape[0], shape[1], ctypes.c_void_p(data), itemsize,
                                                ctypes.byref(self._h)))
             self._keepalive = X  # no ownership of the memory: keep the exporter alive
@@ -233,12 +244,25 @@ class CSRMatrix:
 
     def __init__(self, X):
         X = check_csr(X)
-        indptr = _int32_buffer(X.indptr, "indptr")
-        indices = _int32_buffer(X.indices, "indices")
         data = np.ascontiguousarray(X.data.astype(np.float32))
         self._h = ctypes.c_void_p()
         self.shape = X.shape
         self.nnz = len(data)
+        if np.asarray(X.indptr).dtype == np.int64:
+            # NEW: the reference binds int32 buffers only (a ValueError for int64); scipy switches both index arrays to
+            # int64 once nnz >= 2^31, and the CPU solver accepts that (_als.pyx:76).  Column ids always fit int32.
+            indptr = np.ascontiguousarray(X.indptr)
+            indices = np.asarray(X.indices)
+            if indices.dtype != np.int32:
+                if len(indices) and (indices.max() > np.iinfo(np.int32).max or indices.min() < 0):
+                    raise ValueError("column index out of range for CSRMatrix")
+                indices = indices.astype(np.int32)
+            indices = np.ascontiguousarray(indices)
+            check(lib().imp_csr_create64(X.shape[0], X.shape[1], len(data), _vp(indptr), _vp(indices), _vp(data),
+                                         ctypes.byref(self._h)))
+            return
+        indptr = _int32_buffer(X.indptr, "indptr")
+        indices = _int32_buffer(X.indices, "indices")
         check(lib().imp_csr_create(X.shape[0], X.shape[1], len(data), _vp(indptr), _vp(indices), _vp(data),
                                    ctypes.byref(self._h)))
 
@@ -280,8 +304,12 @@ class LeastSquaresSolver:
         """NEW: mirrors the CPU implicit.cpu._als._least_squares(YtY, ..., regularization): YtY is
         the UNregularised gramian; raises ValueError on a non-positive-definite row."""
         failed = ctypes.c_int64(-1)
-        check(lib().imp_solver_least_squares_cholesky(self._h, cui._h, X._h, YtY._h, Y._h,
-                                                      float(regularization), ctypes.byref(failed)))
+        try:
+            check(lib().imp_solver_least_squares_cholesky(self._h, cui._h, X._h, YtY._h, Y._h,
+                                                          float(regularization), ctypes.byref(failed)))
+        except ValueError as e:
+            e.failed_row = failed.value  # -1 unless the factorisation itself failed (then: the smallest failing row)
+            raise
 
     def calculate_loss(self, cui, X, Y, regularization):
         loss = ctypes.c_float(0)

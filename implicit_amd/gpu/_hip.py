@@ -40,6 +40,8 @@ _SIGNATURES = {
     "imp_intvector_destroy": [ctypes.c_void_p],
     "imp_csr_create": [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                        ctypes.c_void_p, c_void_pp],
+    "imp_csr_create64": [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                         ctypes.c_void_p, c_void_pp],
     "imp_csr_shape": [ctypes.c_void_p, c_i32_p, c_i32_p, ctypes.POINTER(ctypes.c_int64)],
     "imp_csr_destroy": [ctypes.c_void_p],
     "imp_coo_create": [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,

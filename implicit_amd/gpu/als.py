@@ -15,7 +15,11 @@ numerics of the reference's *CPU* path, which is the parity oracle (implicit/cpu
     (gpu/als.py:188-195);
   * NaN factors after fit raise ModelFitError (cpu/als.py:202).
 
-Multi-GPU (`comm=`): one process per GPU; see implicit_amd/gpu/sharded.py.
+Multi-GPU: `AlternatingLeastSquares(..., comm=implicit_amd.gpu.Comm(...))`, one process per GPU, every rank calling
+fit() with the same matrix (implicit_amd/gpu/sharded.py: rows sharded by nnz, RCCL all-reduce of the gramian and
+all-gather of the solved factor rows; all ranks end with identical full factors).  `rendezvous.init_comm(gpu)` builds the
+communicator from the launcher's RANK / WORLD_SIZE / MASTER_* environment.  No reference counterpart
+(implicit/gpu/als.cu:169 "TODO: multi-gpu support").
 """
 import logging
 import time
@@ -34,7 +38,7 @@ _CHOLESKY_MAX_FACTORS = 160
 
 class AlternatingLeastSquares(MatrixFactorizationBase):
     def __init__(self, factors=64, regularization=0.01, alpha=1.0, dtype=np.float32, iterations=15,
-                 calculate_training_loss=False, random_state=None, use_cg=True, cg_steps=3, init="numpy"):
+                 calculate_training_loss=False, random_state=None, use_cg=True, cg_steps=3, init="numpy", comm=None):
         if not gpu.HAS_CUDA:
             raise ValueError("No usable HIP device / extension, can't train on GPU.")
         super().__init__()
@@ -48,10 +52,11 @@ class AlternatingLeastSquares(MatrixFactorizationBase):
         self.use_cg = use_cg
         self.cg_steps = cg_steps
         self.init = init
+        self.comm = comm
         self.fit_callback = None
         self._solver = None
-        self._YtY = None
-        self._XtX = None
+        self._YtY = self._XtX = None      # regularised gramians (the reference's cached properties)
+        self._YtY0 = self._XtX0 = None    # unregularised ones, for the Cholesky fold-in
 
     # ---- training ----------------------------------------------------------------------------------
     def _initial_factors(self, users, items):
@@ -87,7 +92,10 @@ class AlternatingLeastSquares(MatrixFactorizationBase):
         self._initial_factors(users, items)
         self._item_norms = self._user_norms = None
         self._item_norms_host = self._user_norms_host = None
-        self._YtY = self._XtX = None
+        self._YtY = self._XtX = self._YtY0 = self._XtX0 = None
+
+        if self.comm is not None and self.comm.nranks > 1:
+            return self._fit_sharded(Cui, Ciu, callback)
 
         Cui_dev, Ciu_dev = gpu.CSRMatrix(Cui), gpu.CSRMatrix(Ciu)
         X, Y = self.user_factors, self.item_factors
@@ -111,6 +119,25 @@ class AlternatingLeastSquares(MatrixFactorizationBase):
             log.info("Final training loss %s", loss)
         self._check_fit_errors()
 
+    def _fit_sharded(self, Cui, Ciu, callback):
+        from . import sharded
+
+        if not self.use_cg:
+            raise ValueError("the multi-GPU fit runs the CG solver (use_cg=True)")
+        if self.dtype != np.float32:
+            raise ValueError("the multi-GPU fit keeps float32 factor replicas")
+        # every rank must start from the same factors whatever its random_state: rank 0's win (the others contribute
+        # zeros to a sum all-reduce)
+        for m in (self.user_factors, self.item_factors):
+            if self.comm.rank != 0:
+                m.copy_from_numpy(np.zeros(m.shape, dtype=np.float32))
+            self.comm.allreduce_sum(m)
+        sharded.fit_sharded(self, Cui, Ciu, self.comm, callback or self.fit_callback)
+        if self.calculate_training_loss:
+            loss = self.solver.calculate_loss(gpu.CSRMatrix(Cui), self.user_factors, self.item_factors, self.regularization)
+            log.info("Final training loss %s", loss)
+        self._check_fit_errors()
+
     def _half_sweep(self, C, X, Y, gram):
         """One half iteration: X <- argmin given Y (gramian + per-row solves)."""
         if self.use_cg:
@@ -121,7 +148,7 @@ class AlternatingLeastSquares(MatrixFactorizationBase):
             self.solver.least_squares_cholesky(C, X, gram, Y, self.regularization)
 
     # ---- fold-in -----------------------------------------------------------------------------------
-    def _recalculate(self, ids, rows_csr, other_factors, gram_reg, gram_unreg_fn):
+    def _recalculate(self, ids, rows_csr, other_factors, gram_reg_fn, gram_unreg_fn):
         rows_csr = check_csr(rows_csr)
         count = 1 if np.isscalar(ids) else len(ids)
         if rows_csr.shape[0] != count:
@@ -130,19 +157,18 @@ class AlternatingLeastSquares(MatrixFactorizationBase):
             rows_csr = self.alpha * rows_csr
         out = gpu.Matrix.zeros(count, self.factors).astype(self.dtype)
         C = gpu.CSRMatrix(rows_csr.astype(np.float32))
+        # only the gramian the chosen solver needs is evaluated, and both are cached until the factors change
         if self.factors <= _CHOLESKY_MAX_FACTORS:
             self.solver.least_squares_cholesky(C, out, gram_unreg_fn(), other_factors, self.regularization)
         else:
-            self.solver.least_squares(C, out, gram_reg, other_factors, self.factors)
+            self.solver.least_squares(C, out, gram_reg_fn(), other_factors, self.factors)
         return out[0] if np.isscalar(ids) else out
 
     def recalculate_user(self, userid, user_items):
-        return self._recalculate(userid, user_items, self.item_factors, self.YtY,
-                                 lambda: self._gram(self.item_factors, 0.0))
+        return self._recalculate(userid, user_items, self.item_factors, lambda: self.YtY, lambda: self._YtY_unreg)
 
     def recalculate_item(self, itemid, item_users):
-        return self._recalculate(itemid, item_users, self.user_factors, self.XtX,
-                                 lambda: self._gram(self.user_factors, 0.0))
+        return self._recalculate(itemid, item_users, self.user_factors, lambda: self.XtX, lambda: self._XtX_unreg)
 
     def partial_fit_users(self, userids, user_items):
         if len(userids) != user_items.shape[0]:
@@ -154,7 +180,7 @@ class AlternatingLeastSquares(MatrixFactorizationBase):
         self.user_factors.assign_rows(userids, _as_f32(new_rows)) if self.dtype == np.float32 else \
             self._assign_half(self.user_factors, userids, new_rows)
         self._user_norms = self._user_norms_host = None
-        self._XtX = None
+        self._XtX = self._XtX0 = None
 
     def partial_fit_items(self, itemids, item_users):
         if len(itemids) != item_users.shape[0]:
@@ -166,7 +192,7 @@ class AlternatingLeastSquares(MatrixFactorizationBase):
         self.item_factors.assign_rows(itemids, _as_f32(new_rows)) if self.dtype == np.float32 else \
             self._assign_half(self.item_factors, itemids, new_rows)
         self._item_norms = self._item_norms_host = None
-        self._YtY = None
+        self._YtY = self._YtY0 = None
 
     @staticmethod
     def _assign_half(target, ids, new_rows):
@@ -198,6 +224,34 @@ class AlternatingLeastSquares(MatrixFactorizationBase):
         if self._XtX is None:
             self._XtX = self._gram(self.user_factors, self.regularization)
         return self._XtX
+
+    @property
+    def _YtY_unreg(self):
+        if self._YtY0 is None:
+            self._YtY0 = self._gram(self.item_factors, 0.0)
+        return self._YtY0
+
+    @property
+    def _XtX_unreg(self):
+        if self._XtX0 is None:
+            self._XtX0 = self._gram(self.user_factors, 0.0)
+        return self._XtX0
+
+    def to_cpu(self):
+        """implicit/gpu/als.py:300-313: the same model as the reference's CPU class.  This package does not ship a CPU
+        model (the reference's is the parity oracle), so stock `implicit` has to be importable."""
+        try:
+            import implicit.cpu.als as cpu_als
+        except ImportError as e:
+            raise ImportError("to_cpu() builds implicit.cpu.als.AlternatingLeastSquares: install benfred/implicit for the "
+                              "CPU model (implicit_amd ships the MI355X path only)") from e
+        ret = cpu_als.AlternatingLeastSquares(factors=self.factors, regularization=self.regularization, alpha=self.alpha,
+                                              dtype=np.float32, iterations=self.iterations, use_cg=self.use_cg,
+                                              calculate_training_loss=self.calculate_training_loss,
+                                              random_state=self.random_state)
+        ret.user_factors = None if self.user_factors is None else self.user_factors.to_numpy().astype(np.float32)
+        ret.item_factors = None if self.item_factors is None else self.item_factors.to_numpy().astype(np.float32)
+        return ret
 
     # ---- persistence (same .npz keys as implicit/cpu/als.py:458-477 so stock implicit can load it) ----
     def save(self, fileobj_or_path):
@@ -231,6 +285,8 @@ class AlternatingLeastSquares(MatrixFactorizationBase):
     def __getstate__(self):
         state = super().__getstate__()
         state["_solver"] = None
+        state["comm"] = None  # a communicator belongs to a process group, not to a model file
+        state["_XtX0"] = state["_YtY0"] = None
         state["_XtX"] = self._XtX.to_numpy() if self._XtX is not None else None
         state["_YtY"] = self._YtY.to_numpy() if self._YtY is not None else None
         return state

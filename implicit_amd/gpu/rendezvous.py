@@ -1,0 +1,93 @@
+"""Rank rendezvous for the multi-GPU driver without torch: the only thing the ranks must agree on before RCCL
+exists is the 128-byte communicator id, which rank 0 creates (imp_comm_unique_id) and hands to the others over
+one short-lived TCP connection each.  Everything after that -- barriers, the max over ranks of the timed
+region -- goes through the RCCL communicator itself (implicit_amd.gpu.Comm).
+
+The launcher's environment is the one `python -m torch.distributed.run` / torchrun sets (the bench driver uses
+it): RANK, WORLD_SIZE, LOCAL_RANK, MASTER_ADDR, MASTER_PORT.  MASTER_PORT itself belongs to the launcher's own
+store, so the exchange listens on MASTER_PORT + 1 + IMP_RDZV_PORT_OFFSET (override the absolute port with
+IMP_RDZV_PORT).  No reference counterpart (implicit/gpu/als.cu:169 "TODO: multi-gpu support").
+"""
+import os
+import socket
+import struct
+import time
+
+_MAGIC = b"IMPRDZV1"
+
+
+def env_world():
+    """(rank, world_size, local_rank) from the launcher's environment (defaults: a single rank)."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    return rank, world, int(os.environ.get("LOCAL_RANK", str(rank)))
+
+
+def _endpoint():
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    if "IMP_RDZV_PORT" in os.environ:
+        return addr, int(os.environ["IMP_RDZV_PORT"])
+    port = int(os.environ.get("MASTER_PORT", "29500")) + 1 + int(os.environ.get("IMP_RDZV_PORT_OFFSET", "0"))
+    return addr, 1024 + (port - 1024) % (65536 - 1024)
+
+
+def _recv_exact(conn, n):
+    buf = b""
+    while len(buf) < n:
+        chunk = conn.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("rendezvous peer closed the connection early")
+        buf += chunk
+    return buf
+
+
+def broadcast_bytes(payload, rank, world, timeout=300.0):
+    """Rank 0 passes `payload` (bytes), the others pass None; every rank returns rank 0's bytes."""
+    if world == 1:
+        return payload
+    addr, port = _endpoint()
+    deadline = time.time() + timeout
+    if rank == 0:
+        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        srv.bind(("", port))
+        srv.listen(world)
+        srv.settimeout(timeout)
+        served = set()
+        try:
+            while len(served) < world - 1:
+                conn, _ = srv.accept()
+                with conn:
+                    conn.settimeout(timeout)
+                    hello = _recv_exact(conn, len(_MAGIC) + 4)
+                    if hello[:len(_MAGIC)] != _MAGIC:
+                        continue  # not one of ours
+                    peer = struct.unpack("<i", hello[len(_MAGIC):])[0]
+                    conn.sendall(struct.pack("<q", len(payload)) + payload)
+                    served.add(peer)
+        finally:
+            srv.close()
+        return payload
+    last = None
+    while time.time() < deadline:
+        try:
+            with socket.create_connection((addr, port), timeout=5.0) as conn:
+                conn.settimeout(timeout)
+                conn.sendall(_MAGIC + struct.pack("<i", rank))
+                n = struct.unpack("<q", _recv_exact(conn, 8))[0]
+                return _recv_exact(conn, n)
+        except (ConnectionError, OSError) as e:  # rank 0 is not listening yet
+            last = e
+            time.sleep(0.2)
+    raise TimeoutError(f"rendezvous with rank 0 at {addr}:{port} failed: {last}")
+
+
+def init_comm(gpu, rank=None, world=None, local_rank=None):
+    """Sets the device, exchanges the RCCL id and returns an implicit_amd.gpu.Comm for this rank."""
+    env = env_world()
+    rank = env[0] if rank is None else rank
+    world = env[1] if world is None else world
+    local_rank = env[2] if local_rank is None else local_rank
+    gpu.set_device(local_rank)
+    uid = broadcast_bytes(gpu.Comm.unique_id() if rank == 0 else None, rank, world)
+    return gpu.Comm(uid, world, rank)

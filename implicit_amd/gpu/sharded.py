@@ -13,6 +13,10 @@ scheme keeps every per-row solve byte-for-byte the single-GPU kernel (DESIGN.md,
 
 Per iteration and rank: two f x f all-reduces and two all-gathers moving (N-1)/N of X and of Y.
 The only arithmetic difference from one GPU is the summation order of the gramian across ranks.
+(north_star's literal scheme -- users sharded only, the item side as a replicated-state CG with an all-reduce
+of an I x f buffer per CG pass -- moves fewer bytes over xGMI at U >> I but re-streams every gathered factor row
+1 + cg_steps times from HBM, because no row's nonzeros are local to one GPU any more; DESIGN.md section 6 has the
+numbers for BASELINE configs[3].)
 
 The driver below is written against two small interfaces so that its logic (shard plan, exchange
 order, views) is exercised on CPU by tests/test_sharded_gloo.py with a gloo communicator and the
@@ -45,9 +49,9 @@ def shard_offsets(n_rows, nranks, weights=None):
 class GpuBackend:
     """The real thing: implicit_amd.gpu objects (HIP kernels through the C-ABI)."""
 
-    def __init__(self, gpu):
+    def __init__(self, gpu, solver=None):
         self.gpu = gpu
-        self.solver = gpu.LeastSquaresSolver()
+        self.solver = solver or gpu.LeastSquaresSolver()
 
     def calculate_yty(self, rows, gram, reg):
         self.solver.calculate_yty(rows, gram, reg)
@@ -104,60 +108,93 @@ def iteration(backend, comm, Cui_shard, Ciu_shard, X_full, Y_full, u_offsets, i_
     half_sweep(backend, comm, Ciu_shard, Y_full, i_offsets, X_full, u_offsets, gram, reg, cg_steps)
 
 
-# ---- synthetic weak-scaling workload + benchmark driver (bench.py --gpus N) -----------------------------
+# ---- model-level entry: AlternatingLeastSquares(..., comm=...).fit ------------------------------------------------------
 
 
-def weak_scaling_shards(rank, nranks, users, items, nnz, gamma, seed=42):
-    """Rank `rank`'s pieces of the global (nranks*users) x (nranks*items) matrix whose user block s is
-    synthetic_csr(users, nranks*items, nnz, seed=seed+s).  Every rank regenerates all blocks (cheap,
-    deterministic, no host-side exchange) and keeps (a) its own user block as CSR with global item
-    ids and (b) the columns of its item range from every block, transposed, as CSR with global user
-    ids."""
-    import scipy.sparse as sp
+def fit_sharded(model, Cui, Ciu, comm, callback=None, chunks=None):
+    """The iterations of AlternatingLeastSquares.fit on `comm.nranks` GPUs.  Every rank calls it with the SAME full
+    matrices (scipy CSR, users x items and its transpose) and the same initial factors in model.user_factors /
+    item_factors; rows are cut by nnz weight, every rank keeps its own rows of both orientations on the device, and
+    all ranks finish with identical full factor matrices."""
+    import time
 
-    from ..synthetic import synthetic_csr
+    import implicit_amd.gpu as gpu
 
-    total_items = nranks * items
-    i0, i1 = rank * items, (rank + 1) * items
-    pieces, mine, total_nnz = [], None, 0
-    for s in range(nranks):
-        block = synthetic_csr(users, total_items, nnz, gamma=gamma, seed=seed + s)
-        total_nnz += block.nnz
-        if s == rank:
-            mine = block
-        pieces.append(block[:, i0:i1].T.tocsr())  # items x users-of-block-s
-    item_rows = sp.hstack(pieces, format="csr").astype(np.float32)
-    item_rows.sort_indices()
-    if item_rows.indices.dtype != np.int32:
-        item_rows.indices = item_rows.indices.astype(np.int32)
-        item_rows.indptr = item_rows.indptr.astype(np.int32)
-    return mine, item_rows, total_nnz
+    r, n = comm.rank, comm.nranks
+    u_off = shard_offsets(Cui.shape[0], n, weights=np.diff(Cui.indptr))
+    i_off = shard_offsets(Ciu.shape[0], n, weights=np.diff(Ciu.indptr))
+    mine_u, mine_i = Cui[u_off[r]:u_off[r + 1]], Ciu[i_off[r]:i_off[r + 1]]
+    if chunks is None:
+        chunks = 4 if n > 1 else 1
+    if chunks > 1:
+        Cu = [gpu.CSRMatrix(c) for c in split_rows(mine_u, chunks)]
+        Ci = [gpu.CSRMatrix(c) for c in split_rows(mine_i, chunks)]
+    else:
+        Cu, Ci = gpu.CSRMatrix(mine_u), gpu.CSRMatrix(mine_i)
+    backend = GpuBackend(gpu, solver=model.solver)
+    gram = gpu.Matrix.zeros(model.factors, model.factors)
+    X, Y = model.user_factors, model.item_factors
+    for it in range(model.iterations):
+        t0 = time.time()
+        iteration(backend, comm, Cu, Ci, X, Y, u_off, i_off, gram, model.regularization, model.cg_steps)
+        if callback:
+            gpu.synchronize()
+            callback(it, time.time() - t0, None)
+    gpu.synchronize()
+    comm.barrier()
 
 
-def bench(args, gpu, users, items, nnz_target, gamma, factors, reg, cg_steps, roofline_fn=None):
-    """Weak-scaling benchmark body for WORLD_SIZE > 1 (launched by torch.distributed.run).  torch is
-    used ONLY for rendezvous (RCCL unique id), the barrier around the timed region and the max over
-    ranks; the data path is RCCL inside libimplicit_hip.so."""
-    import datetime
+# ---- synthetic workloads + benchmark driver (bench.py --gpus N) -------------------------------------------------------
+
+
+def rank_sum(comm, gpu, value):
+    """Exact sum of a non-negative integer over the ranks through the fp32 all-reduce (split into 16-bit limbs)."""
+    limbs = [(int(value) >> (16 * k)) & 0xFFFF for k in range(4)]
+    m = gpu.Matrix(np.array([limbs], dtype=np.float32))
+    comm.allreduce_sum(m)
+    back = m.to_numpy()[0]
+    return sum(int(round(float(back[k]))) << (16 * k) for k in range(4))
+
+
+def rank_max(comm, gpu, value):
+    """Max of a float over the ranks: every rank writes its slot of a zero vector, the all-reduce fills in the rest."""
+    slots = np.zeros((1, comm.nranks), dtype=np.float32)
+    slots[0, comm.rank] = value
+    m = gpu.Matrix(slots)
+    comm.allreduce_sum(m)
+    return float(m.to_numpy().max())
+
+
+def bench(args, gpu, shapes, factors, reg, cg_steps, roofline_fn=None):
+    """Benchmark body for WORLD_SIZE > 1, one process per GPU (launched by torch.distributed.run, whose environment
+    variables are all that is used of it: the rendezvous is a TCP hand-off of the RCCL id, barriers and the max over
+    ranks go through RCCL).  Default: STRONG scaling on BASELINE configs[3] (10 M users x 1 M items x 500 M nnz,
+    f = 128, user- and item-sharded); --weak: one BASELINE configs[2]-shaped shard per GPU."""
     import os
 
-    import torch
-    import torch.distributed as dist
+    from ..synthetic import grid_shards
+    from . import rendezvous
 
-    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    local_rank = int(os.environ.get("LOCAL_RANK", rank))
-    dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=30))
-    box = [gpu.Comm.unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(box, src=0)
-    comm = gpu.Comm(box[0], world, rank)
-
+    rank, world, local_rank = rendezvous.env_world()
+    comm = rendezvous.init_comm(gpu, rank, world, local_rank)
     t0 = time.time()
-    Cui, Ciu, total_nnz = weak_scaling_shards(rank, world, users, items, nnz_target, gamma)
-    u_off = np.arange(world + 1, dtype=np.int64) * users
-    i_off = np.arange(world + 1, dtype=np.int64) * items
-    rng = np.random.default_rng(7)
-    X0 = rng.random((world * users, factors), dtype=np.float32) * 0.01  # same seed on every rank: replicas agree
-    Y0 = rng.random((world * items, factors), dtype=np.float32) * 0.01
+    if args.weak:
+        users, items, nnz_target, gamma = shapes[args.shape]
+        users_total, items_total, nnz_total, grid = world * users, world * items, world * nnz_target, world
+        label = (f"weak scaling: one BASELINE configs[2]-shaped shard per GPU ({args.shape}), global {users_total} users x "
+                 f"{items_total} items")
+        scaling = "weak"
+    else:
+        shape = args.shape if args.shape != "lastfm360k" else "c4"
+        users_total, items_total, nnz_total, gamma = shapes[shape]
+        grid = 8 if 8 % world == 0 else world  # the matrix is a function of the grid, not of the rank count
+        label = (f"BASELINE configs[3]: {users_total} users x {items_total} items, synthetic CSR composed of {grid} x {grid} "
+                 f"blocks, users and items sharded over {world} GPU(s)")
+        scaling = "strong"
+    if args.scale != 1.0:
+        users_total, items_total, nnz_total = (int(users_total * args.scale), int(items_total * args.scale),
+                                               int(nnz_total * args.scale))
+    Cui, Ciu, u_off, i_off = grid_shards(rank, world, users_total, items_total, nnz_total, grid, gamma=gamma, seed=42)
     t_gen = time.time() - t0
 
     backend = GpuBackend(gpu)
@@ -169,18 +206,18 @@ def bench(args, gpu, users, items, nnz_target, gamma, factors, reg, cg_steps, ro
         Ciu_d = [gpu.CSRMatrix(c) for c in split_rows(Ciu, chunks)]
     else:
         Cui_d, Ciu_d = gpu.CSRMatrix(Cui), gpu.CSRMatrix(Ciu)
-    X, Y = gpu.Matrix(X0), gpu.Matrix(Y0)
-    del X0, Y0
+    # replicas drawn on the device from the same Philox seed on every rank (5 GB at configs[3]: no host copy)
+    X = gpu.RandomState(7).uniform(users_total, factors, 0.0, 0.01)
+    Y = gpu.RandomState(8).uniform(items_total, factors, 0.0, 0.01)
     gram = gpu.Matrix.zeros(factors, factors)
+    total_nnz = rank_sum(comm, gpu, Cui.nnz)
 
     def step():
         iteration(backend, comm, Cui_d, Ciu_d, X, Y, u_off, i_off, gram, reg, cg_steps)
 
     def fence():
         gpu.synchronize()
-        if torch.cuda.is_available():
-            torch.cuda.synchronize(local_rank)
-        dist.barrier()
+        comm.barrier()
 
     for _ in range(args.warmup):
         step()
@@ -195,42 +232,43 @@ def bench(args, gpu, users, items, nnz_target, gamma, factors, reg, cg_steps, ro
     fence()
     elapsed = time.perf_counter() - t0
     gpu.Profiler.enable(False)
-    t = torch.tensor([elapsed], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    timed = {k: gpu.Profiler.get(k) for k in gpu.Profiler.names()}
+    elapsed = rank_max(comm, gpu, elapsed)
 
-    kernels = {}
-    for name in gpu.Profiler.names():
-        ms, n = gpu.Profiler.get(name)
-        kernels[name] = ms / args.steps
+    # untimed extra iteration with events on everything: where rank 0's time goes (kernels vs exchange)
+    gpu.Profiler.reset()
+    gpu.Profiler.enable(True)
+    step()
+    fence()
+    gpu.Profiler.enable(False)
+    kernels = {name: gpu.Profiler.get(name)[0] for name in gpu.Profiler.names()}
     step_s = elapsed / args.steps
     result = {
         "metric": "ALS user+item updates/sec per iteration (factors=128)",
-        "value": world * (users + items) / step_s,
+        "value": (users_total + items_total) / step_s,
         "unit": "updates/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * step_s,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": scaling,
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"weak scaling: one BASELINE configs[2]-shaped shard per GPU ({args.shape}), "
-                        f"global {world * users} users x {world * items} items, ALS CG cg_steps={cg_steps}",
-            "users": world * users, "items": world * items, "nnz": int(total_nnz), "factors": factors,
+            "workload": f"{label}, ALS CG cg_steps={cg_steps}" + ("" if args.scale == 1.0 else f" (scaled x{args.scale})"),
+            "users": users_total, "items": items_total, "nnz": int(total_nnz), "factors": factors,
             "regularization": reg, "solver": "cg", "cg_steps": cg_steps,
             "parallelism": f"row-sharded x{world}, RCCL all-reduce(f x f) + all-gather(factor shards) pipelined in "
                            f"{chunks} row chunk(s) per half sweep",
         },
         "nnz_visits_per_s": 2 * int(total_nnz) / step_s,
-        "roofline": roofline_fn(Cui, Ciu, {k: gpu.Profiler.get(k) for k in gpu.Profiler.names()}, args.steps)
-        if (roofline_fn and rank == 0) else None,
+        "roofline": roofline_fn(Cui, Ciu, timed, args.steps) if (roofline_fn and rank == 0) else None,
         "kernels_ms_per_step_rank0": kernels,
+        "rank0_shard": {"user_rows": int(Cui.shape[0]), "item_rows": int(Ciu.shape[0]), "user_nnz": int(Cui.nnz),
+                        "item_nnz": int(Ciu.nnz)},
         "setup_s": {"generate": t_gen},
     }
-    dist.barrier()
-    dist.destroy_process_group()
+    fence()
     return result

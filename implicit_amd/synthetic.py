@@ -55,3 +55,73 @@ def named(name, seed=42, scale=1.0, **kw):
     if scale != 1.0:
         users, items, nnz = max(int(users * scale), 8), max(int(items * scale), 8), max(int(nnz * scale), 8)
     return synthetic_csr(users, items, nnz, gamma=gamma, seed=seed, **kw)
+
+
+# ---- block-composed matrices for the multi-GPU driver ---------------------------------------------------------------
+#
+# A global (users x items) matrix is DEFINED as a grid x grid composition of independent blocks: block (s, t) covers user
+# range s and item range t (equal splits), holds ~nnz / grid^2 entries, and is a deterministic function of
+# (seed, s, t) alone -- so a rank can produce exactly the blocks it owns (its user rows: one block row; its item rows:
+# one block column) without generating, or communicating, anything else.  Every block has the same power-law item
+# popularity, i.e. popular items are spread evenly over the item ranges (what relabelling item ids round-robin by
+# popularity does to a real catalogue), so contiguous item shards carry equal work.  The matrix depends on `grid`, not
+# on the number of ranks: with grid = 8, runs on 1 / 2 / 4 / 8 ranks factorise the SAME matrix.
+
+
+def grid_bounds(total, grid):
+    return (np.arange(grid + 1, dtype=np.int64) * total) // grid
+
+
+def grid_block(users_total, items_total, nnz_total, grid, s, t, gamma=2.0, seed=42, sigma=1.0):
+    """Block (s, t) as scipy CSR (block users x block items), float32 / int32, sorted indices, de-duplicated."""
+    ub, ib = grid_bounds(users_total, grid), grid_bounds(items_total, grid)
+    nu, ni = int(ub[s + 1] - ub[s]), int(ib[t + 1] - ib[t])
+    # per-user degree: log-normal with the global mean nnz / users (the same for every item block of this user range)
+    deg = np.random.default_rng([seed, 1, s]).lognormal(mean=0.0, sigma=sigma, size=nu)
+    deg *= (nnz_total / users_total) / np.exp(sigma * sigma / 2.0) / grid
+    rng = np.random.default_rng([seed, 2, s, t])
+    cnt = np.minimum(np.floor(deg + rng.random(nu)).astype(np.int64), ni)  # randomised rounding of the block's share
+    total = int(cnt.sum())
+    rows = np.repeat(np.arange(nu, dtype=np.int64), cnt)
+    cols = np.minimum((ni * rng.random(total) ** gamma).astype(np.int64), ni - 1)
+    key = np.unique(rows * ni + cols)
+    data = (1.0 + 4.0 * rng.random(len(key), dtype=np.float32)).astype(np.float32)
+    indptr = np.zeros(nu + 1, dtype=np.int64)
+    indptr[1:] = np.bincount(key // ni, minlength=nu)
+    m = sp.csr_matrix((data, (key % ni).astype(np.int32), np.cumsum(indptr).astype(np.int32)), shape=(nu, ni))
+    m.has_sorted_indices = True
+    return m
+
+
+def _as_int32_csr(m):
+    m = m.tocsr()
+    m.sort_indices()
+    if m.indices.dtype != np.int32:
+        m.indices = m.indices.astype(np.int32)
+    if m.indptr.dtype != np.int32 and m.nnz < 2**31:
+        m.indptr = m.indptr.astype(np.int32)
+    return m
+
+
+def grid_shards(rank, nranks, users_total, items_total, nnz_total, grid, gamma=2.0, seed=42):
+    """Rank `rank`'s pieces of the block-composed matrix: (Cui_shard, Ciu_shard, u_offsets, i_offsets).
+
+    Cui_shard: the rank's user rows x ALL items (global item ids); Ciu_shard: the rank's item rows x ALL users (global
+    user ids); *_offsets: the nranks + 1 row offsets of the shards (every rank computes the same ones)."""
+    if grid % nranks:
+        raise ValueError(f"the block grid ({grid}) must be a multiple of the number of ranks ({nranks})")
+    per = grid // nranks
+    ub, ib = grid_bounds(users_total, grid), grid_bounds(items_total, grid)
+    mine = range(rank * per, (rank + 1) * per)
+    cache = {}
+
+    def block(s, t):
+        if (s, t) not in cache:
+            cache[(s, t)] = grid_block(users_total, items_total, nnz_total, grid, s, t, gamma, seed)
+        return cache[(s, t)]
+
+    cui = sp.vstack([sp.hstack([block(s, t) for t in range(grid)], format="csr") for s in mine], format="csr")
+    ciu = sp.vstack([sp.hstack([block(s, t).T.tocsr() for s in range(grid)], format="csr") for t in mine], format="csr")
+    u_off = ub[::per].copy()
+    i_off = ib[::per].copy()
+    return _as_int32_csr(cui), _as_int32_csr(ciu), u_off, i_off

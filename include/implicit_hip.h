@@ -93,6 +93,11 @@ int imp_intvector_destroy(imp_intvector *v);
  * row-length bins the solver kernels schedule from (device-side metadata, not visible here). */
 int imp_csr_create(int32_t rows, int32_t cols, int64_t nonzeros, const int32_t *indptr,
                    const int32_t *indices, const float *data, imp_csr **out);
+/* NEW: the same with 64-bit row offsets (the CPU reference accepts both widths, _als.pyx:76; the CUDA class is int32
+ * only, matrix.h:92-99).  More than 2^31 - 1 nonzeros are held as consecutive row blocks internally; indices stay
+ * int32 (cols < 2^31). */
+int imp_csr_create64(int32_t rows, int32_t cols, int64_t nonzeros, const int64_t *indptr,
+                     const int32_t *indices, const float *data, imp_csr **out);
 int imp_csr_shape(const imp_csr *m, int32_t *rows, int32_t *cols, int64_t *nonzeros);
 int imp_csr_destroy(imp_csr *m);
 int imp_coo_create(int32_t rows, int32_t cols, int64_t nonzeros, const int32_t *row,

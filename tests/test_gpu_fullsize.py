@@ -13,6 +13,31 @@ def rel(a, b):
     return float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b), 1e-30))
 
 
+def _cg_fp64(row, x0, Y, A0, cg_steps):
+    """One row of the oracle's CG (implicit/cpu/_als.pyx:179-244) in float64 on the same inputs; A0 = YtY + reg I."""
+    idx, c = row.indices, row.data.astype(np.float64)
+    Yu = Y[idx].astype(np.float64)
+    A0 = A0.astype(np.float64)
+    x = x0.astype(np.float64)
+    cm1 = np.abs(c) - 1.0
+    r = -A0 @ x + Yu.T @ (np.where(c > 0, c, 0.0) - cm1 * (Yu @ x))
+    p = r.copy()
+    rsold = r @ r
+    if rsold < 1e-20:
+        return x
+    for _ in range(cg_steps):
+        Ap = A0 @ p + Yu.T @ (cm1 * (Yu @ p))
+        alpha = rsold / (p @ Ap)
+        x += alpha * p
+        r -= alpha * Ap
+        rsnew = r @ r
+        if rsnew < 1e-20:
+            break
+        p = r + (rsnew / rsold) * p
+        rsold = rsnew
+    return x
+
+
 def _sampled_rows_check(gpu, oracle, C, X0, Y0, reg, solve_gpu, solve_oracle, n_sample=4000, tol=1e-4):
     Xd, Yd = gpu.Matrix(X0), gpu.Matrix(Y0)
     solve_gpu(gpu.CSRMatrix(C), Xd, Yd)
@@ -85,3 +110,129 @@ def test_topk_full_item_count(gpu, oracle):
     assert ok.mean() > 0.9
     np.testing.assert_array_equal(ids[ok], want_ids[ok, :10])
     np.testing.assert_allclose(d[ok], want_d[ok, :10], rtol=2e-5)
+
+
+# ---- round 2: every BASELINE configuration at its stated size --------------------------------------------------------
+
+
+def test_config2_full_size_cholesky_and_cg(gpu, oracle):
+    """BASELINE configs[1] at FULL size: 1M users x 100K items, ~50M nnz, f=64 -- Cholesky (the configuration's solver)
+    and CG 3 on the user side, CG 3 on the item side (100K rows averaging 500 nnz: the long-row path)."""
+    C = named("c2")
+    assert C.shape == (1_000_000, 100_000) and C.nnz > 45_000_000
+    f, reg = 64, 0.01
+    rng = np.random.default_rng(3)
+    X0 = rng.random((C.shape[0], f), dtype=np.float32) * 0.2 - 0.1
+    Y0 = rng.random((C.shape[1], f), dtype=np.float32) * 0.2 - 0.1
+    solver = gpu.LeastSquaresSolver()
+
+    def chol_gpu(Cd, Xd, Yd):
+        gram = gpu.Matrix.zeros(f, f)
+        solver.calculate_yty(Yd, gram, 0.0)
+        solver.least_squares_cholesky(Cd, Xd, gram, Yd, reg)
+
+    def chol_oracle(Csub, Xsub, Y):
+        oracle.least_squares(Csub, Xsub, Y, reg)
+
+    _sampled_rows_check(gpu, oracle, C, np.zeros_like(X0), Y0, reg, chol_gpu, chol_oracle, n_sample=2000)
+
+    def cg_gpu(Cd, Xd, Yd):
+        gram = gpu.Matrix.zeros(f, f)
+        solver.calculate_yty(Yd, gram, reg)
+        solver.least_squares(Cd, Xd, gram, Yd, 3)
+        cg_gpu.gram = gram.to_numpy()
+
+    def cg_oracle(Csub, Xsub, Y):
+        oracle.least_squares_cg(Csub, Xsub, Y, reg, cg_steps=3, YtY=cg_gpu.gram)
+
+    X1 = _sampled_rows_check(gpu, oracle, C, X0, Y0, reg, cg_gpu, cg_oracle, n_sample=2000)
+    Ct = C.T.tocsr()
+    del C
+    _sampled_rows_check(gpu, oracle, Ct, Y0, X1, reg, cg_gpu, cg_oracle, n_sample=1000)
+
+
+def test_config5_f256_cg_and_similar_items_k100(gpu, oracle):
+    """BASELINE configs[4]: MovieLens-20M shape (138,493 x 26,744, ~20M nnz), f=256 fp32 CG -- both orientations -- and
+    KnnQuery similar_items k=100 over all 26,744 items with norms, ids identical to the oracle's top-k."""
+    C = named("ml20m")
+    f, reg = 256, 0.01
+    rng = np.random.default_rng(9)
+    X0 = rng.random((C.shape[0], f), dtype=np.float32) * 0.2 - 0.1
+    Y0 = rng.random((C.shape[1], f), dtype=np.float32) * 0.2 - 0.1
+    solver = gpu.LeastSquaresSolver()
+
+    def cg_gpu(Cd, Xd, Yd):
+        gram = gpu.Matrix.zeros(f, f)
+        solver.calculate_yty(Yd, gram, reg)
+        solver.least_squares(Cd, Xd, gram, Yd, 3)
+        cg_gpu.gram = gram.to_numpy()
+
+    def cg_oracle(Csub, Xsub, Y):
+        oracle.least_squares_cg(Csub, Xsub, Y, reg, cg_steps=3, YtY=cg_gpu.gram)
+
+    X1 = _sampled_rows_check(gpu, oracle, C, X0, Y0, reg, cg_gpu, cg_oracle, n_sample=1500)
+    Y1 = _sampled_rows_check(gpu, oracle, C.T.tocsr(), Y0, X1, reg, cg_gpu, cg_oracle, n_sample=1000)
+
+    # similar_items(k=100) = top-k of (Y q) / |y_i| (gpu/matrix_factorization_base.py:162-200), 200 query items
+    items = gpu.Matrix(Y1)
+    norms = gpu.calculate_norms(items)
+    q = np.arange(0, Y1.shape[0], Y1.shape[0] // 200)[:200]
+    ids, d = gpu.KnnQuery().topk(items, items[q], 100, item_norms=norms)
+    nh = norms.to_numpy().reshape(-1)
+    want_ids, want_d = oracle.topk(Y1, Y1[q], 100, item_norms=nh)
+    np.testing.assert_allclose(d, want_d, rtol=3e-5)          # the score at every rank agrees
+    # ids: identical wherever the neighbouring scores are further apart than the fp32 noise of a 256-term dot product;
+    # inside such a near-tie two GEMM summation orders may legitimately swap neighbours -- then the id the GPU put at a
+    # rank must still HAVE that rank's score (checked in fp64)
+    tol = 4 * f * np.finfo(np.float32).eps
+    differ = ids != want_ids
+    assert differ.mean() < 0.05
+    Y64 = Y1.astype(np.float64)
+    for r, j in zip(*np.nonzero(differ)):
+        exact = Y64[ids[r, j]] @ Y64[q[r]] / nh[ids[r, j]]
+        assert abs(exact - want_d[r, j]) <= tol * max(abs(want_d[r, j]), 1e-30), (r, j, exact, want_d[r, j])
+        assert len(set(ids[r]) ^ set(want_ids[r])) <= 2      # only the boundary of the list can differ as a set
+    assert (ids[:, 0] == q).mean() > 0.99   # an item's nearest neighbour by cosine is itself
+
+
+def test_config4_one_eighth_shard_on_one_gpu(gpu, oracle):
+    """BASELINE configs[3] (10M users x 1M items x 500M nnz, f=128, 8 GPUs): what RANK 0 of the 8-GPU run computes, on
+    one GPU -- its 1.25M user rows (62M nnz, global item ids) against the full item-factor replica, then its 125K item
+    rows (62M nnz, global user ids) against the full 10M x 128 user-factor replica."""
+    from implicit_amd.synthetic import SHAPES, grid_shards
+
+    users, items, nnz, gamma = SHAPES["c4"]
+    Cui, Ciu, u_off, i_off = grid_shards(0, 8, users, items, nnz, 8, gamma=gamma, seed=42)
+    assert Cui.shape == (1_250_000, 1_000_000) and Ciu.shape == (125_000, 10_000_000)
+    assert 55_000_000 < Cui.nnz < 70_000_000 and 55_000_000 < Ciu.nnz < 70_000_000
+    f, reg = 128, 0.01
+    solver = gpu.LeastSquaresSolver()
+    X = gpu.RandomState(7).uniform(users, f, -0.1, 0.1)      # replicas drawn on the device (5.1 GB + 0.5 GB)
+    Y = gpu.RandomState(8).uniform(items, f, -0.1, 0.1)
+    gram = gpu.Matrix.zeros(f, f)
+
+    def sweep(Cshard, mine, other, lens_name):
+        before = mine.to_numpy()
+        solver.calculate_yty(other, gram, reg)
+        solver.least_squares(gpu.CSRMatrix(Cshard), mine, gram, other, 3)
+        got = mine.to_numpy()
+        assert np.isfinite(got).all()
+        lens = np.diff(Cshard.indptr)
+        assert not got[lens == 0].any()
+        other_h, gram_h = other.to_numpy(), gram.to_numpy()
+        # a uniform sample of 500 rows plus the 16 longest (up to 170K nonzeros on the item side).  The item rows average 500
+        # nonzeros here and an fp32 sum of that many terms depends on its order by more than 1e-4 -- the oracle's sequential
+        # order (measured 3.6e-4 from the fp64 answer) more than the GPU's tiled one (1.4e-5) -- so both samples are judged
+        # against the same solve in fp64: the GPU within 1e-4 of it, and of the oracle within the oracle's own distance
+        for name, rows in (("sampled", np.arange(0, Cshard.shape[0], Cshard.shape[0] // 500)), ("longest", np.argsort(lens)[-16:])):
+            want = np.ascontiguousarray(before[rows])
+            oracle.least_squares_cg(Cshard[rows], want, other_h, reg, cg_steps=3, YtY=gram_h)
+            exact = np.stack([_cg_fp64(Cshard[int(r)], before[int(r)], other_h, gram_h, 3) for r in rows])
+            e_gpu, e_oracle, e_pair = rel(got[rows], exact), rel(want, exact), rel(got[rows], want)
+            print(f"config4 shard {lens_name} ({Cshard.shape}, nnz={Cshard.nnz}, max row {lens.max()}), {len(rows)} {name} rows: "
+                  f"gpu-vs-fp64 {e_gpu:.2e}  oracle-vs-fp64 {e_oracle:.2e}  gpu-vs-oracle {e_pair:.2e}")
+            assert e_gpu < 1e-4
+            assert e_pair < max(1e-4, 2.0 * e_oracle)
+
+    sweep(Cui, X[int(u_off[0]):int(u_off[1])], Y, "user rows")
+    sweep(Ciu, Y[int(i_off[0]):int(i_off[1])], X, "item rows")

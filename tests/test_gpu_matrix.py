@@ -87,11 +87,17 @@ def test_csr_requires_int32_and_converts_non_csr(gpu):
     gpu.CSRMatrix(C)
     with pytest.warns(ParameterWarning):
         gpu.CSRMatrix(C.tocoo())
+    # int32 row offsets with any other index dtype are a buffer mismatch, as in the reference (`cdef int[:]`, _cuda.pyx:225-227)
     bad = C.copy()
     bad.indices = bad.indices.astype(np.int64)
-    bad.indptr = bad.indptr.astype(np.int64)
     with pytest.raises(ValueError):
         gpu.CSRMatrix(bad)
+    # NEW: int64 row offsets (scipy's format beyond 2^31 nonzeros; accepted by the CPU reference, _als.pyx:76) go through
+    # imp_csr_create64
+    wide = C.copy()
+    wide.indices = wide.indices.astype(np.int64)
+    wide.indptr = wide.indptr.astype(np.int64)
+    assert gpu.CSRMatrix(wide).nnz == C.nnz
 
 
 def test_random_state(gpu):

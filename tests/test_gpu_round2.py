@@ -1,0 +1,270 @@
+"""Round-2 additions: hygiene of the C-ABI (empty inputs, malformed CSR, int64 offsets / row blocks, failed_row),
+oracle parity of the fold-in paths, the A/B environment switches, concurrent callers, and the model-level multi-GPU
+entry with a one-rank communicator."""
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from implicit_amd.synthetic import synthetic_csr
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def rel(a, b):
+    return float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def test_gramian_of_an_empty_matrix_is_reg_times_identity(gpu):
+    """calculate_yty on a 0-row Matrix (an empty shard of the multi-GPU driver): reg * I, as the reference's GEMM +
+    l2_regularize pair leaves (als.cu:122-152)."""
+    solver = gpu.LeastSquaresSolver()
+    for f in (16, 128):
+        out = gpu.Matrix(np.ones((f, f), dtype=np.float32))
+        solver.calculate_yty(gpu.Matrix(np.zeros((0, f), dtype=np.float32)), out, 0.5)
+        np.testing.assert_array_equal(out.to_numpy(), 0.5 * np.eye(f, dtype=np.float32))
+        full = gpu.Matrix(np.ones((10, f), dtype=np.float32))
+        solver.calculate_yty(full[3:3], out, 0.25)      # empty row-range view
+        np.testing.assert_array_equal(out.to_numpy(), 0.25 * np.eye(f, dtype=np.float32))
+
+
+def test_malformed_csr_is_rejected_on_the_host(gpu):
+    good = synthetic_csr(50, 40, 400, seed=1)
+    bad = good.copy()
+    bad.indices = bad.indices.copy()
+    bad.indices[5] = 40                                  # == cols: out of range
+    with pytest.raises(ValueError, match="column index out of range"):
+        gpu.CSRMatrix(bad)
+    bad.indices[5] = -1
+    with pytest.raises(ValueError, match="column index out of range"):
+        gpu.CSRMatrix(bad)
+    bad = good.copy()
+    bad.indptr = bad.indptr.copy()
+    bad.indptr[3], bad.indptr[4] = bad.indptr[4], bad.indptr[3] - 1
+    with pytest.raises(ValueError):
+        gpu.CSRMatrix(bad)
+
+
+def test_cholesky_failure_reports_the_row(gpu):
+    """A non-positive-definite system raises ValueError (as _als.pyx:136-138) and names the smallest failing row."""
+    f = 16
+    C = sp.csr_matrix(np.array([[2.0, 0, 3.0], [0, 2.0, 0], [1.5, 0, 0]], dtype=np.float32))
+    Y = gpu.Matrix(np.zeros((3, f), dtype=np.float32))          # YtY = 0 and reg = 0: singular for every row
+    X = gpu.Matrix.zeros(3, f)
+    gram = gpu.Matrix.zeros(f, f)
+    with pytest.raises(ValueError, match="cholesky") as info:
+        gpu.LeastSquaresSolver().least_squares_cholesky(gpu.CSRMatrix(C), X, gram, Y, 0.0)
+    assert info.value.failed_row == 0
+
+
+@pytest.mark.parametrize("solver_kind", ["cg", "cholesky"])
+def test_int64_offsets_and_row_blocks_match_the_int32_matrix(gpu, solver_kind, monkeypatch):
+    """imp_csr_create64: int64 indptr (what scipy hands over beyond 2^31 nonzeros; the CPU reference accepts it,
+    _als.pyx:76).  With the block limit lowered the same matrix is held as several row blocks: identical results."""
+    f, reg = 64, 0.05
+    C = synthetic_csr(4000, 900, 120_000, seed=2, neg_frac=0.05, empty_frac=0.02)
+    rng = np.random.default_rng(1)
+    X0 = rng.random((4000, f), dtype=np.float32) * 0.1
+    Y0 = rng.random((900, f), dtype=np.float32) * 0.1
+    solver = gpu.LeastSquaresSolver()
+    Yd = gpu.Matrix(Y0)
+    gram = gpu.Matrix.zeros(f, f)
+    solver.calculate_yty(Yd, gram, reg if solver_kind == "cg" else 0.0)
+
+    def solve(Cd):
+        Xd = gpu.Matrix(X0)
+        if solver_kind == "cg":
+            solver.least_squares(Cd, Xd, gram, Yd, 3)
+        else:
+            solver.least_squares_cholesky(Cd, Xd, gram, Yd, reg)
+        return Xd.to_numpy(), solver.calculate_loss(Cd, Xd, Yd, reg)
+
+    want, want_loss = solve(gpu.CSRMatrix(C))
+    C64 = C.copy()
+    C64.indptr = C64.indptr.astype(np.int64)
+    C64.indices = C64.indices.astype(np.int64)
+    got, got_loss = solve(gpu.CSRMatrix(C64))
+    np.testing.assert_array_equal(got, want)
+    monkeypatch.setenv("IMP_CSR_PART_NNZ", "25000")      # ~5 row blocks
+    blocks = gpu.CSRMatrix(C64)
+    monkeypatch.delenv("IMP_CSR_PART_NNZ")
+    got, got_loss = solve(blocks)
+    assert rel(got, want) < 1e-6                           # the row schedule differs per block, the arithmetic per row does not
+    assert got_loss == pytest.approx(want_loss, rel=1e-5)
+
+
+def test_fold_in_matches_the_oracle(gpu, oracle):
+    """recalculate_user / recalculate_item / partial_fit_* against the oracle's solvers on the same rows (the round-1
+    tests compared the model with itself): Cholesky fold-in as cpu/als.py:221-241."""
+    from implicit_amd.als import AlternatingLeastSquares
+
+    C = synthetic_csr(600, 300, 9000, seed=4)
+    model = AlternatingLeastSquares(factors=32, regularization=0.05, random_state=3, use_gpu=True, iterations=3)
+    model.fit(C, show_progress=False)
+    Xh, Yh = model.user_factors.to_numpy(), model.item_factors.to_numpy()
+    users = np.array([5, 17, 99, 400])
+    got = model.recalculate_user(users, C[users]).to_numpy()
+    want = np.zeros((len(users), 32), dtype=np.float32)
+    oracle.least_squares(C[users], want, Yh, 0.05)
+    assert rel(got, want) < 1e-4
+    one = model.recalculate_user(7, C[7]).to_numpy()
+    want1 = np.zeros((1, 32), dtype=np.float32)
+    oracle.least_squares(C[7], want1, Yh, 0.05)
+    assert rel(one, want1) < 1e-4
+    Ct = C.T.tocsr()
+    items = np.array([0, 3, 250])
+    got = model.recalculate_item(items, Ct[items]).to_numpy()
+    want = np.zeros((len(items), 32), dtype=np.float32)
+    oracle.least_squares(Ct[items], want, Xh, 0.05)
+    assert rel(got, want) < 1e-4
+    # partial_fit_users: new user ids beyond the model grow the matrix; rows equal the fold-in solution
+    new_ids = np.array([600, 602])
+    model.partial_fit_users(new_ids, C[[1, 2]])
+    after = model.user_factors.to_numpy()
+    assert after.shape == (603, 32) and not after[601].any()
+    want = np.zeros((2, 32), dtype=np.float32)
+    oracle.least_squares(C[[1, 2]], want, Yh, 0.05)
+    assert rel(after[new_ids], want) < 1e-4
+    np.testing.assert_array_equal(after[:600], Xh)
+    # the cached unregularised gramian is dropped when the factors it was built from change
+    assert model._XtX0 is None                               # partial_fit_users changed the user factors
+    grown = sp.csr_matrix((Ct[2].data, Ct[2].indices, Ct[2].indptr), shape=(1, 603))
+    model.recalculate_item(2, grown)
+    assert model._XtX0 is not None and model._YtY0 is not None  # both unregularised gramians are cached now ...
+    model.partial_fit_items(np.array([2]), grown)
+    assert model._YtY0 is None and model._YtY is None           # ... and the item-side ones are dropped again
+
+
+_SWITCH_SCRIPT = r"""
+import sys, numpy as np, warnings
+sys.path.insert(0, {root!r})
+warnings.simplefilter("ignore")
+import implicit_amd.gpu as gpu
+from implicit_amd.synthetic import synthetic_csr
+from oracle import oracle
+oracle.build()
+rel = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b), 1e-30))
+solver = gpu.LeastSquaresSolver()
+for f in (64, 128):
+    C = synthetic_csr(3000, 700, 150_000, seed=6, neg_frac=0.05, empty_frac=0.01)   # item side: rows > 512 nnz
+    for M in (C, C.T.tocsr()):
+        rng = np.random.default_rng(2)
+        X0 = rng.random((M.shape[0], f), dtype=np.float32) * 0.2 - 0.1
+        Y0 = rng.random((M.shape[1], f), dtype=np.float32) * 0.2 - 0.1
+        Xd, Yd, gram = gpu.Matrix(X0), gpu.Matrix(Y0), gpu.Matrix.zeros(f, f)
+        solver.calculate_yty(Yd, gram, 0.05)
+        solver.least_squares(gpu.CSRMatrix(M), Xd, gram, Yd, 3)
+        want = X0.copy()
+        oracle.least_squares_cg(M, want, Y0, 0.05, cg_steps=3, YtY=gram.to_numpy())
+        assert rel(Xd.to_numpy(), want) < 1e-4, ("cg", f, rel(Xd.to_numpy(), want))
+    if f == 64:
+        Xd = gpu.Matrix.zeros(C.shape[0], f)
+        solver.calculate_yty(Yd if Yd.shape[0] == C.shape[1] else gpu.Matrix(Y0), gram, 0.0)
+Cc = synthetic_csr(2000, 500, 60_000, seed=3)
+rng = np.random.default_rng(5)
+Y0 = rng.random((500, 64), dtype=np.float32) * 0.2 - 0.1
+Yd, gram, Xd = gpu.Matrix(Y0), gpu.Matrix.zeros(64, 64), gpu.Matrix.zeros(2000, 64)
+solver.calculate_yty(Yd, gram, 0.0)
+solver.least_squares_cholesky(gpu.CSRMatrix(Cc), Xd, gram, Yd, 0.05)
+want = np.zeros((2000, 64), dtype=np.float32)
+oracle.least_squares(Cc, want, Y0, 0.05)
+assert rel(Xd.to_numpy(), want) < 1e-4, ("cholesky", rel(Xd.to_numpy(), want))
+items = (rng.standard_normal((5000, 64)) * 0.1).astype(np.float32)
+q = (rng.standard_normal((40, 64)) * 0.1).astype(np.float32)
+ids, d = gpu.KnnQuery().topk(gpu.Matrix(items), gpu.Matrix(q), 10)
+wi, wd = oracle.topk(items, q, 10)
+assert (ids == wi).mean() > 0.99
+print("switch ok")
+"""
+
+
+@pytest.mark.parametrize("switch", ["IMP_SHORT_TEAM1=1", "IMP_SHORT_TEAM1=0", "IMP_STRIPE=0", "IMP_SEGMENT=128",
+                                    "IMP_CHOL_NO_MFMA=1", "IMP_CHOL_NO_WAVE=1", "IMP_TOPK_NO_FAST=1"])
+def test_ab_switch_paths_keep_parity(gpu, switch):
+    """Every debug / A-B environment switch selects kernels the default run does not take (they are read once per
+    process, hence the subprocess): CG both orientations at f = 64 / 128, Cholesky f = 64 and top-k against the oracle."""
+    name, value = switch.split("=")
+    env = dict(os.environ, **{name: value})
+    out = subprocess.run([sys.executable, "-c", _SWITCH_SCRIPT.format(root=ROOT)], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0 and "switch ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_concurrent_callers_on_one_device(gpu, oracle):
+    """ctypes releases the GIL around every C-ABI call and the model caches ONE KnnQuery / solver: calls on a device are
+    serialised inside the library (per-device lock), so threads sharing a model get the single-threaded answers."""
+    rng = np.random.default_rng(0)
+    items = gpu.Matrix((rng.standard_normal((20_000, 64)) * 0.1).astype(np.float32))
+    queries = [(rng.standard_normal((64, 64)) * 0.1).astype(np.float32) for _ in range(8)]
+    knn = gpu.KnnQuery()
+    want = [knn.topk(items, gpu.Matrix(q), 10) for q in queries]
+    C = synthetic_csr(1500, 20_000, 40_000, seed=9)
+    Y = items
+    solver = gpu.LeastSquaresSolver()
+    gram = gpu.Matrix.zeros(64, 64)
+    solver.calculate_yty(Y, gram, 0.1)
+    X0 = rng.random((1500, 64), dtype=np.float32) * 0.01
+    Xref = gpu.Matrix(X0)
+    Cd = gpu.CSRMatrix(C)
+    solver.least_squares(Cd, Xref, gram, Y, 3)
+    want_x = Xref.to_numpy()
+    errors = []
+
+    def knn_worker(i):
+        try:
+            for _ in range(5):
+                ids, d = knn.topk(items, gpu.Matrix(queries[i]), 10)
+                np.testing.assert_array_equal(ids, want[i][0])
+                np.testing.assert_array_equal(d, want[i][1])
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    def solve_worker():
+        try:
+            for _ in range(5):
+                Xd = gpu.Matrix(X0)
+                solver.calculate_yty(Y, gram, 0.1)
+                solver.least_squares(Cd, Xd, gram, Y, 3)
+                np.testing.assert_array_equal(Xd.to_numpy(), want_x)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=knn_worker, args=(i,)) for i in range(8)] + [threading.Thread(target=solve_worker)] * 1
+    threads += [threading.Thread(target=solve_worker)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:2]
+
+
+def test_model_fit_with_a_communicator(gpu, oracle):
+    """AlternatingLeastSquares(comm=...): the multi-GPU fit entry.  One real rank here (the N = 2 logic runs on CPU in
+    tests/test_sharded_gloo.py): a one-rank communicator is the plain fit; IMP_FORCE... is not needed -- nranks == 1
+    short-circuits to the single-GPU loop -- so the sharded body is driven directly with chunks."""
+    from implicit_amd.als import AlternatingLeastSquares
+    from implicit_amd.gpu import sharded
+
+    C = synthetic_csr(800, 500, 20_000, seed=12)
+    comm = gpu.Comm(gpu.Comm.unique_id(), 1, 0)
+    plain = AlternatingLeastSquares(factors=64, regularization=0.05, random_state=5, use_gpu=True, iterations=2)
+    plain.fit(C, show_progress=False)
+    model = AlternatingLeastSquares(factors=64, regularization=0.05, random_state=5, use_gpu=True, iterations=2)
+    model.comm = comm
+    model.fit(C, show_progress=False)                      # nranks == 1: same loop
+    np.testing.assert_array_equal(model.user_factors.to_numpy(), plain.user_factors.to_numpy())
+    # the sharded body itself (what every rank of an N-GPU job runs), chunked exchange included
+    model2 = AlternatingLeastSquares(factors=64, regularization=0.05, random_state=5, use_gpu=True, iterations=2)
+    Cui = C.astype(np.float32)
+    model2._initial_factors(*C.shape)
+    sharded.fit_sharded(model2, Cui, Cui.T.tocsr(), comm, chunks=3)
+    assert rel(model2.user_factors.to_numpy(), plain.user_factors.to_numpy()) < 1e-5
+    assert rel(model2.item_factors.to_numpy(), plain.item_factors.to_numpy()) < 1e-5
+    import pickle
+
+    assert pickle.loads(pickle.dumps(model)).comm is None

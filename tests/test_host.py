@@ -50,3 +50,30 @@ def test_check_random_state():
     b = check_random_state(5).random(3)
     assert_array_equal(a, b)
     assert isinstance(check_random_state(np.random.RandomState(1)), np.random.Generator)
+
+
+def test_grid_shards_compose_one_matrix_whatever_the_rank_count():
+    """The block-composed generator of the multi-GPU bench: a rank's user rows and item rows are consistent pieces of
+    ONE global matrix, and the matrix depends on the grid, not on how many ranks share it."""
+    from implicit_amd.synthetic import grid_shards
+
+    users, items, nnz, grid = 3000, 800, 40_000, 4
+    whole = {}
+    for n in (1, 2, 4):
+        parts = [grid_shards(r, n, users, items, nnz, grid, gamma=2.0, seed=3) for r in range(n)]
+        cui = sp.vstack([p[0] for p in parts]).tocsr()
+        ciu = sp.vstack([p[1] for p in parts]).tocsr()
+        assert cui.shape == (users, items) and ciu.shape == (items, users)
+        assert abs(cui - ciu.T).nnz == 0                      # item rows = transpose of the user rows
+        for p in parts:
+            assert p[0].indices.dtype == np.int32 and p[0].indptr.dtype == np.int32 and p[0].has_sorted_indices
+            assert_array_equal(p[2], parts[0][2])             # every rank computes the same offsets
+            assert p[2][0] == 0 and p[2][-1] == users and p[3][-1] == items
+        whole[n] = cui
+    assert abs(whole[1] - whole[2]).nnz == 0 and abs(whole[1] - whole[4]).nnz == 0
+    assert 0.8 * nnz < whole[1].nnz <= 1.05 * nnz
+    # popular items are spread over the item ranges: the shards carry comparable work
+    per_shard = np.diff(whole[1].tocsc().indptr).reshape(4, -1).sum(axis=1)
+    assert per_shard.max() < 1.3 * per_shard.min()
+    with pytest.raises(ValueError):
+        grid_shards(0, 3, users, items, nnz, grid)

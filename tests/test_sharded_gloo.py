@@ -92,6 +92,55 @@ def _worker(rank, world, port, out_dir, chunks):
     dist.destroy_process_group()
 
 
+def _worker_grid(rank, world, port, out_dir):
+    """BASELINE configs[3] in miniature: every rank generates ONLY its own user rows and item rows of the block-composed
+    matrix (implicit_amd.synthetic.grid_shards), as bench.py --gpus N does."""
+    sys.path.insert(0, ROOT)
+    os.environ.setdefault("OPENBLAS_NUM_THREADS", "4")
+    import torch
+    import torch.distributed as dist
+
+    from implicit_amd.gpu import sharded
+    from implicit_amd.synthetic import grid_shards
+    from oracle import oracle
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    users, items, nnz, grid, f, reg = 2000, 240, 20_000, 4, 32, 0.05
+    Cui_shard, Ciu_shard, u_off, i_off = grid_shards(rank, world, users, items, nnz, grid, gamma=2.0, seed=11)
+    assert Cui_shard.shape == (u_off[rank + 1] - u_off[rank], items) and Ciu_shard.shape == (i_off[rank + 1] - i_off[rank], users)
+    rng = np.random.default_rng(3)
+    X = rng.random((users, f), dtype=np.float32) * 0.1 - 0.05
+    Y = rng.random((items, f), dtype=np.float32) * 0.1 - 0.05
+    gram = np.zeros((f, f), dtype=np.float32)
+    comm, backend = GlooComm(dist, torch), NumpyBackend(oracle)
+    Cu, Ci = sharded.split_rows(Cui_shard, 2), sharded.split_rows(Ciu_shard, 2)
+    for _ in range(2):
+        sharded.iteration(backend, comm, Cu, Ci, X, Y, u_off, i_off, gram, reg, 3)
+    np.savez(os.path.join(out_dir, f"grid_rank{rank}.npz"), X=X, Y=Y)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_on_a_config4_shaped_miniature(tmp_path, oracle):
+    import scipy.sparse as sp
+    import torch.multiprocessing as mp
+
+    from implicit_amd.synthetic import grid_shards
+
+    world = 2
+    mp.spawn(_worker_grid, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "grid_rank0.npz"), np.load(tmp_path / "grid_rank1.npz")
+    np.testing.assert_array_equal(r0["X"], r1["X"])
+    np.testing.assert_array_equal(r0["Y"], r1["Y"])
+    C = sp.vstack([grid_shards(r, world, 2000, 240, 20_000, 4, gamma=2.0, seed=11)[0] for r in range(world)]).tocsr()
+    rng = np.random.default_rng(3)
+    X = rng.random((2000, 32), dtype=np.float32) * 0.1 - 0.05
+    Y = rng.random((240, 32), dtype=np.float32) * 0.1 - 0.05
+    Xs, Ys = oracle.fit(C, 32, regularization=0.05, iterations=2, user_factors=X, item_factors=Y)
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)  # noqa: E731
+    assert rel(r0["X"], Xs) < 1e-5 and rel(r0["Y"], Ys) < 1e-5
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
