@@ -265,14 +265,28 @@ __global__ __launch_bounds__(BLOCK) void select_kernel(const float *__restrict__
 // coalesced score write, and the per-(query, 64-item) maximum for the pruned select below.
 constexpr int kTileItems = 64;  // granularity of the tile maxima
 
+// MODE 0: scores written to S[q][item] + per-(query, 64-item) maxima          (materialising path)
+// MODE 1: only every `block_stride`-th 128-item block is computed, into the compact S[q][128 b + ...] (threshold pre-pass)
+// MODE 2: nothing is materialised: scores >= tau[q] that are not filtered (bitmaps) are appended to the query's candidate list
+struct EmitArgs {
+  const uint32_t *tau;        // [nq] ordered key of the query's threshold
+  const uint32_t *row_bits;   // [nq][words] per-query filter bitmap (may be null)
+  const uint32_t *item_bits;  // [words] global item filter bitmap (may be null)
+  int words;
+  uint64_t *cand;             // [nq][cap]
+  unsigned int *count;        // [nq]
+  int cap;
+};
+
+template <int MODE>
 __global__ __launch_bounds__(256) void score_gemm_direct_kernel(const float *__restrict__ Q, int nq, const float *__restrict__ I,
                                                                 int ni, int f, const float *__restrict__ norms,
                                                                 float *__restrict__ S, float *__restrict__ tile_max,
-                                                                int n_tiles) {
+                                                                int n_tiles, int block_stride, EmitArgs emit) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, kh = lane >> 5;
   const int q_base = blockIdx.y * 128 + 64 * (wave >> 1);
-  const int i_base = blockIdx.x * 128 + 64 * (wave & 1);
+  const int i_base = (MODE == 1 ? blockIdx.x * block_stride : blockIdx.x) * 128 + 64 * (wave & 1);
   const float *qp[2], *ip[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
@@ -324,6 +338,54 @@ __global__ __launch_bounds__(256) void score_gemm_direct_kernel(const float *__r
   for (int ti = 0; ti < 2; ++ti) {
     int item = i_base + 32 * ti + r;
     nrm[ti] = (norms && item < ni) ? norms[item] : 1.f;
+  }
+  if constexpr (MODE == 1) {
+    // compact layout: block b of the subset occupies columns [128 b, 128 b + 128); items past the end score -FLT_MAX
+    const int sub_cols = gridDim.x * 128;
+    const int c_base = blockIdx.x * 128 + 64 * (wave & 1);
+#pragma unroll
+    for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int q = q_base + 32 * tq + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        if (q < nq) {
+#pragma unroll
+          for (int ti = 0; ti < 2; ++ti) {
+            float sc = acc[tq][ti][e];
+            if (norms) sc = sc / nrm[ti];
+            S[(size_t)q * sub_cols + c_base + 32 * ti + r] = (i_base + 32 * ti + r < ni) ? sc : -FLT_MAX;
+          }
+        }
+      }
+    return;
+  }
+  if constexpr (MODE == 2) {
+    // emission is rare (a few hundred scores per query row out of all items): the divergent branch costs nothing next to the
+    // 64 stores per lane it replaces
+#pragma unroll
+    for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int q = q_base + 32 * tq + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        if (q >= nq) continue;
+        const uint32_t t = emit.tau[q];
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+          const int item = i_base + 32 * ti + r;
+          float sc = acc[tq][ti][e];
+          if (norms) sc = sc / nrm[ti];
+          if (item < ni && ordered(sc) >= t) {
+            const uint32_t bit = 1u << (item & 31);
+            bool filtered = emit.item_bits && (emit.item_bits[item >> 5] & bit);
+            if (!filtered && emit.row_bits) filtered = emit.row_bits[(size_t)q * emit.words + (item >> 5)] & bit;
+            if (!filtered) {
+              const unsigned int slot = atomicAdd(&emit.count[q], 1u);
+              if (slot < (unsigned)emit.cap) emit.cand[(size_t)q * emit.cap + slot] = make_key(sc, item);
+            }
+          }
+        }
+      }
+    return;
   }
   const int tile = i_base / kTileItems;
   if (q_base + 64 <= nq && i_base + 64 <= ni) {
@@ -516,6 +578,181 @@ __global__ __launch_bounds__(BLOCK) void select_pruned_kernel(const float *__res
   }
 }
 
+// ---- emit path: top-k without the score matrix -----------------------------------------------------------------------
+// The materialising path writes and re-reads batch x items scores (1.17 GB per 1000-query batch at 292 K items: the
+// GEMM ran at the speed of that write, ~1 TB/s, not of the matrix pipe).  Here:
+//   1. pre-pass: the scores of every kSubStride-th 128-item block (3 % of the items) go to a small buffer, filters are
+//      applied to it, and tau[q] = its k-th largest entry -- a valid lower bound of the k-th best score over ALL items,
+//      because those k entries are themselves unfiltered scores of the row;
+//   2. the full GEMM (MODE 2) appends every unfiltered score >= tau[q] to the query's candidate list (about
+//      kSubStride x k of them): filters are looked up in bitmaps, only for the scores that pass the threshold;
+//   3. one workgroup per query sorts its candidates and writes the best k.  Overflowing lists, lists shorter than k and
+//      an exact tie at the k-th score (the reference heap's arrival-order rule needs the whole row) raise `fallback`:
+//      those queries are redone by the materialising path, 64 at a time.
+// Scores are the same MFMA accumulations in both passes (same kernel body, same k order): bit-identical.
+constexpr int kSubStride = 32;
+constexpr int kEmitCap = 4096;  // candidates per query (32 KiB: the LDS sort buffer of select_candidates_kernel)
+
+__global__ void coo_bitmap_kernel(uint32_t *__restrict__ bits, int words, int start, int end, int ni, const int32_t *__restrict__ row,
+                                  const int32_t *__restrict__ col, size_t nnz, float *__restrict__ S_sub, int sub_cols) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nnz; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = row[i], c = col[i];
+    if (r < start || r >= end || c < 0 || c >= ni) continue;
+    atomicOr(&bits[(size_t)(r - start) * words + (c >> 5)], 1u << (c & 31));
+    const int blk = c >> 7;
+    if (S_sub && blk % kSubStride == 0) S_sub[(size_t)(r - start) * sub_cols + (blk / kSubStride) * 128 + (c & 127)] = -FLT_MAX;
+  }
+}
+
+__global__ void item_bitmap_kernel(uint32_t *__restrict__ bits, int ni, const int32_t *__restrict__ items, int n_items,
+                                   float *__restrict__ S_sub, int rows, int sub_cols) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)n_items; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = items[i];
+    if (c < 0 || c >= ni) continue;
+    atomicOr(&bits[c >> 5], 1u << (c & 31));
+    const int blk = c >> 7;
+    if (blk % kSubStride == 0)
+      for (int q = 0; q < rows; ++q) S_sub[(size_t)q * sub_cols + (blk / kSubStride) * 128 + (c & 127)] = -FLT_MAX;
+  }
+}
+
+// key of the m-th largest of n values (4-pass byte radix select; one workgroup)
+template <int BLOCK>
+__device__ __forceinline__ uint32_t kth_largest_key(const float *__restrict__ v, int n, unsigned int m, unsigned int *hist,
+                                                    unsigned int *sh_bucket, unsigned int *sh_remaining) {
+  const int tid = threadIdx.x;
+  uint32_t prefix = 0, mask = 0;
+  unsigned int remaining = m;
+  for (int digit = 3; digit >= 0; --digit) {
+    const int shift = digit * 8;
+    for (int i = tid; i < 256; i += BLOCK) hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += BLOCK) {
+      uint32_t key = ordered(v[i]);
+      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 0xFF], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned int acc = 0;
+      int b = 255;
+      for (; b > 0; --b) {
+        if (acc + hist[b] >= remaining) break;
+        acc += hist[b];
+      }
+      *sh_bucket = b;
+      *sh_remaining = remaining - acc;
+    }
+    __syncthreads();
+    prefix |= (uint32_t)*sh_bucket << shift;
+    mask |= 0xFFu << shift;
+    remaining = *sh_remaining;
+    __syncthreads();
+  }
+  return prefix;
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void subset_threshold_kernel(const float *__restrict__ S_sub, int sub_cols, int k,
+                                                                 uint32_t *__restrict__ tau, unsigned int *__restrict__ count) {
+  __shared__ unsigned int hist[256];
+  __shared__ unsigned int sh_bucket, sh_remaining;
+  const int q = blockIdx.x;
+  const uint32_t key = kth_largest_key<BLOCK>(S_sub + (size_t)q * sub_cols, sub_cols, (unsigned)min(k, sub_cols), hist, &sh_bucket,
+                                              &sh_remaining);
+  if (threadIdx.x == 0) {
+    tau[q] = key;  // ordered(-FLT_MAX) when fewer than k subset entries survive the filters: everything is emitted -> fallback
+    count[q] = 0;
+  }
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void select_candidates_kernel(const uint64_t *__restrict__ gcand, const unsigned int *__restrict__ count,
+                                                                  int cap, int k, int32_t *__restrict__ out_ids,
+                                                                  float *__restrict__ out_dist, int out_stride,
+                                                                  int *__restrict__ fallback) {
+  __shared__ uint64_t cand[kEmitCap];
+  const int tid = threadIdx.x, q = blockIdx.x;
+  const unsigned int n_c = count[q];
+  if (n_c > (unsigned)cap || n_c < (unsigned)k) {  // uniform
+    if (tid == 0) fallback[q] = 1;
+    return;
+  }
+  int npad = 2;
+  while (npad < (int)n_c) npad <<= 1;
+  for (int i = tid; i < npad; i += BLOCK) cand[i] = i < (int)n_c ? gcand[(size_t)q * cap + i] : 0;  // pads sort last
+  __syncthreads();
+  for (int size = 2; size <= npad; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (npad >> 1); t += BLOCK) {
+        int lo = 2 * t - (t & (stride - 1));
+        int hi = lo + stride;
+        bool desc = ((lo & size) == 0);
+        uint64_t a = cand[lo], b = cand[hi];
+        if ((a < b) == desc) {
+          cand[lo] = b;
+          cand[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // exact tie at the k-th score -> the heap rule needs the full row
+  const bool tie = (int)n_c > k && (uint32_t)(cand[k - 1] >> 32) == (uint32_t)(cand[k] >> 32);
+  if (tid == 0) fallback[q] = tie ? 1 : 0;
+  if (tie) return;
+  for (int i = tid; i < k; i += BLOCK) {
+    uint64_t key = cand[i];
+    out_ids[(size_t)q * out_stride + i] = (int32_t)(uint32_t)key;
+    out_dist[(size_t)q * out_stride + i] = unordered((uint32_t)(key >> 32));
+  }
+}
+
+// fallback rows: query rows gathered into a compact matrix, filters replayed from the bitmaps onto the materialised scores
+__global__ void gather_query_rows_kernel(const float *__restrict__ Q, const int32_t *__restrict__ rows, int n, int f,
+                                         float *__restrict__ out) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)n * f; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = Q[(size_t)rows[i / f] * f + i % f];
+}
+
+__global__ void bitmap_filter_kernel(float *__restrict__ S, float *__restrict__ tile_max, int ni, int n_tiles,
+                                     const int32_t *__restrict__ rows, int n, const uint32_t *__restrict__ row_bits,
+                                     const uint32_t *__restrict__ item_bits, int words) {
+  // one thread per (row, 64-item tile): clears the filtered scores of the tile and recomputes its maximum if any was hit
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)n * n_tiles; i += (size_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i / n_tiles), tile = (int)(i % n_tiles);
+    uint32_t w0 = 0, w1 = 0;
+    const int wi = 2 * tile;
+    if (item_bits) {
+      w0 |= item_bits[wi];
+      if (wi + 1 < words) w1 |= item_bits[wi + 1];
+    }
+    if (row_bits) {
+      const uint32_t *rb = row_bits + (size_t)rows[j] * words;
+      w0 |= rb[wi];
+      if (wi + 1 < words) w1 |= rb[wi + 1];
+    }
+    if (!(w0 | w1)) continue;
+    float *srow = S + (size_t)j * ni;
+    float m = -FLT_MAX;
+    const int c0 = tile * kTileItems, c1 = min(ni, c0 + kTileItems);
+    for (int c = c0; c < c1; ++c) {
+      const uint32_t w = (c - c0) < 32 ? w0 : w1;
+      if (w & (1u << (c & 31))) srow[c] = -FLT_MAX;
+      m = fmaxf(m, srow[c]);
+    }
+    tile_max[(size_t)j * n_tiles + tile] = m;
+  }
+}
+
+__global__ void scatter_topk_rows_kernel(const int32_t *__restrict__ ids, const float *__restrict__ dist, const int32_t *__restrict__ rows,
+                                         int n, int k, int32_t *__restrict__ out_ids, float *__restrict__ out_dist) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)n * k; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t dst = (size_t)rows[i / k] * k + i % k;
+    out_ids[dst] = ids[i];
+    out_dist[dst] = dist[i];
+  }
+}
+
 static bool is_host_pointer(const void *p) {
   hipPointerAttribute_t attr;
   hipError_t err = hipPointerGetAttributes(&attr, p);
@@ -539,6 +776,12 @@ struct imp_knn {
   DeviceArray<uint64_t> gcand;
   DeviceArray<int32_t> dev_ids, counts, fallback;
   DeviceArray<float> dev_dist;
+  // emit path
+  DeviceArray<float> sub_scores, fb_query, fb_dist;
+  DeviceArray<uint32_t> tau, row_bits, item_bits;
+  DeviceArray<unsigned int> cand_count;
+  DeviceArray<uint64_t> cand;
+  DeviceArray<int32_t> fb_rows, fb_ids;
   template <typename T> static T *ensure(DeviceArray<T> &a, size_t n) {
     if (a.size < n) a.alloc(n);
     return a.data();
@@ -609,7 +852,9 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
 
     size_t temp = std::min<size_t>(knn->max_temp_memory, (size_t)4 << 30);
     size_t batch = std::max<size_t>(1, std::min<size_t>(nq, temp / (sizeof(float) * ni)));
-    float *scores = imp_knn::ensure(knn->scores, batch * ni);
+    static const bool no_emit_alloc = getenv("IMP_TOPK_NO_EMIT") != nullptr;
+    const bool will_emit = !no_emit_alloc && getenv("IMP_TOPK_NO_FAST") == nullptr && (f % 8 == 0) && ni >= 32768 && k_eff == k && k_eff <= 256;
+    float *scores = will_emit ? nullptr : imp_knn::ensure(knn->scores, batch * ni);  // the emit path materialises fallback rows only
     const bool use_lds = (size_t)kpad * 8 <= 96 * 1024;
     uint64_t *gcand = use_lds ? nullptr : imp_knn::ensure(knn->gcand, batch * (size_t)kpad);
 
@@ -617,10 +862,114 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
     static const bool no_fast = getenv("IMP_TOPK_NO_FAST") != nullptr;
     const bool fast = !no_fast && (f % 8 == 0) && k_eff <= kCandCap;
     const int n_tiles = (int)((ni + kTileItems - 1) / kTileItems);
-    float *tile_max = fast ? imp_knn::ensure(knn->tile_max, batch * (size_t)n_tiles) : nullptr;
-    int *fallback = fast ? imp_knn::ensure(knn->fallback, batch) : nullptr;
+    float *tile_max = (fast && !will_emit) ? imp_knn::ensure(knn->tile_max, batch * (size_t)n_tiles) : nullptr;
+    int *fallback = (fast && !will_emit) ? imp_knn::ensure(knn->fallback, batch) : nullptr;
     int *counts = nullptr;  // tile maxima are refreshed after the filters: no slack for filtered entries is needed
     const int extra = 0;
+
+    // emit path (no score matrix): large item sets, k small against the candidate lists
+    static const bool no_emit = getenv("IMP_TOPK_NO_EMIT") != nullptr;
+    const bool emit_path = fast && !no_emit && ni >= 32768 && k_eff == k && k_eff <= 256;
+    if (emit_path) {
+      const float *norms = item_norms ? item_norms->f32() : nullptr;
+      const int words = (int)((ni + 31) / 32);
+      const int n_blocks = (int)((ni + 127) / 128), n_sub = (n_blocks + kSubStride - 1) / kSubStride, sub_cols = n_sub * 128;
+      const size_t ebatch = std::min<size_t>(nq, 2048);
+      constexpr int FB = 64;  // fallback rows per materialised group
+      float *sub = imp_knn::ensure(knn->sub_scores, ebatch * (size_t)sub_cols);
+      uint32_t *tau = imp_knn::ensure(knn->tau, ebatch);
+      unsigned int *cnt = imp_knn::ensure(knn->cand_count, ebatch);
+      uint64_t *cand = imp_knn::ensure(knn->cand, ebatch * (size_t)kEmitCap);
+      int *fallback_e = imp_knn::ensure(knn->fallback, ebatch);
+      const bool have_coo = query_filter && query_filter->nnz, have_items = item_filter && item_filter->size;
+      uint32_t *row_bits = have_coo ? imp_knn::ensure(knn->row_bits, ebatch * (size_t)words) : nullptr;
+      uint32_t *item_bits = have_items ? imp_knn::ensure(knn->item_bits, (size_t)words) : nullptr;
+      if (have_items) IMP_CHECK_HIP(hipMemsetAsync(item_bits, 0, (size_t)words * 4, stream()));
+      std::vector<int> flags(ebatch);
+      std::vector<int32_t> fb_list;
+      for (size_t start = 0; start < nq; start += ebatch) {
+        const size_t end = std::min(nq, start + ebatch), rows = end - start;
+        const float *qptr = query->f32() + start * f;
+        const unsigned qblocks = (unsigned)((rows + 127) / 128);
+        if (have_coo) IMP_CHECK_HIP(hipMemsetAsync(row_bits, 0, rows * (size_t)words * 4, stream()));
+        {
+          IMP_PROF("score_gemm_subset");
+          score_gemm_direct_kernel<1><<<dim3((unsigned)n_sub, qblocks), 256, 0, stream()>>>(qptr, (int)rows, items->f32(), (int)ni, f, norms,
+                                                                                          sub, nullptr, 0, kSubStride, EmitArgs{});
+          IMP_CHECK_HIP(hipGetLastError());
+        }
+        if (have_items) {
+          IMP_PROF("item_filter");
+          int grid = (int)std::min<size_t>((item_filter->size + 255) / 256, (size_t)ctx().num_cus * 8);
+          item_bitmap_kernel<<<grid, 256, 0, stream()>>>(item_bits, (int)ni, item_filter->v.data(), (int)item_filter->size, sub, (int)rows,
+                                                         sub_cols);
+          IMP_CHECK_HIP(hipGetLastError());
+        }
+        if (have_coo) {
+          IMP_PROF("coo_filter");
+          int grid = (int)std::min<size_t>(((size_t)query_filter->nnz + 255) / 256, (size_t)ctx().num_cus * 8);
+          coo_bitmap_kernel<<<grid, 256, 0, stream()>>>(row_bits, words, (int)start, (int)end, (int)ni, query_filter->row.data(),
+                                                        query_filter->col.data(), (size_t)query_filter->nnz, sub, sub_cols);
+          IMP_CHECK_HIP(hipGetLastError());
+        }
+        {
+          IMP_PROF("topk_threshold");
+          subset_threshold_kernel<512><<<(unsigned)rows, 512, 0, stream()>>>(sub, sub_cols, k_eff, tau, cnt);
+          IMP_CHECK_HIP(hipGetLastError());
+        }
+        {
+          IMP_PROF("score_gemm");
+          EmitArgs ea{tau, row_bits, item_bits, words, cand, cnt, kEmitCap};
+          score_gemm_direct_kernel<2><<<dim3((unsigned)n_blocks, qblocks), 256, 0, stream()>>>(qptr, (int)rows, items->f32(), (int)ni, f,
+                                                                                             norms, nullptr, nullptr, 0, 1, ea);
+          IMP_CHECK_HIP(hipGetLastError());
+        }
+        {
+          IMP_PROF("topk_select_candidates");
+          select_candidates_kernel<512><<<(unsigned)rows, 512, 0, stream()>>>(cand, cnt, kEmitCap, k_eff, d_ids + start * k,
+                                                                             d_dist + start * k, k, fallback_e);
+          IMP_CHECK_HIP(hipGetLastError());
+        }
+        IMP_CHECK_HIP(hipMemcpyAsync(flags.data(), fallback_e, rows * sizeof(int), hipMemcpyDeviceToHost, stream()));
+        sync();
+        fb_list.clear();
+        for (size_t i = 0; i < rows; ++i)
+          if (flags[i]) fb_list.push_back((int32_t)i);
+        if (!fb_list.empty()) {  // overflow / short list / exact tie at the k-th score: the materialising path, FB rows at a time
+          IMP_PROF("topk_fallback");
+          int32_t *d_rows = imp_knn::ensure(knn->fb_rows, fb_list.size());
+          IMP_CHECK_HIP(hipMemcpyAsync(d_rows, fb_list.data(), fb_list.size() * 4, hipMemcpyHostToDevice, stream()));
+          float *fbq = imp_knn::ensure(knn->fb_query, (size_t)FB * f);
+          float *fscores = imp_knn::ensure(knn->scores, (size_t)FB * ni);
+          float *ftile = imp_knn::ensure(knn->tile_max, (size_t)FB * n_tiles);
+          int32_t *fids = imp_knn::ensure(knn->fb_ids, (size_t)FB * k);
+          float *fdist = imp_knn::ensure(knn->fb_dist, (size_t)FB * k);
+          uint64_t *fg = use_lds ? nullptr : imp_knn::ensure(knn->gcand, (size_t)FB * kpad);
+          const size_t lds = use_lds ? (size_t)kpad * 8 : 0;
+          auto kern = select_kernel<512>;
+          IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)std::max<size_t>(lds, 1)));
+          for (size_t g0 = 0; g0 < fb_list.size(); g0 += FB) {
+            const int n = (int)std::min<size_t>(FB, fb_list.size() - g0);
+            gather_query_rows_kernel<<<std::max(1, (n * f + 255) / 256), 256, 0, stream()>>>(qptr, d_rows + g0, n, f, fbq);
+            score_gemm_direct_kernel<0><<<dim3((unsigned)n_blocks, 1), 256, 0, stream()>>>(fbq, n, items->f32(), (int)ni, f, norms, fscores,
+                                                                                         ftile, n_tiles, 1, EmitArgs{});
+            if (have_coo || have_items) {
+              int grid = (int)std::min<size_t>(((size_t)n * n_tiles + 255) / 256, (size_t)ctx().num_cus * 8);
+              bitmap_filter_kernel<<<grid, 256, 0, stream()>>>(fscores, ftile, (int)ni, n_tiles, d_rows + g0, n, row_bits, item_bits, words);
+            }
+            kern<<<(unsigned)n, 512, lds, stream()>>>(fscores, (int)ni, k_eff, kpad, fids, fdist, k, fg, use_lds ? 1 : 0, nullptr);
+            scatter_topk_rows_kernel<<<std::max(1, (n * k + 255) / 256), 256, 0, stream()>>>(fids, fdist, d_rows + g0, n, k,
+                                                                                         d_ids + start * k, d_dist + start * k);
+            IMP_CHECK_HIP(hipGetLastError());
+          }
+        }
+      }
+      if (host_ids) IMP_CHECK_HIP(hipMemcpyAsync(indices, d_ids, nq * (size_t)k * 4, hipMemcpyDeviceToHost, stream()));
+      if (host_dist) IMP_CHECK_HIP(hipMemcpyAsync(distances, d_dist, nq * (size_t)k * 4, hipMemcpyDeviceToHost, stream()));
+      sync();
+      return;
+    }
 
     for (size_t start = 0; start < nq; start += batch) {
       size_t end = std::min(nq, start + batch), rows = end - start;
@@ -628,9 +977,9 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
       if (fast) {
         IMP_PROF("score_gemm");
         dim3 grid((unsigned)((ni + 127) / 128), (unsigned)((rows + 127) / 128));
-        score_gemm_direct_kernel<<<grid, 256, 0, stream()>>>(query->f32() + start * f, (int)rows, items->f32(), (int)ni, f,
-                                                             item_norms ? item_norms->f32() : nullptr, scores, tile_max,
-                                                             n_tiles);
+        score_gemm_direct_kernel<0><<<grid, 256, 0, stream()>>>(query->f32() + start * f, (int)rows, items->f32(), (int)ni, f,
+                                                                item_norms ? item_norms->f32() : nullptr, scores, tile_max,
+                                                                n_tiles, 1, EmitArgs{});
         IMP_CHECK_HIP(hipGetLastError());
       } else {
         IMP_PROF("score_gemm_lds");

@@ -268,3 +268,33 @@ def test_model_fit_with_a_communicator(gpu, oracle):
     import pickle
 
     assert pickle.loads(pickle.dumps(model)).comm is None
+
+
+def test_topk_emit_path_and_its_fallbacks(gpu, oracle):
+    """The score-matrix-free top-k (>= 32768 items): random rows with both filters, and the rows it must hand back to the
+    materialising path -- exact ties at the k-th score (all-equal rows: the reference heap's arrival-order rule), rows
+    whose whole threshold subset is filtered (no valid lower bound), candidate overflow (thousands of tied maxima)."""
+    rng = np.random.default_rng(11)
+    ni, f, k = 40_000, 64, 10
+    items = (rng.standard_normal((ni, f)) * 0.1).astype(np.float32)
+    items[::7] = items[3]                          # thousands of identical items: ties everywhere they score high
+    queries = (rng.standard_normal((70, f)) * 0.1).astype(np.float32)
+    queries[5] = 0.0                               # all scores 0: every item ties
+    queries[6] = items[3] * 4                      # the duplicated item is the best: > 5000 candidates tie at the top
+    # per-query filter: query 0 filters the whole threshold subset (every 32nd 128-item block), query 1 a random set
+    sub = np.concatenate([np.arange(b * 128, min(ni, b * 128 + 128)) for b in range(0, (ni + 127) // 128, 32)])
+    rows = np.concatenate([np.zeros(len(sub), dtype=np.int64), np.ones(500, dtype=np.int64)])
+    cols = np.concatenate([sub, rng.choice(ni, 500, replace=False)])
+    liked = sp.csr_matrix((np.ones(len(rows), dtype=np.float32), (rows, cols)), shape=(70, ni))
+    banned = rng.choice(ni, 300, replace=False).astype(np.int32)
+    ids, d = gpu.KnnQuery().topk(gpu.Matrix(items), gpu.Matrix(queries), k, query_filter=gpu.COOMatrix(liked.tocoo()),
+                                 item_filter=gpu.IntVector(banned))
+    want_ids, want_d = oracle.topk(items, queries, k, filter_query_items=liked, filter_items=banned)
+    np.testing.assert_allclose(d, want_d, rtol=2e-5, atol=1e-7)
+    exact_rows = [5, 6]                            # pure tie rows: ids must follow select.h bit for bit
+    np.testing.assert_array_equal(ids[exact_rows], want_ids[exact_rows])
+    assert not (set(ids[0]) & set(sub.tolist())) and not (set(ids.ravel().tolist()) & set(banned.tolist()))
+    plain = [r for r in range(70) if r not in exact_rows]
+    assert (ids[plain] == want_ids[plain]).mean() > 0.97     # duplicated items tie: order inside a tie group may differ
+    for r in plain:
+        assert sorted(d[r], reverse=True) == list(d[r])

@@ -15,7 +15,11 @@ SUITE = os.path.join(ROOT, "build", "refsuite")
 
 
 def _run(args):
-    env = dict(os.environ, PYTHONPATH=os.pathsep.join([SUITE, os.path.join(SUITE, "tests"), ROOT]), OPENBLAS_NUM_THREADS="1")
+    # the reference's CPU extensions call BLAS from every OpenMP thread and OpenBLAS serves at most 128 concurrent callers:
+    # on the 256-core GPU box its own calculate_loss (als_test.py::test_gpu_loss, CPU leg) segfaults with the default thread
+    # count -- nothing of this repository is involved -- hence the caps
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([SUITE, os.path.join(SUITE, "tests"), ROOT]), OPENBLAS_NUM_THREADS="1",
+               OMP_NUM_THREADS="32")
     out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", *args], cwd=os.path.join(SUITE, "tests"),
                          env=env, capture_output=True, text=True, timeout=1500)
     tail = out.stdout[-3000:] + out.stderr[-1500:]
