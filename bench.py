@@ -374,7 +374,8 @@ def main():
         del Cui_d, Ciu_d, X, Y
         out["extras_note"] = ("secondary measurements on the other BASELINE configs (synthetic, inputs resident, HIP-event / "
                               "wall times of 3 iterations after 1 warm-up); `value` above is configs[2] only")
-        for name, fn in (("fit_c3", lambda: extra_fit(gpu, Cui)), ("c2", lambda: extra_c2(gpu, SHAPES)),
+        for name, fn in (("fit_c3", lambda: extra_fit(gpu, Cui)), ("fp16_c3", lambda: extra_fp16(gpu, Cui, Ciu, X0, Y0)),
+                         ("c2", lambda: extra_c2(gpu, SHAPES)),
                          ("c5", lambda: extra_c5(gpu, SHAPES)), ("c4_shard", lambda: extra_c4_shard(gpu, SHAPES))):
             t0 = time.time()
             try:
@@ -422,6 +423,57 @@ def extra_fit(gpu, Cui):
                        "setup_s": total - sum(times),
                        "note": "AlternatingLeastSquares.fit() on the configs[2] matrix: setup = float32/CSR checks, host "
                                "transpose, two CSRMatrix uploads with their row schedules, factor init and upload"}}
+
+
+def extra_fp16(gpu, Cui, Ciu, X0, Y0):
+    """configs[2] with fp16 factor STORAGE (the reference's dtype=np.float16 mode, tests/als_test.py:30-34): the f=128 kernels
+    load / store half precision directly, arithmetic and CG state stay fp32 -- the gathered bytes per nonzero halve."""
+    f = X0.shape[1]
+    X, Y = gpu.Matrix(X0.astype(np.float16)), gpu.Matrix(Y0.astype(np.float16))
+    Cd, Ctd = gpu.CSRMatrix(Cui), gpu.CSRMatrix(Ciu)
+    gram = gpu.Matrix.zeros(f, f)
+    solver = gpu.LeastSquaresSolver()
+
+    def step():
+        solver.calculate_yty(Y, gram, REG)
+        solver.least_squares(Cd, X, gram, Y, CG_STEPS)
+        solver.calculate_yty(X, gram, REG)
+        solver.least_squares(Ctd, Y, gram, X, CG_STEPS)
+
+    t, kernels = _time_iterations(gpu, step)
+    rows, nnz = Cui.shape[0] + Cui.shape[1], int(Cui.nnz)
+    gb = (2 * nnz * (2 * f + 8) + rows * (4 * f + 8) + 2 * 4 * f * f) / 1e9  # SURVEY 8d's formula with 2-byte factors
+    model_rows = 1000
+    fold = _fold_in_latency(gpu, Cui, X0, Y0, model_rows)
+    return {"fp16_c3": {"workload": "configs[2] matrix, factors stored as float16 (fp32 arithmetic), CG cg_steps=%d" % CG_STEPS,
+                        "ms_per_iter": 1e3 * t, "updates_per_s": rows / t,
+                        "roofline": {"bound": "hbm", "achieved": gb / t, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": gb / t / HBM_PEAK_GBS, "algorithmic_GB_per_iter": gb},
+                        "kernels_ms_per_iter": kernels},
+            "fold_in_c3": fold}
+
+
+def _fold_in_latency(gpu, Cui, X0, Y0, batch):
+    """recalculate_user / partial_fit_users (implicit/gpu/als.py:184-278) on a trained-shape model: the second caller of the
+    solver, small batches where launch latency and the CSR upload dominate."""
+    from implicit_amd.als import AlternatingLeastSquares
+
+    model = AlternatingLeastSquares(factors=X0.shape[1], regularization=REG, use_gpu=True)
+    model.user_factors, model.item_factors = gpu.Matrix(X0), gpu.Matrix(Y0)
+    out = {}
+    for n in (1, 100, batch):
+        ids = np.arange(n)
+        rows = Cui[:n]
+        model.recalculate_user(ids, rows)  # warm-up (builds the cached gramian)
+        gpu.synchronize()
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            model.recalculate_user(ids, rows)
+        gpu.synchronize()
+        out[f"recalculate_user_{n}_rows_ms"] = 1e3 * (time.perf_counter() - t0) / reps
+    out["note"] = "host CSR slice upload + one solver call per batch; Cholesky fold-in for factors <= 160, else CG run to f steps"
+    return out
 
 
 def extra_c2(gpu, SHAPES):

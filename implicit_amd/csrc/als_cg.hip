@@ -21,6 +21,8 @@
 //     segment-parallel partial kernel plus a per-row combine/update kernel, so a 150K-nnz row is
 //     spread over the whole chip instead of serialising one workgroup (fixed summation order).
 //   * any other f <= 512 runs a generic lane-strided variant of the same structure.
+#include <type_traits>
+
 #include "common.h"
 #include "wave_ops.h"
 #include "als_qtile.h"
@@ -28,7 +30,7 @@
 
 namespace imp {
 
-void least_squares_cg_q(const imp_csr *C, float *X, const float *Y, const float *A0, int f, int cg_steps);      // als_cg_q.hip
+template <typename T> void least_squares_cg_q(const imp_csr *C, T *X, const T *Y, const float *A0, int f, int cg_steps);  // als_cg_q.hip
 
 // ---- generic per-nnz pass (any f): 4 gathers in flight, one DPP all-reduce per dot -------------------
 template <int VPL, bool VEC, bool FIRST>
@@ -206,10 +208,10 @@ __global__ __launch_bounds__(256) void cg_long_partial_kernel(const LongPlanDev 
 // Quarter-layout variant of the partial kernel (f = 64, 128): same segments, ~half the VALU work per tile pass.
 // The operand vector is read from memory directly in expanded form; the partial result is stored by factor index,
 // so cg_long_combine_kernel is unchanged.
-template <int F, bool FIRST>
+template <int F, bool FIRST, typename T>
 __global__ __launch_bounds__(256) void cg_long_partial_q_kernel(const LongPlanDev plan, const int32_t *__restrict__ indices,
-                                                                const float *__restrict__ data, const float *__restrict__ X,
-                                                                const float *__restrict__ Y, float *__restrict__ partial,
+                                                                const float *__restrict__ data, const T *__restrict__ X,
+                                                                const T *__restrict__ Y, float *__restrict__ partial,
                                                                 const float *__restrict__ pvec, const float *__restrict__ scal) {
   constexpr int FE = F / 16, FC = F / 64, LD = F;
   const int lane = threadIdx.x & 63;
@@ -238,11 +240,12 @@ __global__ __launch_bounds__(256) void cg_long_partial_q_kernel(const LongPlanDe
     s1 = s2, li1 = li2, b1 = b2, e1 = e2;
     descriptor(i + 2 * nwaves, s2, li2, b2, e2);
     const bool skip = !FIRST && scal[2 * li + 1] != 0.f;  // row finished (early exit): no arithmetic, no partial
-    const float *vsrc = (FIRST ? X + (size_t)plan.rows[li] * F : pvec + (size_t)li * LD) + 4 * (lane & 15);
     float ve[FE], ae[FE];
 #pragma unroll
     for (int e = 0; e < FE; e += 4) {
-      const float4 v = *reinterpret_cast<const float4 *>(vsrc + 16 * e);
+      float4 v;  // the operand in expanded form: x of the row (factor storage type) or the fp32 search direction
+      if constexpr (FIRST) v = load4(X + (size_t)plan.rows[li] * F + 4 * (lane & 15) + 16 * e);
+      else v = load4(pvec + (size_t)li * LD + 4 * (lane & 15) + 16 * e);
       ve[e] = v.x, ve[e + 1] = v.y, ve[e + 2] = v.z, ve[e + 3] = v.w;
       ae[e] = ae[e + 1] = ae[e + 2] = ae[e + 3] = 0.f;
     }
@@ -263,11 +266,29 @@ __global__ __launch_bounds__(256) void cg_long_partial_q_kernel(const LongPlanDe
 
 // PHASE 0: r = sum(partials) - A0 x ; p = r ; rsold = r.r ; done = rsold < 1e-20
 // PHASE 1: Ap = sum(partials) + A0 p ; alpha ; x += alpha p ; r -= alpha Ap ; rsnew ; done |= rsnew < 1e-20 ; p = r + beta p
-template <int VPL, bool VEC, int BLOCK, bool A_LDS, int PHASE>
-__global__ __launch_bounds__(BLOCK) void cg_long_combine_kernel(const LongPlanDev plan, float *__restrict__ X,
+// row of X in the factor storage type <-> the lane-contiguous fp32 registers of the generic kernels (VEC layouts only for fp16)
+template <int VPL, bool VEC> __device__ __forceinline__ void load_xrow(const float *row, int f, int lane, float (&x)[VPL]) {
+  load_row<VPL, VEC>(row, f, lane, x);
+}
+template <int VPL, bool VEC> __device__ __forceinline__ void load_xrow(const __half *row, int f, int lane, float (&x)[VPL]) {
+  static_assert(VEC && VPL <= 2, "fp16 rows: f = 64 / 128 only");
+  if constexpr (VPL == 2) {
+    const float2 t = load2(row + 2 * lane);
+    x[0] = t.x, x[1] = t.y;
+  } else {
+    x[0] = load1(row + lane);
+  }
+}
+template <typename T> __device__ __forceinline__ void store_x(T *p, float v) { store1(p, v); }
+
+template <int VPL, bool VEC, int BLOCK, bool A_LDS, int PHASE, typename T>
+__global__ __launch_bounds__(BLOCK) void cg_long_combine_kernel(const LongPlanDev plan, T *__restrict__ X,
                                                                 const float *__restrict__ A0, int f,
                                                                 const float *__restrict__ partial, float *__restrict__ rvec,
-                                                                float *__restrict__ pvec, float *__restrict__ scal) {
+                                                                float *__restrict__ pvec, float *__restrict__ scal,
+                                                                float *__restrict__ xvec) {
+  // xvec (fp16 factor storage only): the fp32 iterate of every long row between passes -- X itself would round it to
+  // fp16 after every CG step, where the resident kernels (and the reference, als.cu:45-109) round once at the end
   constexpr int LD = 64 * VPL;
   constexpr int WAVES = BLOCK / 64;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -278,7 +299,7 @@ __global__ __launch_bounds__(BLOCK) void cg_long_combine_kernel(const LongPlanDe
   const int vld = VEC ? LD : f;  // logical length for guarded loads from the LD-strided workspaces
   for (int li = blockIdx.x * WAVES + wave; li < plan.n_long; li += gridDim.x * WAVES) {
     if (PHASE == 1 && scal[2 * li + 1] != 0.f) continue;
-    float *xrow = X + (size_t)plan.rows[li] * f;
+    T *xrow = X + (size_t)plan.rows[li] * f;
     float acc[VPL];
     const int s0 = plan.row_seg[li], s1 = plan.row_seg[li + 1];
     {  // fixed association: NS interleaved running sums, folded pairwise (a 147 K-nnz row has 288 segment partials;
@@ -313,7 +334,8 @@ __global__ __launch_bounds__(BLOCK) void cg_long_combine_kernel(const LongPlanDe
         acc[v] = ((a8[0][v] + a8[1][v]) + (a8[2][v] + a8[3][v])) + ((a8[4][v] + a8[5][v]) + (a8[6][v] + a8[7][v]));
     }
     float x[VPL], dense[VPL];
-    load_row<VPL, VEC>(xrow, f, lane, x);
+    if (PHASE == 1 && xvec) load_row<VPL, VEC>(xvec + (size_t)li * LD, VEC ? LD : f, lane, x);
+    else load_xrow<VPL, VEC>(xrow, f, lane, x);
 #pragma unroll
     for (int v = 0; v < VPL; ++v) dense[v] = 0.f;
     if (PHASE == 0) {
@@ -327,6 +349,7 @@ __global__ __launch_bounds__(BLOCK) void cg_long_combine_kernel(const LongPlanDe
         int e = elem<VPL, VEC>(lane, v);
         rvec[(size_t)li * LD + e] = r[v];
         pvec[(size_t)li * LD + e] = r[v];
+        if (xvec) xvec[(size_t)li * LD + e] = x[v];
       }
       if (lane == 0) {
         scal[2 * li] = rsold;
@@ -352,7 +375,8 @@ __global__ __launch_bounds__(BLOCK) void cg_long_combine_kernel(const LongPlanDe
 #pragma unroll
       for (int v = 0; v < VPL; ++v) {
         int e = elem<VPL, VEC>(lane, v);
-        if (e < f) xrow[e] = x[v];
+        if (e < f) store_x(xrow + e, x[v]);
+        if (xvec) xvec[(size_t)li * LD + e] = x[v];
         rvec[(size_t)li * LD + e] = r[v];
         pvec[(size_t)li * LD + e] = fmaf(beta, p[v], r[v]);
       }
@@ -364,22 +388,24 @@ __global__ __launch_bounds__(BLOCK) void cg_long_combine_kernel(const LongPlanDe
   }
 }
 
-__global__ void zero_rows_kernel(const int32_t *__restrict__ order, int first, int count, float *__restrict__ X, int f) {
+template <typename T>
+__global__ void zero_rows_kernel(const int32_t *__restrict__ order, int first, int count, T *__restrict__ X, int f) {
   size_t total = (size_t)count * f;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     size_t r = i / f, c = i - r * f;
-    X[(size_t)order[first + r] * f + c] = 0.f;
+    store1(X + (size_t)order[first + r] * f + c, 0.f);
   }
 }
 
-void zero_rows(const int32_t *order, int first, int count, float *X, int f) {
+template <typename T> static void zero_rows_t(const int32_t *order, int first, int count, T *X, int f) {
   if (count <= 0) return;
   IMP_PROF("zero_rows");
   size_t total = (size_t)count * f;
   int grid = (int)std::min<size_t>((total + 255) / 256, (size_t)ctx().num_cus * 8);
-  zero_rows_kernel<<<grid, 256, 0, stream()>>>(order, first, count, X, f);
+  zero_rows_kernel<T><<<grid, 256, 0, stream()>>>(order, first, count, X, f);
   IMP_CHECK_HIP(hipGetLastError());
 }
+void zero_rows(const int32_t *order, int first, int count, float *X, int f) { zero_rows_t<float>(order, first, count, X, f); }
 
 template <int VPL, bool VEC, bool A_LDS, bool RESIDENT>
 static void launch_fused(const imp_csr *C, int first, int count, float *X, const float *Y, const float *A0, int f,
@@ -399,24 +425,26 @@ static void launch_fused(const imp_csr *C, int first, int count, float *X, const
   IMP_CHECK_HIP(hipGetLastError());
 }
 
-template <int VPL, bool VEC, bool A_LDS>
-static void launch_long(const imp_csr *C, float *X, const float *Y, const float *A0, int f, int cg_steps) {
+template <int VPL, bool VEC, bool A_LDS, typename T>
+static void launch_long(const imp_csr *C, T *X, const T *Y, const float *A0, int f, int cg_steps) {
   const int n_long = C->n_long, n_seg = C->n_seg;
   if (n_long <= 0) return;
   constexpr int BLOCK = 512;
   constexpr int LD = 64 * VPL;
-  size_t need = ((size_t)n_seg + 2 * (size_t)n_long) * LD + 2 * (size_t)n_long;
+  constexpr bool kHalf = !std::is_same<T, float>::value;
+  size_t need = ((size_t)n_seg + (kHalf ? 3 : 2) * (size_t)n_long) * LD + 2 * (size_t)n_long;
   auto &ws = ctx().long_ws;
   if (ws.size < need) ws.alloc(need);
   float *partial = ws.data();
   float *rvec = partial + (size_t)n_seg * LD;
   float *pvec = rvec + (size_t)n_long * LD;
   float *scal = pvec + (size_t)n_long * LD;
+  float *xvec = kHalf ? scal + 2 * (size_t)n_long : nullptr;
   LongPlanDev plan = C->long_plan_dev();
 
   size_t lds = (A_LDS ? (size_t)f * LD : 0) * sizeof(float);
-  auto comb0 = cg_long_combine_kernel<VPL, VEC, BLOCK, A_LDS, 0>;
-  auto comb1 = cg_long_combine_kernel<VPL, VEC, BLOCK, A_LDS, 1>;
+  auto comb0 = cg_long_combine_kernel<VPL, VEC, BLOCK, A_LDS, 0, T>;
+  auto comb1 = cg_long_combine_kernel<VPL, VEC, BLOCK, A_LDS, 1, T>;
   IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(comb0), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)std::max<size_t>(lds, 16)));
   IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(comb1), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -426,45 +454,45 @@ static void launch_long(const imp_csr *C, float *X, const float *Y, const float 
   {
     IMP_PROF("als_cg_long_partial");
     if constexpr (VEC && (VPL == 1 || VPL == 2))
-      cg_long_partial_q_kernel<64 * VPL, true>
+      cg_long_partial_q_kernel<64 * VPL, true, T>
           <<<grid_part, 256, 0, stream()>>>(plan, C->indices.data(), C->data.data(), X, Y, partial, pvec, scal);
-    else
+    else if constexpr (std::is_same<T, float>::value)
       cg_long_partial_kernel<VPL, VEC, true>
           <<<grid_part, 256, 0, stream()>>>(plan, C->indices.data(), C->data.data(), X, Y, f, partial, pvec, scal);
     IMP_CHECK_HIP(hipGetLastError());
   }
   {
     IMP_PROF("als_cg_long_combine");
-    comb0<<<grid_comb, BLOCK, lds, stream()>>>(plan, X, A0, f, partial, rvec, pvec, scal);
+    comb0<<<grid_comb, BLOCK, lds, stream()>>>(plan, X, A0, f, partial, rvec, pvec, scal, xvec);
     IMP_CHECK_HIP(hipGetLastError());
   }
   for (int it = 0; it < cg_steps; ++it) {
     {
       IMP_PROF("als_cg_long_partial");
       if constexpr (VEC && (VPL == 1 || VPL == 2))
-        cg_long_partial_q_kernel<64 * VPL, false>
+        cg_long_partial_q_kernel<64 * VPL, false, T>
             <<<grid_part, 256, 0, stream()>>>(plan, C->indices.data(), C->data.data(), X, Y, partial, pvec, scal);
-      else
+      else if constexpr (std::is_same<T, float>::value)
         cg_long_partial_kernel<VPL, VEC, false>
             <<<grid_part, 256, 0, stream()>>>(plan, C->indices.data(), C->data.data(), X, Y, f, partial, pvec, scal);
       IMP_CHECK_HIP(hipGetLastError());
     }
     {
       IMP_PROF("als_cg_long_combine");
-      comb1<<<grid_comb, BLOCK, lds, stream()>>>(plan, X, A0, f, partial, rvec, pvec, scal);
+      comb1<<<grid_comb, BLOCK, lds, stream()>>>(plan, X, A0, f, partial, rvec, pvec, scal, xvec);
       IMP_CHECK_HIP(hipGetLastError());
     }
   }
 }
 
-template <int VPL, bool VEC, bool A_LDS>
-static void launch_all(const imp_csr *C, float *X, const float *Y, const float *A0, int f, int cg_steps) {
+template <int VPL, bool VEC, bool A_LDS, typename T>
+static void launch_all(const imp_csr *C, T *X, const T *Y, const float *A0, int f, int cg_steps) {
   // schedule classes (imp_csr): 0 long (segment-split), 1..4 mid, 5..6 short, 7 empty
   const int32_t *b = C->bin_start;
-  launch_long<VPL, VEC, A_LDS>(C, X, Y, A0, f, cg_steps);
-  if (VEC && A_LDS && (f == 64 || f == 128)) {
-    least_squares_cg_q(C, X, Y, A0, f, cg_steps);  // quarter-layout register tiles, wave teams (als_cg_q.hip)
-  } else {
+  launch_long<VPL, VEC, A_LDS, T>(C, X, Y, A0, f, cg_steps);
+  if constexpr (VEC && A_LDS && (VPL == 1 || VPL == 2)) {
+    least_squares_cg_q<T>(C, X, Y, A0, f, cg_steps);  // quarter-layout register tiles, wave teams (als_cg_q.hip)
+  } else if constexpr (std::is_same<T, float>::value) {
     bool resident_ok = false;
     if constexpr (VEC) resident_ok = tile_size<VPL>() >= imp_csr::kShortRow;
     if constexpr (VEC) {
@@ -475,23 +503,34 @@ static void launch_all(const imp_csr *C, float *X, const float *Y, const float *
     }
     if (!resident_ok) launch_fused<VPL, VEC, A_LDS, false>(C, b[1], b[7] - b[1], X, Y, A0, f, cg_steps, "als_cg_mid_rows");
   }
-  zero_rows(C->order.data(), C->first_empty(), C->n_empty(), X, f);
+  zero_rows_t<T>(C->order.data(), C->first_empty(), C->n_empty(), X, f);
 }
+
+// fp16 factor storage is handled natively (converted in registers) by the f = 64 / 128 kernels
+bool cg_native_half(int f) { return f == 64 || f == 128; }
 
 void least_squares_cg(const imp_csr *C, imp_matrix *X, const imp_matrix *YtY, const imp_matrix *Y, int cg_steps) {
   const int f = (int)X->cols;
+  const float *a0 = YtY->f32();
+  if (X->itemsize == 2) {
+    if (!cg_native_half(f)) throw std::invalid_argument("least_squares: fp16 factors with this factor count are converted by the caller");
+    __half *x = reinterpret_cast<__half *>(X->data);
+    const __half *y = reinterpret_cast<const __half *>(Y->data);
+    if (f == 64) launch_all<1, true, true, __half>(C, x, y, a0, f, cg_steps);
+    else launch_all<2, true, true, __half>(C, x, y, a0, f, cg_steps);
+    return;
+  }
   float *x = X->f32();
   const float *y = Y->f32();
-  const float *a0 = YtY->f32();
-  if (f == 64) launch_all<1, true, true>(C, x, y, a0, f, cg_steps);
-  else if (f == 128) launch_all<2, true, true>(C, x, y, a0, f, cg_steps);
-  else if (f == 256) launch_all<4, true, false>(C, x, y, a0, f, cg_steps);
-  else if (f < 64) launch_all<1, false, true>(C, x, y, a0, f, cg_steps);
-  else if (f < 128) launch_all<2, false, true>(C, x, y, a0, f, cg_steps);
-  else if (f < 192) launch_all<3, false, true>(C, x, y, a0, f, cg_steps);
-  else if (f < 256) launch_all<4, false, false>(C, x, y, a0, f, cg_steps);
-  else if (f <= 384) launch_all<6, false, false>(C, x, y, a0, f, cg_steps);
-  else if (f <= 512) launch_all<8, false, false>(C, x, y, a0, f, cg_steps);
+  if (f == 64) launch_all<1, true, true, float>(C, x, y, a0, f, cg_steps);
+  else if (f == 128) launch_all<2, true, true, float>(C, x, y, a0, f, cg_steps);
+  else if (f == 256) launch_all<4, true, false, float>(C, x, y, a0, f, cg_steps);
+  else if (f < 64) launch_all<1, false, true, float>(C, x, y, a0, f, cg_steps);
+  else if (f < 128) launch_all<2, false, true, float>(C, x, y, a0, f, cg_steps);
+  else if (f < 192) launch_all<3, false, true, float>(C, x, y, a0, f, cg_steps);
+  else if (f < 256) launch_all<4, false, false, float>(C, x, y, a0, f, cg_steps);
+  else if (f <= 384) launch_all<6, false, false, float>(C, x, y, a0, f, cg_steps);
+  else if (f <= 512) launch_all<8, false, false, float>(C, x, y, a0, f, cg_steps);
   else throw std::invalid_argument("least_squares: factors must be <= 512 in this build");
 }
 

@@ -56,12 +56,12 @@ __device__ __forceinline__ void group_gram_matvec_q(const float *A0s, float *Ps,
 }
 
 // ---- short rows (<= 32 nnz): one wave per row, 16 rows per workgroup ----------------------------------------------
-template <int F>
+template <int F, typename T>
 __global__ __launch_bounds__(1024) void als_cg_qgroup_kernel(const int32_t *__restrict__ order, int first, int count,
                                                              const int32_t *__restrict__ indptr,
                                                              const int32_t *__restrict__ indices,
-                                                             const float *__restrict__ data, float *__restrict__ X,
-                                                             const float *__restrict__ Y, const float *__restrict__ A0,
+                                                             const float *__restrict__ data, T *__restrict__ X,
+                                                             const T *__restrict__ Y, const float *__restrict__ A0,
                                                              int cg_steps) {
   using Cfg = QGroupCfg<F>;
   constexpr int FC = F / 64, FE = F / 16, LD = Cfg::LD;
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(1024) void als_cg_qgroup_kernel(const int32_t *__re
     u1 = u2, rb1 = rb2, re1 = re2;                    // group g + 1: complete
     u2 = u3, rb2 = indptr[u2], re2 = indptr[u2 + 1];  // group g + 2: row id known -> its range
     u3 = row_id(g + 3 * g_step);                      // group g + 3: row id
-    float *xrow = X + (size_t)u * F;
+    T *xrow = X + (size_t)u * F;
     float x[FC], r[FC], p[FC], Ap[FC], sp[FC];
     load_compact<F>(xrow, lane, x);
     QTile<F> tile;
@@ -150,12 +150,12 @@ __global__ __launch_bounds__(1024) void als_cg_qgroup_kernel(const int32_t *__re
 // STATS (debug, IMP_CG_STATS=1): s_memtime ticks (shader-clock cycles on gfx950) summed over waves per phase --
 //   [0] row start -> tile resident (gathers drained)  [1] operand vector to LDS + expand  [2] dense part
 //   [3] tile entries  [4] reduce-scatter  [5] combine (barriers included)  [6] dots / CG update  [7] wave-rows
-template <int F, int WPR, int BLOCK, bool STATS = false>
+template <int F, int WPR, int BLOCK, bool STATS, typename ST>
 __global__ __launch_bounds__(BLOCK, 4) void als_cg_qteam_kernel(const int32_t *__restrict__ order, int first, int count,
                                                                 const int32_t *__restrict__ indptr,
                                                                 const int32_t *__restrict__ indices,
-                                                                const float *__restrict__ data, float *__restrict__ X,
-                                                                const float *__restrict__ Y, const float *__restrict__ A0,
+                                                                const float *__restrict__ data, ST *__restrict__ X,
+                                                                const ST *__restrict__ Y, const float *__restrict__ A0,
                                                                 int cg_steps, unsigned long long *__restrict__ stats = nullptr) {
   unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = 0;
   auto tick = [&](int slot) {  // charge the time since the previous tick to `slot`
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(BLOCK, 4) void als_cg_qteam_kernel(const int32_t *_
     u1 = u2, rb1 = rb2, re1 = re2;                    // row i + step: complete
     u2 = u3, rb2 = indptr[u2], re2 = indptr[u2 + 1];  // row i + 2 step: row id known -> its range
     u3 = row_id(i + 3 * i_step);                      // row i + 3 step: row id
-    float *xrow = X + (size_t)u * F;
+    ST *xrow = X + (size_t)u * F;
     float x[FC], r[FC], p[FC], Ap[FC];
     tick(-1);
     const int cnt = cnt_next;  // this wave's slice of the row (may be empty)
@@ -341,12 +341,12 @@ __global__ __launch_bounds__(BLOCK, 4) void als_cg_qteam_kernel(const int32_t *_
   }
 }
 
-template <int F>
-static void launch_qgroup(const imp_csr *C, int first, int count, float *X, const float *Y, const float *A0, int cg_steps,
+template <int F, typename T>
+static void launch_qgroup(const imp_csr *C, int first, int count, T *X, const T *Y, const float *A0, int cg_steps,
                           const char *name) {
   if (count <= 0) return;
   size_t lds = QGroupCfg<F>::lds_floats * sizeof(float);
-  auto kern = als_cg_qgroup_kernel<F>;
+  auto kern = als_cg_qgroup_kernel<F, T>;
   IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int grid = std::min((count + 15) / 16, ctx().num_cus * 2);
   IMP_PROF(name);
@@ -355,13 +355,13 @@ static void launch_qgroup(const imp_csr *C, int first, int count, float *X, cons
   IMP_CHECK_HIP(hipGetLastError());
 }
 
-template <int F, int WPR, int BLOCK>
-static void launch_qteam(const imp_csr *C, int first, int count, float *X, const float *Y, const float *A0, int cg_steps,
+template <int F, int WPR, int BLOCK, typename T>
+static void launch_qteam(const imp_csr *C, int first, int count, T *X, const T *Y, const float *A0, int cg_steps,
                          const char *name) {
   if (count <= 0) return;
   constexpr int WAVES = BLOCK / 64, TEAMS = WAVES / WPR;
   size_t lds = ((size_t)F * F + 3 * WAVES * F + TEAMS) * sizeof(float);
-  auto kern = als_cg_qteam_kernel<F, WPR, BLOCK>;
+  auto kern = als_cg_qteam_kernel<F, WPR, BLOCK, false, T>;
   IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / BLOCK, (160 * 1024) / lds));
   int grid = std::min((count + TEAMS - 1) / TEAMS, ctx().num_cus * per_cu);
@@ -370,7 +370,7 @@ static void launch_qteam(const imp_csr *C, int first, int count, float *X, const
     static unsigned long long *stats = nullptr;
     if (!stats) IMP_CHECK_HIP(hipMalloc(&stats, 8 * sizeof(unsigned long long)));
     IMP_CHECK_HIP(hipMemsetAsync(stats, 0, 8 * sizeof(unsigned long long), stream()));
-    auto skern = als_cg_qteam_kernel<F, WPR, BLOCK, true>;
+    auto skern = als_cg_qteam_kernel<F, WPR, BLOCK, true, T>;
     IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(skern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     skern<<<grid, BLOCK, lds, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(), C->data.data(), X,
                                          Y, A0, cg_steps, stats);
@@ -390,26 +390,28 @@ static void launch_qteam(const imp_csr *C, int first, int count, float *X, const
   IMP_CHECK_HIP(hipGetLastError());
 }
 
-template <int F> static void run_classes_q(const imp_csr *C, float *X, const float *Y, const float *A0, int cg_steps) {
+template <int F, typename T> static void run_classes_q(const imp_csr *C, T *X, const T *Y, const float *A0, int cg_steps) {
   const int32_t *b = C->bin_start;  // classes: 1 (256,512]  2 (128,256]  3 (64,128]  4 (32,64]  5 (16,32]  6 (0,16]
-  launch_qteam<F, 16, 1024>(C, b[1], b[2] - b[1], X, Y, A0, cg_steps, "als_cg_team16_rows");
-  launch_qteam<F, 8, 512>(C, b[2], b[3] - b[2], X, Y, A0, cg_steps, "als_cg_team8_rows");
-  launch_qteam<F, 4, 512>(C, b[3], b[4] - b[3], X, Y, A0, cg_steps, "als_cg_team4_rows");
-  launch_qteam<F, 2, 512>(C, b[4], b[5] - b[4], X, Y, A0, cg_steps, "als_cg_team2_rows");
+  launch_qteam<F, 16, 1024, T>(C, b[1], b[2] - b[1], X, Y, A0, cg_steps, "als_cg_team16_rows");
+  launch_qteam<F, 8, 512, T>(C, b[2], b[3] - b[2], X, Y, A0, cg_steps, "als_cg_team8_rows");
+  launch_qteam<F, 4, 512, T>(C, b[3], b[4] - b[3], X, Y, A0, cg_steps, "als_cg_team4_rows");
+  launch_qteam<F, 2, 512, T>(C, b[4], b[5] - b[4], X, Y, A0, cg_steps, "als_cg_team2_rows");
   // short rows.  f = 128: 16 rows per workgroup in lock step with the gramian product on fp32 MFMA (measured 1.16 ms per
   // C3 iteration against 1.38 ms for independent waves with the VALU product -- at f = 128 the product is 57 % of a short
   // row's arithmetic); f = 64: independent waves win (C2: 0.84 against 0.94 ms), the product is a quarter of the size
   // and the lock step costs more than the matrix pipe saves.  IMP_SHORT_TEAM1=0/1 forces one or the other (A/B).
   static const int short_team1 = getenv("IMP_SHORT_TEAM1") ? atoi(getenv("IMP_SHORT_TEAM1")) : -1;
   const bool team1 = short_team1 >= 0 ? short_team1 != 0 : F == 64;
-  if (team1) launch_qteam<F, 1, 512>(C, b[5], b[7] - b[5], X, Y, A0, cg_steps, "als_cg_short_rows");
-  else launch_qgroup<F>(C, b[5], b[7] - b[5], X, Y, A0, cg_steps, "als_cg_short_rows");  // tile steps beyond cnt are skipped
+  if (team1) launch_qteam<F, 1, 512, T>(C, b[5], b[7] - b[5], X, Y, A0, cg_steps, "als_cg_short_rows");
+  else launch_qgroup<F, T>(C, b[5], b[7] - b[5], X, Y, A0, cg_steps, "als_cg_short_rows");  // tile steps beyond cnt are skipped
 }
 
-void least_squares_cg_q(const imp_csr *C, float *X, const float *Y, const float *A0, int f, int cg_steps) {
-  if (f == 128) run_classes_q<128>(C, X, Y, A0, cg_steps);
-  else if (f == 64) run_classes_q<64>(C, X, Y, A0, cg_steps);
+template <typename T> void least_squares_cg_q(const imp_csr *C, T *X, const T *Y, const float *A0, int f, int cg_steps) {
+  if (f == 128) run_classes_q<128, T>(C, X, Y, A0, cg_steps);
+  else if (f == 64) run_classes_q<64, T>(C, X, Y, A0, cg_steps);
   else throw std::invalid_argument("least_squares_cg_q: f must be 64 or 128");
 }
+template void least_squares_cg_q<float>(const imp_csr *, float *, const float *, const float *, int, int);
+template void least_squares_cg_q<__half>(const imp_csr *, __half *, const __half *, const float *, int, int);
 
 }  // namespace imp

@@ -16,6 +16,8 @@
 // in whole steps (4 q >= cnt is wave-uniform).
 #ifndef IMPLICIT_AMD_CSRC_ALS_QTILE_H_
 #define IMPLICIT_AMD_CSRC_ALS_QTILE_H_
+#include <hip/hip_fp16.h>
+
 #include "als_tile.h"
 
 namespace imp {
@@ -32,22 +34,40 @@ template <int F> struct QL {
   __device__ static __forceinline__ int cfactor(int lane, int c) { return efactor(lane, FC * (lane >> 4) + c); }
 };
 
+// ---- factor storage: fp32, or fp16 converted in registers at the point of the load / store (the reference's kernels do the
+// same per element, implicit/gpu/als.cu:41,55,109 + convert.cuh:7-17); all arithmetic and the CG state stay fp32 ---------
+__device__ __forceinline__ float4 load4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ float4 load4(const __half *p) {  // 4 consecutive factors = one 8-byte load
+  const uint2 raw = *reinterpret_cast<const uint2 *>(p);
+  const float2 a = __half22float2(*reinterpret_cast<const __half2 *>(&raw.x));
+  const float2 b = __half22float2(*reinterpret_cast<const __half2 *>(&raw.y));
+  return make_float4(a.x, a.y, b.x, b.y);
+}
+__device__ __forceinline__ float2 load2(const float *p) { return *reinterpret_cast<const float2 *>(p); }
+__device__ __forceinline__ float2 load2(const __half *p) { return __half22float2(*reinterpret_cast<const __half2 *>(p)); }
+__device__ __forceinline__ float load1(const float *p) { return *p; }
+__device__ __forceinline__ float load1(const __half *p) { return __half2float(*p); }
+__device__ __forceinline__ void store2(float *p, float a, float b) { *reinterpret_cast<float2 *>(p) = make_float2(a, b); }
+__device__ __forceinline__ void store2(__half *p, float a, float b) { *reinterpret_cast<__half2 *>(p) = __floats2half2_rn(a, b); }
+__device__ __forceinline__ void store1(float *p, float a) { *p = a; }
+__device__ __forceinline__ void store1(__half *p, float a) { *p = __float2half_rn(a); }
+
 // compact <-> memory (a row of X, or an LD-strided LDS vector)
-template <int F> __device__ __forceinline__ void load_compact(const float *__restrict__ row, int lane, float (&v)[F / 64]) {
-  const float *p = row + QL<F>::cfactor(lane, 0);
+template <int F, typename T> __device__ __forceinline__ void load_compact(const T *__restrict__ row, int lane, float (&v)[F / 64]) {
+  const T *p = row + QL<F>::cfactor(lane, 0);
   if constexpr (F == 128) {
-    float2 t = *reinterpret_cast<const float2 *>(p);
+    const float2 t = load2(p);
     v[0] = t.x, v[1] = t.y;
   } else {
-    v[0] = *p;
+    v[0] = load1(p);
   }
 }
-template <int F> __device__ __forceinline__ void store_compact(float *__restrict__ row, int lane, const float (&v)[F / 64]) {
-  float *p = row + QL<F>::cfactor(lane, 0);
+template <int F, typename T> __device__ __forceinline__ void store_compact(T *__restrict__ row, int lane, const float (&v)[F / 64]) {
+  T *p = row + QL<F>::cfactor(lane, 0);
   if constexpr (F == 128) {
-    *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[1]);
+    store2(p, v[0], v[1]);
   } else {
-    *p = v[0];
+    store1(p, v[0]);
   }
 }
 
@@ -90,9 +110,9 @@ template <int F> struct QTile {
 };
 
 // entry t = 4 q + g of the tile covers nnz k0 + t; lanes past the end repeat the last valid entry with weight 0
-template <int F>
+template <int F, typename T>
 __device__ __forceinline__ void load_qtile(QTile<F> &tile, const int32_t *__restrict__ indices,
-                                           const float *__restrict__ data, const float *__restrict__ Y, int lane, int k0,
+                                           const float *__restrict__ data, const T *__restrict__ Y, int lane, int k0,
                                            int end) {
   constexpr int FE = QL<F>::FE, EQ = QL<F>::EQ;
   const int cnt = max(0, min(4 * EQ, end - k0));
@@ -110,10 +130,10 @@ __device__ __forceinline__ void load_qtile(QTile<F> &tile, const int32_t *__rest
   // gathers back to back, in two wave-uniform halves (q < 4 covers tile entries 0..15); few branches keep the
   // compiler's vmcnt bookkeeping exact so that all loads of a half are in flight together
   auto gather = [&](int q) {
-    const float *src = Y + (size_t)col[q] * F + 4 * (lane & 15);
+    const T *src = Y + (size_t)col[q] * F + 4 * (lane & 15);
 #pragma unroll
     for (int e = 0; e < FE; e += 4) {
-      float4 v = *reinterpret_cast<const float4 *>(src + 16 * e);  // expanded slots e..e+3 = factors 64 (e/4) + 4 m ..
+      const float4 v = load4(src + 16 * e);  // expanded slots e..e+3 = factors 64 (e/4) + 4 m ..
       tile.y[q][e] = v.x, tile.y[q][e + 1] = v.y, tile.y[q][e + 2] = v.z, tile.y[q][e + 3] = v.w;
     }
   };
@@ -146,8 +166,8 @@ __device__ __forceinline__ void fetch_entries(const int32_t *__restrict__ indice
   c = data[k];
 }
 
-template <int F>
-__device__ __forceinline__ void load_qtile_staged(QTile<F> &tile, int col_reg, float c_reg, const float *__restrict__ Y,
+template <int F, typename T>
+__device__ __forceinline__ void load_qtile_staged(QTile<F> &tile, int col_reg, float c_reg, const T *__restrict__ Y,
                                                   int lane, int cnt) {
   constexpr int FE = QL<F>::FE, EQ = QL<F>::EQ;
   tile.cnt = cnt;
@@ -163,10 +183,10 @@ __device__ __forceinline__ void load_qtile_staged(QTile<F> &tile, int col_reg, f
     tile.c[q] = t < cnt ? cv : -1.f;
   }
   auto gather = [&](int q) {
-    const float *src = Y + (size_t)col[q] * F + 4 * (lane & 15);
+    const T *src = Y + (size_t)col[q] * F + 4 * (lane & 15);
 #pragma unroll
     for (int e = 0; e < FE; e += 4) {
-      float4 v = *reinterpret_cast<const float4 *>(src + 16 * e);
+      const float4 v = load4(src + 16 * e);
       tile.y[q][e] = v.x, tile.y[q][e + 1] = v.y, tile.y[q][e + 2] = v.z, tile.y[q][e + 3] = v.w;
     }
   };

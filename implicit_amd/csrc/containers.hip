@@ -145,8 +145,9 @@ __global__ void gather_rows_kernel(const T *__restrict__ src, const int32_t *__r
   }
 }
 
-__global__ void scatter_rows_kernel(float *__restrict__ dst, const int32_t *__restrict__ rowids,
-                                    const float *__restrict__ src, size_t nrows, size_t cols) {
+template <typename T>
+__global__ void scatter_rows_kernel(T *__restrict__ dst, const int32_t *__restrict__ rowids,
+                                    const T *__restrict__ src, size_t nrows, size_t cols) {
   size_t total = nrows * cols;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x) {
@@ -331,12 +332,18 @@ int imp_matrix_assign_rows(imp_matrix *m, const imp_intvector *rowids, const imp
   return guarded([&] {
     if (other->cols != m->cols) throw std::invalid_argument("column dimension mismatch for Matrix::assign_rows");
     if (other->rows != rowids->size) throw std::invalid_argument("row dimension mismatch for Matrix::assign_rows");
-    float *dst = m->f32();
-    const float *src = other->f32();
+    // the reference scatters fp32 only (matrix.cu:133-134); fp16 -> fp16 is accepted here as well, so that a half-precision
+    // model's partial_fit_* stays on the device
+    if (other->itemsize != m->itemsize) throw std::invalid_argument("dtype mismatch for Matrix::assign_rows");
     size_t total = other->rows * other->cols;
     if (total) {
       IMP_PROF("scatter_rows");
-      scatter_rows_kernel<<<grid_for(total), 256, 0, stream()>>>(dst, rowids->v.data(), src, other->rows, other->cols);
+      if (m->itemsize == 4)
+        scatter_rows_kernel<float><<<grid_for(total), 256, 0, stream()>>>(m->f32(), rowids->v.data(), other->f32(), other->rows,
+                                                                          other->cols);
+      else
+        scatter_rows_kernel<__half><<<grid_for(total), 256, 0, stream()>>>((__half *)m->data, rowids->v.data(),
+                                                                           (const __half *)other->data, other->rows, other->cols);
       IMP_CHECK_HIP(hipGetLastError());
     }
     sync();

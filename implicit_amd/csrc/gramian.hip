@@ -9,6 +9,8 @@
 // segments of the same two rows -- no LDS staging needed), accumulating a 32x32 tile of Y^T Y.
 // The row range is split over grid.x (split-K); partial tiles go to a workspace and a second
 // kernel sums them in a FIXED order and adds reg on the diagonal, so the result is deterministic.
+#include <hip/hip_fp16.h>
+
 #include "common.h"
 
 namespace imp {
@@ -16,8 +18,8 @@ namespace imp {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // TJ = number of 32-wide column tiles this block covers (<= 8); tile rows: one per wave.
-template <int TJ>
-__global__ __launch_bounds__(256) void gramian_partial_kernel(const float *__restrict__ Y, long n_rows, int f,
+template <int TJ, typename T>
+__global__ __launch_bounds__(256) void gramian_partial_kernel(const T *__restrict__ Y, long n_rows, int f,
                                                               long rows_per_chunk, float *__restrict__ ws) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -56,10 +58,10 @@ __global__ __launch_bounds__(256) void gramian_partial_kernel(const float *__res
       for (int s = 0; s < 4; ++s) {
         const long r = r0 + 2 * s + khalf;
         mask_r[buf][s] = -(int)(r < r_end);
-        const float *row = Y + min(r, n_rows - 1) * (long)f;
-        a[buf][s] = row[ca];
+        const T *row = Y + min(r, n_rows - 1) * (long)f;
+        a[buf][s] = (float)row[ca];  // fp16 storage converts here; the products are fp32
 #pragma unroll
-        for (int t = 0; t < TJ; ++t) b[buf][s][t] = row[cb[t]];
+        for (int t = 0; t < TJ; ++t) b[buf][s][t] = (float)row[cb[t]];
       }
     };
     auto masked = [](float v, int m) { return __int_as_float(__float_as_int(v) & m); };
@@ -121,7 +123,7 @@ __global__ void gramian_reduce_kernel(const float *__restrict__ ws, int chunks, 
 }
 
 // out (f x f) = Y^T Y + reg I over rows [0, n_rows) of Y
-void gramian(const float *Y, long n_rows, int f, float reg, float *out) {
+template <typename T> static void gramian_t(const T *Y, long n_rows, int f, float reg, float *out) {
   const int n_tiles = (f + 31) / 32;
   const int gy = (n_tiles + 3) / 4, gz = (n_tiles + 7) / 8;
   long target_chunks = std::max(1, ctx().num_cus * 2 / (gy * gz));
@@ -139,14 +141,14 @@ void gramian(const float *Y, long n_rows, int f, float reg, float *out) {
     int tj = std::min(n_tiles, 8);
     float *ws = wsbuf.data();
     switch (tj) {
-      case 1: gramian_partial_kernel<1><<<grid, 256, 0, stream()>>>(Y, n_rows, f, rows_per_chunk, ws); break;
-      case 2: gramian_partial_kernel<2><<<grid, 256, 0, stream()>>>(Y, n_rows, f, rows_per_chunk, ws); break;
-      case 3: gramian_partial_kernel<3><<<grid, 256, 0, stream()>>>(Y, n_rows, f, rows_per_chunk, ws); break;
-      case 4: gramian_partial_kernel<4><<<grid, 256, 0, stream()>>>(Y, n_rows, f, rows_per_chunk, ws); break;
-      case 5: gramian_partial_kernel<5><<<grid, 256, 0, stream()>>>(Y, n_rows, f, rows_per_chunk, ws); break;
-      case 6: gramian_partial_kernel<6><<<grid, 256, 0, stream()>>>(Y, n_rows, f, rows_per_chunk, ws); break;
-      case 7: gramian_partial_kernel<7><<<grid, 256, 0, stream()>>>(Y, n_rows, f, rows_per_chunk, ws); break;
-      default: gramian_partial_kernel<8><<<grid, 256, 0, stream()>>>(Y, n_rows, f, rows_per_chunk, ws); break;
+      case 1: gramian_partial_kernel<1, T><<<grid, 256, 0, stream()>>>(Y, n_rows, f, rows_per_chunk, ws); break;
+      case 2: gramian_partial_kernel<2, T><<<grid, 256, 0, stream()>>>(Y, n_rows, f, rows_per_chunk, ws); break;
+      case 3: gramian_partial_kernel<3, T><<<grid, 256, 0, stream()>>>(Y, n_rows, f, rows_per_chunk, ws); break;
+      case 4: gramian_partial_kernel<4, T><<<grid, 256, 0, stream()>>>(Y, n_rows, f, rows_per_chunk, ws); break;
+      case 5: gramian_partial_kernel<5, T><<<grid, 256, 0, stream()>>>(Y, n_rows, f, rows_per_chunk, ws); break;
+      case 6: gramian_partial_kernel<6, T><<<grid, 256, 0, stream()>>>(Y, n_rows, f, rows_per_chunk, ws); break;
+      case 7: gramian_partial_kernel<7, T><<<grid, 256, 0, stream()>>>(Y, n_rows, f, rows_per_chunk, ws); break;
+      default: gramian_partial_kernel<8, T><<<grid, 256, 0, stream()>>>(Y, n_rows, f, rows_per_chunk, ws); break;
     }
     IMP_CHECK_HIP(hipGetLastError());
   }
@@ -155,6 +157,11 @@ void gramian(const float *Y, long n_rows, int f, float reg, float *out) {
     gramian_reduce_kernel<<<(f * f + 63) / 64, 64, 0, stream()>>>(wsbuf.data(), chunks, f, reg, out);
     IMP_CHECK_HIP(hipGetLastError());
   }
+}
+
+void gramian(const float *Y, long n_rows, int f, float reg, float *out) { gramian_t<float>(Y, n_rows, f, reg, out); }
+void gramian_half(const void *Y, long n_rows, int f, float reg, float *out) {
+  gramian_t<__half>(reinterpret_cast<const __half *>(Y), n_rows, f, reg, out);
 }
 
 }  // namespace imp

@@ -10,6 +10,8 @@
 namespace imp {
 
 void gramian(const float *Y, long n_rows, int f, float reg, float *out);                                    // gramian.hip
+void gramian_half(const void *Y, long n_rows, int f, float reg, float *out);                               // fp16 rows, fp32 products
+bool cg_native_half(int f);                                                                                 // als_cg.hip
 void least_squares_cg(const imp_csr *C, imp_matrix *X, const imp_matrix *YtY, const imp_matrix *Y, int cg_steps);  // als_cg.hip
 int64_t least_squares_cholesky(const imp_csr *C, imp_matrix *X, const imp_matrix *YtY, const imp_matrix *Y, double reg);
 
@@ -180,14 +182,8 @@ int imp_solver_calculate_yty(imp_solver *, const imp_matrix *Y, imp_matrix *YtY,
     if (YtY->cols != Y->cols) throw std::invalid_argument("YtY and Y should have the same number of columns");
     if (YtY->rows != YtY->cols) throw std::invalid_argument("YtY must be square");
     if (YtY->itemsize != 4) throw std::invalid_argument("YtY must be float32");
-    if (Y->itemsize == 4) {
-      gramian(Y->f32(), (long)Y->rows, (int)Y->cols, regularization, YtY->f32());
-    } else {
-      imp_matrix *tmp = nullptr;
-      if (imp_matrix_astype(Y, 4, &tmp) != IMP_OK) throw std::runtime_error(imp_last_error());
-      std::unique_ptr<imp_matrix> guard(tmp);
-      gramian(tmp->f32(), (long)Y->rows, (int)Y->cols, regularization, YtY->f32());
-    }
+    if (Y->itemsize == 4) gramian(Y->f32(), (long)Y->rows, (int)Y->cols, regularization, YtY->f32());
+    else gramian_half(Y->data, (long)Y->rows, (int)Y->cols, regularization, YtY->f32());  // converted in registers
     sync();
   });
 }
@@ -216,12 +212,17 @@ int imp_solver_least_squares(imp_solver *, const imp_csr *cui, imp_matrix *X, co
   return guarded([&] {
     check_solver_args(cui, X, YtY, Y);
     if (cg_steps < 0) throw std::invalid_argument("cg_steps must be >= 0");
-    run_with_f32(cui, X, Y, [&](imp_matrix *x, const imp_matrix *y) {
+    auto body = [&](imp_matrix *x, const imp_matrix *y) {
       for_each_part(cui, x, [&](const imp_csr *part, const imp_matrix *xp) {
         least_squares_cg(part, const_cast<imp_matrix *>(xp), YtY, y, cg_steps);
       });
       sync();
-    });
+    };
+    // fp16 factor storage: the f = 64 / 128 kernels load and store it directly (half the gather bytes, fp32 arithmetic, as
+    // als.cu:41,55,109); other factor counts go through an fp32 copy.  IMP_FP16_CONVERT=1 forces the copy (A/B, parity)
+    static const bool force_convert = getenv("IMP_FP16_CONVERT") != nullptr;
+    if (X->itemsize == 2 && cg_native_half((int)X->cols) && !force_convert) body(X, Y);
+    else run_with_f32(cui, X, Y, body);
   });
 }
 

@@ -177,8 +177,7 @@ class AlternatingLeastSquares(MatrixFactorizationBase):
         rows, factors = self.user_factors.shape
         if max(userids) >= rows:
             self.user_factors.resize(max(userids) + 1, factors)
-        self.user_factors.assign_rows(userids, _as_f32(new_rows)) if self.dtype == np.float32 else \
-            self._assign_half(self.user_factors, userids, new_rows)
+        self.user_factors.assign_rows(userids, new_rows)  # same dtype on both sides (fp16 models: scattered on the device)
         self._user_norms = self._user_norms_host = None
         self._XtX = self._XtX0 = None
 
@@ -189,17 +188,9 @@ class AlternatingLeastSquares(MatrixFactorizationBase):
         rows, factors = self.item_factors.shape
         if max(itemids) >= rows:
             self.item_factors.resize(max(itemids) + 1, factors)
-        self.item_factors.assign_rows(itemids, _as_f32(new_rows)) if self.dtype == np.float32 else \
-            self._assign_half(self.item_factors, itemids, new_rows)
+        self.item_factors.assign_rows(itemids, new_rows)
         self._item_norms = self._item_norms_host = None
         self._YtY = self._YtY0 = None
-
-    @staticmethod
-    def _assign_half(target, ids, new_rows):
-        # assign_rows is fp32-only at the boundary (matrix.cu:133-134): round-trip through the host
-        host = target.to_numpy()
-        host[np.asarray(ids)] = new_rows.to_numpy()
-        target.copy_from_numpy(host)
 
     # ---- cached gramians ------------------------------------------------------------------------------
     @property

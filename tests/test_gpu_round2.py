@@ -298,3 +298,35 @@ def test_topk_emit_path_and_its_fallbacks(gpu, oracle):
     assert (ids[plain] == want_ids[plain]).mean() > 0.97     # duplicated items tie: order inside a tie group may differ
     for r in plain:
         assert sorted(d[r], reverse=True) == list(d[r])
+
+
+@pytest.mark.parametrize("f", [64, 128])
+def test_native_fp16_factor_storage(gpu, oracle, f):
+    """fp16 factor storage is read and written by the f = 64 / 128 kernels themselves (half2 / 8-byte loads converted in
+    registers, fp32 arithmetic and CG state, as implicit/gpu/als.cu:41,55,109): equal, bit for bit, to solving an fp32 copy
+    of the fp16 matrices and rounding the result (the IMP_FP16_CONVERT=1 path), and within 1e-3 of the oracle run on the
+    fp16-rounded inputs (the result is stored in fp16)."""
+    C = synthetic_csr(4000, 1500, 200_000, seed=2, neg_frac=0.05, empty_frac=0.01)   # item side has rows > 512 nnz
+    rng = np.random.default_rng(4)
+    for M in (C, C.T.tocsr()):
+        X16 = (rng.random((M.shape[0], f), dtype=np.float32) * 0.2 - 0.1).astype(np.float16)
+        Y16 = (rng.random((M.shape[1], f), dtype=np.float32) * 0.2 - 0.1).astype(np.float16)
+        solver = gpu.LeastSquaresSolver()
+        Xd, Yd, gram = gpu.Matrix(X16), gpu.Matrix(Y16), gpu.Matrix.zeros(f, f)
+        assert Xd.itemsize == 2
+        solver.calculate_yty(Yd, gram, 0.05)
+        gram32 = gpu.Matrix.zeros(f, f)
+        solver.calculate_yty(gpu.Matrix(Y16.astype(np.float32)), gram32, 0.05)
+        np.testing.assert_array_equal(gram.to_numpy(), gram32.to_numpy())   # the products are fp32 either way
+        solver.least_squares(gpu.CSRMatrix(M), Xd, gram, Yd, 3)
+        got = Xd.to_numpy()
+        assert got.dtype == np.float16
+        # the same solve on an fp32 copy, rounded at the end
+        X32, Y32 = gpu.Matrix(X16.astype(np.float32)), gpu.Matrix(Y16.astype(np.float32))
+        solver.least_squares(gpu.CSRMatrix(M), X32, gram, Y32, 3)
+        np.testing.assert_array_equal(got, X32.to_numpy().astype(np.float16))
+        want = X16.astype(np.float32)
+        oracle.least_squares_cg(M, want, Y16.astype(np.float32), 0.05, cg_steps=3, YtY=gram.to_numpy())
+        assert rel(got.astype(np.float32), want) < 1e-3
+        empty = np.diff(M.indptr) == 0
+        assert not got[empty].any()
