@@ -696,14 +696,62 @@ __global__ __launch_bounds__(BLOCK) void select_candidates_kernel(const uint64_t
       __syncthreads();
     }
   }
-  // exact tie at the k-th score -> the heap rule needs the full row
-  const bool tie = (int)n_c > k && (uint32_t)(cand[k - 1] >> 32) == (uint32_t)(cand[k] >> 32);
-  if (tid == 0) fallback[q] = tie ? 1 : 0;
-  if (tie) return;
-  for (int i = tid; i < k; i += BLOCK) {
-    uint64_t key = cand[i];
-    out_ids[(size_t)q * out_stride + i] = (int32_t)(uint32_t)key;
-    out_dist[(size_t)q * out_stride + i] = unordered((uint32_t)(key >> 32));
+  const uint32_t t32 = (uint32_t)(cand[k - 1] >> 32);
+  const bool tie = (int)n_c > k && t32 == (uint32_t)(cand[k] >> 32);
+  if (!tie) {
+    if (tid == 0) fallback[q] = 0;
+    for (int i = tid; i < k; i += BLOCK) {
+      uint64_t key = cand[i];
+      out_ids[(size_t)q * out_stride + i] = (int32_t)(uint32_t)key;
+      out_dist[(size_t)q * out_stride + i] = unordered((uint32_t)(key >> 32));
+    }
+    return;
+  }
+  // Exact tie at the k-th score t.  The reference's heap (implicit/cpu/select.h:12-40) keeps, of the entries tied at t,
+  // those that arrived before the heap was full of entries >= t (saturation column s = column of the k-th entry >= t in
+  // column order) minus the e lowest columns, e = #{column > s : score > t} (closed form derived in select_kernel).  Every
+  // entry >= t is in the candidate list (t >= tau), so the rule can be evaluated right here: the list is sorted by
+  // (score desc, column desc), i.e. [0, g) are the entries > t and [g, g + m) the ties, highest column first.
+  __shared__ unsigned int sh_g, sh_m, sh_e, sh_above;
+  __shared__ int sh_s;
+  if (tid == 0) sh_g = sh_m = sh_e = sh_above = 0;
+  __syncthreads();
+  for (int i = tid; i < (int)n_c; i += BLOCK) {
+    const uint32_t key32 = (uint32_t)(cand[i] >> 32);
+    if (key32 > t32) atomicAdd(&sh_g, 1u);
+    else if (key32 == t32) atomicAdd(&sh_m, 1u);
+  }
+  __syncthreads();
+  const int g = (int)sh_g, m = (int)sh_m, ng = g + m;
+  if (ng > 1024) {  // thousands of tied entries: the quadratic rank below is not worth it, the materialising path takes the row
+    if (tid == 0) fallback[q] = 1;
+    return;
+  }
+  for (int i = tid; i < ng; i += BLOCK) {  // rank in ascending column order; rank k-1 is the saturation column
+    const uint32_t col = (uint32_t)cand[i];
+    int rank = 0;
+    for (int j = 0; j < ng; ++j) rank += (uint32_t)cand[j] < col;
+    if (rank == k - 1) sh_s = (int)col;
+  }
+  __syncthreads();
+  const uint32_t s_col = (uint32_t)sh_s;
+  for (int i = tid; i < ng; i += BLOCK) {
+    const uint32_t col = (uint32_t)cand[i];
+    if (i < g && col > s_col) atomicAdd(&sh_e, 1u);      // later arrivals above t: each evicts the lowest tied column
+    if (i >= g && col > s_col) atomicAdd(&sh_above, 1u);  // ties that arrived after saturation never entered
+  }
+  __syncthreads();
+  const int i0 = g + (int)sh_above, i1 = g + m - (int)sh_e;  // surviving ties: [i0, i1) -- columns <= s minus the e lowest
+  if (tid == 0) fallback[q] = (g + (i1 - i0) == k) ? 0 : 1;   // always k by construction; anything else -> the exact path
+  for (int i = tid; i < ng; i += BLOCK) {
+    int slot = -1;
+    if (i < g) slot = i;
+    else if (i >= i0 && i < i1) slot = g + (i - i0);
+    if (slot >= 0 && slot < k) {
+      const uint64_t key = cand[i];
+      out_ids[(size_t)q * out_stride + slot] = (int32_t)(uint32_t)key;
+      out_dist[(size_t)q * out_stride + slot] = unordered((uint32_t)(key >> 32));
+    }
   }
 }
 
@@ -935,6 +983,17 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
         fb_list.clear();
         for (size_t i = 0; i < rows; ++i)
           if (flags[i]) fb_list.push_back((int32_t)i);
+        static const bool debug = getenv("IMP_TOPK_DEBUG") != nullptr;
+        if (debug && !fb_list.empty()) {
+          std::vector<unsigned int> hc(rows);
+          std::vector<uint32_t> ht(rows);
+          IMP_CHECK_HIP(hipMemcpy(hc.data(), cnt, rows * 4, hipMemcpyDeviceToHost));
+          IMP_CHECK_HIP(hipMemcpy(ht.data(), tau, rows * 4, hipMemcpyDeviceToHost));
+          fprintf(stderr, "[topk-debug] batch at %zu: %zu fallback rows:", start, fb_list.size());
+          for (size_t i = 0; i < std::min<size_t>(fb_list.size(), 8); ++i)
+            fprintf(stderr, " (row %d count %u tau-key %08x)", fb_list[i], hc[fb_list[i]], ht[fb_list[i]]);
+          fprintf(stderr, "\n");
+        }
         if (!fb_list.empty()) {  // overflow / short list / exact tie at the k-th score: the materialising path, FB rows at a time
           IMP_PROF("topk_fallback");
           int32_t *d_rows = imp_knn::ensure(knn->fb_rows, fb_list.size());

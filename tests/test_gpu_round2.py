@@ -281,17 +281,23 @@ def test_topk_emit_path_and_its_fallbacks(gpu, oracle):
     queries = (rng.standard_normal((70, f)) * 0.1).astype(np.float32)
     queries[5] = 0.0                               # all scores 0: every item ties
     queries[6] = items[3] * 4                      # the duplicated item is the best: > 5000 candidates tie at the top
+    # small tie groups scattered over the columns: the tie at the k-th score is resolved INSIDE the candidate list with the
+    # heap's arrival-order rule (no fallback): 25 copies of one vector, some of them filtered for query 8
+    group = np.sort(rng.choice(np.setdiff1d(np.arange(ni), np.arange(0, ni, 7)), 25, replace=False))
+    items[group] = items[group[0]]
+    queries[7] = items[group[0]] * 3
+    queries[8] = items[group[0]] * 3 + items[11] * 0.5
     # per-query filter: query 0 filters the whole threshold subset (every 32nd 128-item block), query 1 a random set
     sub = np.concatenate([np.arange(b * 128, min(ni, b * 128 + 128)) for b in range(0, (ni + 127) // 128, 32)])
-    rows = np.concatenate([np.zeros(len(sub), dtype=np.int64), np.ones(500, dtype=np.int64)])
-    cols = np.concatenate([sub, rng.choice(ni, 500, replace=False)])
+    rows = np.concatenate([np.zeros(len(sub), dtype=np.int64), np.ones(500, dtype=np.int64), np.full(6, 8, dtype=np.int64)])
+    cols = np.concatenate([sub, rng.choice(ni, 500, replace=False), group[::4][:6]])
     liked = sp.csr_matrix((np.ones(len(rows), dtype=np.float32), (rows, cols)), shape=(70, ni))
     banned = rng.choice(ni, 300, replace=False).astype(np.int32)
     ids, d = gpu.KnnQuery().topk(gpu.Matrix(items), gpu.Matrix(queries), k, query_filter=gpu.COOMatrix(liked.tocoo()),
                                  item_filter=gpu.IntVector(banned))
     want_ids, want_d = oracle.topk(items, queries, k, filter_query_items=liked, filter_items=banned)
     np.testing.assert_allclose(d, want_d, rtol=2e-5, atol=1e-7)
-    exact_rows = [5, 6]                            # pure tie rows: ids must follow select.h bit for bit
+    exact_rows = [5, 6, 7, 8]                      # tie rows: ids must follow select.h bit for bit
     np.testing.assert_array_equal(ids[exact_rows], want_ids[exact_rows])
     assert not (set(ids[0]) & set(sub.tolist())) and not (set(ids.ravel().tolist()) & set(banned.tolist()))
     plain = [r for r in range(70) if r not in exact_rows]
