@@ -31,6 +31,7 @@
 namespace imp {
 
 template <typename T> void least_squares_cg_q(const imp_csr *C, T *X, const T *Y, const float *A0, int f, int cg_steps);  // als_cg_q.hip
+template <typename T> void least_squares_cg_cluster(const imp_csr *C, T *X, const T *Y, const float *A0, int f, int cg_steps);  // als_cg_cluster.hip
 
 // ---- generic per-nnz pass (any f): 4 gathers in flight, one DPP all-reduce per dot -------------------
 template <int VPL, bool VEC, bool FIRST>
@@ -426,8 +427,8 @@ static void launch_fused(const imp_csr *C, int first, int count, float *X, const
 }
 
 template <int VPL, bool VEC, bool A_LDS, typename T>
-static void launch_long(const imp_csr *C, T *X, const T *Y, const float *A0, int f, int cg_steps) {
-  const int n_long = C->n_long, n_seg = C->n_seg;
+static void launch_long(const imp_csr *C, const LongPlan &lp, T *X, const T *Y, const float *A0, int f, int cg_steps) {
+  const int n_long = lp.n_long, n_seg = lp.n_seg;
   if (n_long <= 0) return;
   constexpr int BLOCK = 512;
   constexpr int LD = 64 * VPL;
@@ -440,7 +441,7 @@ static void launch_long(const imp_csr *C, T *X, const T *Y, const float *A0, int
   float *pvec = rvec + (size_t)n_long * LD;
   float *scal = pvec + (size_t)n_long * LD;
   float *xvec = kHalf ? scal + 2 * (size_t)n_long : nullptr;
-  LongPlanDev plan = C->long_plan_dev();
+  LongPlanDev plan = lp.dev(C->order.data());
 
   size_t lds = (A_LDS ? (size_t)f * LD : 0) * sizeof(float);
   auto comb0 = cg_long_combine_kernel<VPL, VEC, BLOCK, A_LDS, 0, T>;
@@ -489,10 +490,15 @@ template <int VPL, bool VEC, bool A_LDS, typename T>
 static void launch_all(const imp_csr *C, T *X, const T *Y, const float *A0, int f, int cg_steps) {
   // schedule classes (imp_csr): 0 long (segment-split), 1..4 mid, 5..6 short, 7 empty
   const int32_t *b = C->bin_start;
-  launch_long<VPL, VEC, A_LDS, T>(C, X, Y, A0, f, cg_steps);
   if constexpr (VEC && A_LDS && (VPL == 1 || VPL == 2)) {
+    // f = 64 / 128: rows of 513 .. kClusterRow nonzeros are resident across a cluster of workgroups (als_cg_cluster.hip);
+    // only the rows beyond that are streamed.  IMP_NO_CLUSTER=1: every long row streamed (A/B, parity)
+    static const bool no_cluster = getenv("IMP_NO_CLUSTER") != nullptr;
+    launch_long<VPL, VEC, A_LDS, T>(C, no_cluster ? C->plan_all : C->plan_xl, X, Y, A0, f, cg_steps);
+    if (!no_cluster) least_squares_cg_cluster<T>(C, X, Y, A0, f, cg_steps);
     least_squares_cg_q<T>(C, X, Y, A0, f, cg_steps);  // quarter-layout register tiles, wave teams (als_cg_q.hip)
   } else if constexpr (std::is_same<T, float>::value) {
+    launch_long<VPL, VEC, A_LDS, T>(C, C->plan_all, X, Y, A0, f, cg_steps);
     bool resident_ok = false;
     if constexpr (VEC) resident_ok = tile_size<VPL>() >= imp_csr::kShortRow;
     if constexpr (VEC) {

@@ -1,0 +1,293 @@
+// K1c: CG for rows of 513 .. 4096 nonzeros with the whole row RESIDENT in the registers of a cluster of workgroups.
+//
+// Arithmetic contract: the oracle's CG (implicit/cpu/_als.pyx:152-248), as in als_cg_q.hip.  A row of n nonzeros does
+// not fit the register file of one compute unit beyond 512 entries at f = 128 (a CU has 512 KB of vector registers, an
+// entry is 512 bytes, and the CG state needs room too), which is why round 1 streamed such rows 1 + cg_steps times.  Here
+// a row is dealt to a CLUSTER of CL = 4 / 8 / 16 workgroups of 8 wavefronts (256 entries per workgroup, two workgroups
+// per CU), every wavefront keeps its 32-entry tile for all passes as in the team kernels, and per pass the cluster
+// exchanges ONE f-vector per workgroup through L2:
+//
+//   wave partial --LDS--> workgroup partial --global, tagged--> all CL workgroup partials --LDS--> every wave sums them
+//
+// in a fixed order, so all CL workgroups hold bit-identical CG scalars and take the same early-exit branches without
+// any further agreement.  The exchange needs no flag and no fence: a partial travels as 8-byte {value, sequence number}
+// granules written and read with relaxed agent-scope atomics (sc1: served by L2 / the fabric, never by a CU's L1); a
+// reader polls the granules themselves until all carry the current sequence number.  The slots are double-buffered (a
+// workgroup can run at most one exchange ahead of the slowest member) and zeroed by the host before every launch, so a
+// sequence number never repeats within a slot's lifetime.
+//
+// Placement: workgroup b runs on XCD b % 8 (observed; a speed matter only), so the CL members of a cluster are the
+// workgroups x + 8 (CL q + m) -- one XCD, one L2.  Residency: the grid never exceeds the number of workgroups the chip
+// holds at once (2 per CU), blocks are dispatched in index order, and a cluster's members are neighbours in that order, so
+// a complete cluster is always resident; every poll is bounded all the same (a timed-out exchange sets a host-visible
+// fault word and the call raises).
+#include <type_traits>
+
+#include "als_qtile.h"
+#include "common.h"
+
+namespace imp {
+
+namespace {
+constexpr int kClusterWaves = 8;       // wavefronts per workgroup
+constexpr int kSpinLimit = 1 << 19;    // polls of one exchange before giving up (~1 s)
+}  // namespace
+
+template <int F, int CL, typename ST>
+__global__ __launch_bounds__(64 * kClusterWaves, 4) void als_cg_cluster_kernel(
+    const int32_t *__restrict__ order, int first, int count, const int32_t *__restrict__ indptr,
+    const int32_t *__restrict__ indices, const float *__restrict__ data, ST *__restrict__ X, const ST *__restrict__ Y,
+    const float *__restrict__ A0, int cg_steps, unsigned long long *xchg, unsigned *fault, int allow_plain) {
+  constexpr int FC = F / 64, FE = F / 16, T = 32, WAVES = kClusterWaves, W = WAVES * CL;
+  constexpr int WD = W < F / 4 ? W : F / 4;  // wavefronts of the cluster that share the dense product: 4 NJ gramian rows each
+  constexpr int NJ = F / WD / 4;
+  constexpr int PER = (CL + WAVES - 1) / WAVES;  // exchange slots polled per wavefront
+  static_assert(F % (4 * WD) == 0 && CL >= 2, "cluster shape");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *A0s = smem;                     // [F][F]  (only in the workgroups that own dense rows)
+  float *scratch = A0s + (size_t)F * F;  // [WAVES][F]  wave partials of the combine; between combines: wave-private operand copy
+  float *xb = scratch + (size_t)WAVES * F;  // [CL][F]  the cluster's workgroup partials after the exchange
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+  const int m = jx % CL;                          // member index inside the cluster
+  const int ncl = ((int)(gridDim.x >> 3) / CL) * 8;  // clusters in the grid
+  const int cid = (jx / CL) * 8 + xcd;
+  const int g = m * WAVES + wave;  // wavefront index inside the cluster
+  const bool dense = g < WD;       // wave-uniform
+  const int j_begin = (F / WD) * g;
+  if (m * WAVES < WD)
+    for (int e = threadIdx.x; e < F * F; e += 64 * WAVES) A0s[e] = A0[e];
+  __syncthreads();
+  float *myvec = scratch + (size_t)wave * F;
+  unsigned long long *slots = xchg + (size_t)cid * 2 * CL * 64 * FC;
+
+  // ---- the exchange -------------------------------------------------------------------------------------------------
+  unsigned seq = 0;
+  int parity = 0;
+  bool faulted = false;
+  bool same_xcd = false;  // until verified below
+  auto combine = [&](float (&acc)[FC]) {
+    // addresses of the exchange are re-derived per call: hoisted out of the row loop they would cost registers the
+    // kernel does not have (the tile fills the file) and come back as scratch reloads
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+#pragma unroll
+    for (int c = 0; c < FC; ++c) scratch[wave * F + QL<F>::cfactor(ln, c)] = acc[c];
+    __syncthreads();  // B1: wave partials visible; every wave has finished reading xb of the previous exchange
+    ++seq;
+    unsigned long long *slot = slots + (size_t)parity * CL * 64 * FC;
+    parity ^= 1;
+    if (wave == 0) {  // workgroup partial (fixed order) -> this member's slot
+#pragma unroll
+      for (int c = 0; c < FC; ++c) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) s += scratch[w * F + QL<F>::cfactor(ln, c)];
+        const unsigned long long granule = ((unsigned long long)seq << 32) | (unsigned long long)__float_as_uint(s);
+        // members on one XCD share its L2: a plain store lands there and the readers' sc1 loads (which bypass only
+        // their L1) hit it; an sc1 store writes through to the fabric and drops the line, which the readers then
+        // fetch at the cross-XCD latency -- required when the members sit on different XCDs, whose L2s are not coherent
+        if (same_xcd) __hip_atomic_store(slot + ((m * 64 + ln) * FC + c), granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_store(slot + ((m * 64 + ln) * FC + c), granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (wave < CL) {  // wave w collects members w, w + 8, ...: all of them in flight together
+      unsigned long long granule[PER][FC];
+      int spins = 0;
+      while (true) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+#pragma unroll
+          for (int c = 0; c < FC; ++c) {
+            granule[k][c] = __hip_atomic_load(slot + (((wave + k * WAVES) * 64 + ln) * FC + c), __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT);
+            ok = ok && (unsigned)(granule[k][c] >> 32) == seq;
+          }
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+        if (faulted || ++spins > kSpinLimit) {  // never expected: give up instead of hanging the device
+          if (!faulted && lane == 0) __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          faulted = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+#pragma unroll
+      for (int k = 0; k < PER; ++k)
+#pragma unroll
+        for (int c = 0; c < FC; ++c) xb[(wave + k * WAVES) * F + QL<F>::cfactor(ln, c)] = __uint_as_float((unsigned)granule[k][c]);
+    }
+    __syncthreads();  // B2: all CL partials in LDS; wave 0 has finished reading the wave partials
+#pragma unroll
+    for (int c = 0; c < FC; ++c) {
+      float s = 0.f;
+#pragma unroll
+      for (int mm = 0; mm < CL; ++mm) s += xb[mm * F + QL<F>::cfactor(ln, c)];
+      acc[c] = s;
+    }
+  };
+
+  // one pass: ae (expanded, partial over this wave's work) = sign * [A0 rows of this wave] . v + [tile entries] weights
+  auto pass = [&](auto first_tag, const QTile<F> &tile, const float (&v)[FC], float (&acc)[FC], bool work) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    float ve[FE], ae[FE];
+#pragma unroll
+    for (int e = 0; e < FE; ++e) ae[e] = 0.f;
+    if (work) {  // wave-uniform, identical across the cluster
+      if (dense) {
+#pragma unroll
+        for (int c = 0; c < FC; ++c) myvec[QL<F>::cfactor(lane, c)] = v[c];  // wave-private: no barrier needed
+        gram_matvec_q<F, NJ>(A0s, F, myvec, lane, j_begin, ae);
+        if constexpr (FIRST) {
+#pragma unroll
+          for (int e = 0; e < FE; ++e) ae[e] = -ae[e];  // r = b - A x: the dense part enters with a minus sign
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      expand_vector<F>(v, ve);
+      qtile_apply<F, FIRST>(tile, ve, ae);
+    }
+    reduce_expanded<F>(ae, acc);
+  };
+
+  // Placement check (once per workgroup): the members exchange their XCC ids with write-through stores; only if all CL
+  // ids are equal -- sum and sum of squares of the ids, exact in fp32 -- do later exchanges use plain stores.  Every member
+  // sees the same CL values, hence takes the same decision.
+  if (allow_plain) {
+    const float xcc = (float)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID[3:0]
+    float s1[FC], s2[FC];
+#pragma unroll
+    for (int c = 0; c < FC; ++c) s1[c] = wave == 0 ? xcc : 0.f, s2[c] = wave == 0 ? xcc * xcc : 0.f;
+    combine(s1);
+    combine(s2);
+    same_xcd = (float)CL * s2[0] == s1[0] * s1[0];
+  }
+
+  // this cluster's rows: i = cid + k ncl; the loop bounds depend on cid alone, so all members run the same exchanges
+  auto row_id = [&](int i) { return order[first + min(i, count - 1)]; };  // uniform address: scalar load
+  int u1 = row_id(cid), u2 = row_id(cid + ncl), u3 = row_id(cid + 2 * ncl);
+  int rb1 = indptr[u1], re1 = indptr[u1 + 1], rb2 = indptr[u2], re2 = indptr[u2 + 1];
+  int col_next;
+  float c_next;
+  // even shares of a row for the W wavefronts of the cluster, rounded up to whole 4-entry tile steps (als_cg_q.hip)
+  auto slice = [&](int rb, int re, int &k0, int &cnt) {
+    const int chunk = min(T, (((re - rb) + W - 1) / W + 3) & ~3);
+    k0 = min(rb + chunk * g, re);
+    cnt = min(chunk, re - k0);
+  };
+  int k0_next, cnt_next;
+  slice(rb1, re1, k0_next, cnt_next);
+  fetch_entries(indices, data, lane, k0_next, max(k0_next + cnt_next, rb1 + 1), col_next, c_next);
+  for (int i = cid; i < count; i += ncl) {
+    const int u = u1;
+    u1 = u2, rb1 = rb2, re1 = re2;                    // row i + ncl: complete
+    u2 = u3, rb2 = indptr[u2], re2 = indptr[u2 + 1];  // row i + 2 ncl: row id known -> its range
+    u3 = row_id(i + 3 * ncl);                         // row i + 3 ncl: row id
+    ST *xrow = X + (size_t)u * F;
+    float x[FC], r[FC], p[FC], Ap[FC];
+    const int cnt = cnt_next;  // this wave's slice of the row (may be empty)
+    QTile<F> tile;
+    load_compact<F>(xrow, lane, x);
+    load_qtile_staged<F>(tile, col_next, c_next, Y, lane, cnt);
+    slice(rb1, re1, k0_next, cnt_next);
+    fetch_entries(indices, data, lane, k0_next, max(k0_next + cnt_next, rb1 + 1), col_next, c_next);  // entries of row i + ncl
+
+    // r = -(A0 x) + sum_k (c+ - (|c|-1) y.x) y        (_als.pyx:187-201)
+    pass(std::true_type{}, tile, x, r, true);
+    combine(r);
+#pragma unroll
+    for (int c = 0; c < FC; ++c) p[c] = r[c];
+    float rsold = dot_compact<F>(r, r);
+    bool active = rsold >= 1e-20f;  // else: x untouched (_als.pyx:206)
+    const bool store = active && g == 0;
+
+    for (int it = 0; it < cg_steps; ++it) {
+      pass(std::false_type{}, tile, p, Ap, active);
+      combine(Ap);
+      if (active) {
+        float alpha = rsold / dot_compact<F>(p, Ap);
+#pragma unroll
+        for (int c = 0; c < FC; ++c) {
+          x[c] = fmaf(alpha, p[c], x[c]);
+          r[c] = fmaf(-alpha, Ap[c], r[c]);
+        }
+        float rsnew = dot_compact<F>(r, r);
+        if (rsnew < 1e-20f) {
+          active = false;  // the oracle breaks here (_als.pyx:235); the whole cluster takes the same branch
+        } else {
+          float beta = rsnew / rsold;
+#pragma unroll
+          for (int c = 0; c < FC; ++c) p[c] = fmaf(beta, p[c], r[c]);
+          rsold = rsnew;
+        }
+      }
+    }
+    if (store) store_compact<F>(xrow, lane, x);
+  }
+}
+
+template <int F, int CL, typename T>
+static void launch_cluster(const imp_csr *C, int first, int count, T *X, const T *Y, const float *A0, int cg_steps,
+                           unsigned long long *xchg, const char *name) {
+  if (count <= 0) return;
+  constexpr int FC = F / 64, BLOCK = 64 * kClusterWaves;
+  const size_t lds = ((size_t)F * F + (size_t)kClusterWaves * F + (size_t)CL * F) * sizeof(float);
+  auto kern = als_cg_cluster_kernel<F, CL, T>;
+  IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  // co-resident workgroups: what the occupancy query admits per CU (2 by design), never more than 2; the cluster
+  // protocol only needs ONE complete cluster resident, which any grid in dispatch order provides
+  int per_cu = 0;
+  IMP_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, BLOCK, lds));
+  per_cu = std::max(1, std::min(per_cu, 2));
+  const int max_clusters_per_xcd = std::max(1, ctx().num_cus * per_cu / 8 / CL);
+  const int clusters_per_xcd = std::min(max_clusters_per_xcd, (count + 7) / 8);
+  const int grid = 8 * CL * clusters_per_xcd;
+  (void)FC;
+  static const bool allow_plain = getenv("IMP_CLUSTER_SC1") == nullptr;  // IMP_CLUSTER_SC1=1: write-through stores always (A/B)
+  IMP_PROF(name);
+  kern<<<grid, BLOCK, lds, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(), C->data.data(), X, Y,
+                                      A0, cg_steps, xchg, ctx().cluster_fault, allow_plain ? 1 : 0);
+  IMP_CHECK_HIP(hipGetLastError());
+}
+
+template <int F, typename T> static void run_clusters(const imp_csr *C, T *X, const T *Y, const float *A0, int cg_steps) {
+  const int32_t *cut = C->cluster_cut;  // rows longer than 4096 / 2048 / 1024 / 512: classes (2048,4096] (1024,2048] (512,1024]
+  if (cut[3] - cut[0] <= 0) return;
+  auto &c = ctx();
+  // exchange slots: [class][cluster][2][CL][64 FC] granules; clusters * CL <= workgroups in flight <= 2 per CU
+  constexpr size_t FC = F / 64;
+  const size_t per_class = (size_t)c.num_cus * 2 * 2 * 64 * FC;
+  if (c.cluster_xchg.size < 3 * per_class) c.cluster_xchg.alloc(3 * per_class);
+  if (!c.cluster_fault) {
+    IMP_CHECK_HIP(hipHostMalloc(reinterpret_cast<void **>(&c.cluster_fault), sizeof(unsigned), hipHostMallocMapped));
+    *c.cluster_fault = 0u;
+  }
+  unsigned long long *xchg = c.cluster_xchg.data();
+  {
+    IMP_PROF("als_cg_cluster_reset");
+    IMP_CHECK_HIP(hipMemsetAsync(xchg, 0, 3 * per_class * sizeof(unsigned long long), stream()));
+  }
+  launch_cluster<F, 16, T>(C, cut[0], cut[1] - cut[0], X, Y, A0, cg_steps, xchg, "als_cg_cluster16_rows");
+  launch_cluster<F, 8, T>(C, cut[1], cut[2] - cut[1], X, Y, A0, cg_steps, xchg + per_class, "als_cg_cluster8_rows");
+  launch_cluster<F, 4, T>(C, cut[2], cut[3] - cut[2], X, Y, A0, cg_steps, xchg + 2 * per_class, "als_cg_cluster4_rows");
+}
+
+// true if a cluster kernel of an earlier launch on this device gave up on an exchange (checked by the solver entry point
+// after its stream synchronisation); clears the word
+bool cluster_fault_pending() {
+  auto &c = ctx();
+  if (!c.cluster_fault || *c.cluster_fault == 0u) return false;
+  *c.cluster_fault = 0u;
+  return true;
+}
+
+template <typename T> void least_squares_cg_cluster(const imp_csr *C, T *X, const T *Y, const float *A0, int f, int cg_steps) {
+  if (f == 128) run_clusters<128, T>(C, X, Y, A0, cg_steps);
+  else if (f == 64) run_clusters<64, T>(C, X, Y, A0, cg_steps);
+  else throw std::invalid_argument("least_squares_cg_cluster: f must be 64 or 128");
+}
+template void least_squares_cg_cluster<float>(const imp_csr *, float *, const float *, const float *, int, int);
+template void least_squares_cg_cluster<__half>(const imp_csr *, __half *, const __half *, const float *, int, int);
+
+}  // namespace imp

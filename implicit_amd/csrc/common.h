@@ -65,6 +65,7 @@ template <typename F> int guarded(F &&body) {
 
 inline hipStream_t stream();
 void sync();  // hipStreamSynchronize on the library stream
+bool cluster_fault_pending();  // als_cg_cluster.hip: a cluster exchange timed out since the last check (clears the flag)
 
 // ---- launch-time profiler (HIP events on the library stream) ------------------------------------
 struct ProfScope {
@@ -114,6 +115,8 @@ struct Context {
   DeviceArray<double> loss_buf;   // 4 accumulators of the loss kernel (solver.hip)
   DeviceArray<unsigned long long> chol_failed;  // smallest failing row of a Cholesky sweep (als_cholesky.hip)
   DeviceArray<float> barrier_word;              // operand of the RCCL barrier (comm.hip)
+  DeviceArray<unsigned long long> cluster_xchg;  // partial-vector exchange slots of the cluster kernels (als_cg_cluster.hip)
+  unsigned *cluster_fault = nullptr;             // host-mapped word: set by a cluster kernel whose exchange timed out
 };
 inline hipStream_t stream() { return ctx().stream; }
 
@@ -148,6 +151,19 @@ struct LongPlanDev {
   int xcd_start[9];          // seg_exec[xcd_start[x] .. xcd_start[x+1]) is swept by the workgroups with blockIdx % 8 == x
 };
 
+// Host-side owner of one long-row plan (device arrays + the per-XCD cut of the execution order).
+struct LongPlan {
+  int32_t n_long = 0, n_seg = 0;
+  imp::DeviceArray<int32_t> row_seg, seg_row, seg_begin, seg_end, seg_exec;
+  int32_t xcd_start[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int32_t stripe = 0;  // column-stripe width (0: rows cut into plain kSegment runs)
+  LongPlanDev dev(const int32_t *rows) const {
+    LongPlanDev d{n_long, n_seg, rows, row_seg.data(), seg_row.data(), seg_begin.data(), seg_end.data(), seg_exec.data(), {0}};
+    for (int x = 0; x < 9; ++x) d.xcd_start[x] = xcd_start[x];
+    return d;
+  }
+};
+
 // Rows are scheduled in length classes so that the work per wavefront is even and the longest rows
 // start first (SURVEY section 7 "load imbalance"): `order` = row ids sorted by descending nnz;
 // class b covers order[bin_start[b] .. bin_start[b+1]) and holds the rows with
@@ -172,17 +188,14 @@ struct imp_csr {
   imp::DeviceArray<int32_t> order;
   int32_t bin_start[kBins + 1] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   int32_t max_row = 0;
-  // long-row plan
-  int32_t n_long = 0, n_seg = 0;
-  imp::DeviceArray<int32_t> row_seg, seg_row, seg_begin, seg_end, seg_exec;
-  int32_t xcd_start[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  int32_t stripe = 0;  // column-stripe width of the long-row plan (0: rows cut into plain kSegment runs)
-  LongPlanDev long_plan_dev() const {
-    LongPlanDev d{n_long,           n_seg,          order.data(),    row_seg.data(), seg_row.data(),
-                  seg_begin.data(), seg_end.data(), seg_exec.data(), {0}};
-    for (int x = 0; x < 9; ++x) d.xcd_start[x] = xcd_start[x];
-    return d;
-  }
+  // long-row plans: `plan_all` covers every row of class 0 (> kLongRow nonzeros) and is what the generic kernels stream;
+  // `plan_xl` covers only the rows beyond the reach of the cluster-resident kernels (> kClusterRow nonzeros; the first
+  // cluster_cut[0] entries of `order`), which is what the f = 64 / 128 path streams.  cluster_cut[i] = number of rows
+  // longer than kClusterRow >> i (i = 0, 1, 2), cluster_cut[3] = number of long rows: the cluster classes are
+  // order[cluster_cut[i] .. cluster_cut[i + 1]).
+  static constexpr int kClusterRow = 4096;
+  LongPlan plan_all, plan_xl;
+  int32_t cluster_cut[4] = {0, 0, 0, 0};
   // A matrix with more than 2^31 - 1 nonzeros (imp_csr_create64) is held as consecutive row blocks, each a complete
   // imp_csr of its own with int32 offsets; the top-level object then only carries rows / cols / nnz and the solver
   // entry points walk the blocks (every row solve is independent of the others).

@@ -503,90 +503,101 @@ int imp_csr_create(int32_t rows, int32_t cols, int64_t nnz, const int32_t *indpt
     // enough stripes to balance) -- hence about 24 stripes, between 4096 and 12288 columns
     int32_t stripe = std::min(12288, std::max(4096, (cols / 24 + 1023) / 1024 * 1024));
     if (const char *e = getenv("IMP_STRIPE")) stripe = std::max(0, atoi(e));
-    int64_t long_nnz = 0;
-    bool sorted = true;
-    for (int32_t li = 0; li < n_long; ++li) {
-      const int32_t r = order[li];
-      long_nnz += indptr[r + 1] - indptr[r];
-      if (stripe > 0 && sorted) sorted = std::is_sorted(indices + indptr[r], indices + indptr[r + 1]);
-    }
-    const bool striped = stripe > 0 && sorted && n_long > 0 && long_nnz >= 4 * (int64_t)cols;
-    std::vector<int32_t> row_seg((size_t)n_long + 1, 0), seg_row, seg_begin, seg_end, seg_stripe;
-    for (int32_t li = 0; li < n_long; ++li) {
-      const int32_t r = order[li];
-      row_seg[li] = (int32_t)seg_row.size();
-      int32_t pos = indptr[r];
-      const int32_t row_end = indptr[r + 1];
-      while (pos < row_end) {
-        int32_t hi = row_end, st = 0;
-        if (striped) {
-          st = indices[pos] / stripe;
-          const int64_t bound = ((int64_t)st + 1) * stripe;
-          hi = (int32_t)(std::lower_bound(indices + pos, indices + row_end, bound,
-                                          [](int32_t c, int64_t b) { return (int64_t)c < b; }) -
-                         indices);
+    auto build_plan = [&](int32_t n_plan, LongPlan &lp) {
+      int64_t long_nnz = 0;
+      bool sorted = true;
+      for (int32_t li = 0; li < n_plan; ++li) {
+        const int32_t r = order[li];
+        long_nnz += indptr[r + 1] - indptr[r];
+        if (stripe > 0 && sorted) sorted = std::is_sorted(indices + indptr[r], indices + indptr[r + 1]);
+      }
+      const bool striped = stripe > 0 && sorted && n_plan > 0 && long_nnz >= 4 * (int64_t)cols;
+      std::vector<int32_t> row_seg((size_t)n_plan + 1, 0), seg_row, seg_begin, seg_end, seg_stripe;
+      for (int32_t li = 0; li < n_plan; ++li) {
+        const int32_t r = order[li];
+        row_seg[li] = (int32_t)seg_row.size();
+        int32_t pos = indptr[r];
+        const int32_t row_end = indptr[r + 1];
+        while (pos < row_end) {
+          int32_t hi = row_end, st = 0;
+          if (striped) {
+            st = indices[pos] / stripe;
+            const int64_t bound = ((int64_t)st + 1) * stripe;
+            hi = (int32_t)(std::lower_bound(indices + pos, indices + row_end, bound,
+                                            [](int32_t c, int64_t b) { return (int64_t)c < b; }) -
+                           indices);
+          }
+          for (int32_t b = pos; b < hi; b += segment) {
+            seg_row.push_back(li);
+            seg_begin.push_back(b);
+            seg_end.push_back(std::min(hi, b + segment));
+            seg_stripe.push_back(st);
+          }
+          pos = hi;
         }
-        for (int32_t b = pos; b < hi; b += segment) {
-          seg_row.push_back(li);
-          seg_begin.push_back(b);
-          seg_end.push_back(std::min(hi, b + segment));
-          seg_stripe.push_back(st);
+      }
+      row_seg[n_plan] = (int32_t)seg_row.size();
+      const int32_t n_seg = (int32_t)seg_row.size();
+      std::vector<int32_t> seg_exec((size_t)n_seg);
+      if (striped) {
+        const int32_t n_stripes = (cols + stripe - 1) / stripe;
+        std::vector<int64_t> weight((size_t)n_stripes, 0);
+        for (int32_t s = 0; s < n_seg; ++s) weight[seg_stripe[s]] += seg_end[s] - seg_begin[s] + 16;  // + per-segment overhead
+        std::vector<int32_t> by_weight((size_t)n_stripes);
+        for (int32_t i = 0; i < n_stripes; ++i) by_weight[i] = i;
+        std::stable_sort(by_weight.begin(), by_weight.end(), [&](int32_t a, int32_t b) { return weight[a] > weight[b]; });
+        int64_t load[8] = {0};
+        std::vector<int32_t> stripe_xcd((size_t)n_stripes, 0), stripe_rank((size_t)n_stripes, 0);
+        int32_t per_xcd[8] = {0};
+        for (int32_t st : by_weight) {  // heaviest first onto the least loaded XCD
+          int x = (int)(std::min_element(load, load + 8) - load);
+          load[x] += weight[st];
+          stripe_xcd[st] = x;
+          stripe_rank[st] = per_xcd[x]++;
         }
-        pos = hi;
+        std::vector<int32_t> ids((size_t)n_seg);
+        for (int32_t s = 0; s < n_seg; ++s) ids[s] = s;
+        std::stable_sort(ids.begin(), ids.end(), [&](int32_t a, int32_t b) {
+          const int32_t sa = seg_stripe[a], sb = seg_stripe[b];
+          if (stripe_xcd[sa] != stripe_xcd[sb]) return stripe_xcd[sa] < stripe_xcd[sb];
+          return stripe_rank[sa] < stripe_rank[sb];  // equal stripe: ascending segment id = ascending row
+        });
+        seg_exec = ids;
+        int32_t posx = 0;
+        for (int x = 0; x < 8; ++x) {
+          lp.xcd_start[x] = posx;
+          while (posx < n_seg && stripe_xcd[seg_stripe[seg_exec[posx]]] == x) ++posx;
+        }
+        lp.xcd_start[8] = n_seg;
+        lp.stripe = stripe;
+      } else {
+        // plain plan: runs of 4 consecutive segments dealt round-robin to the XCDs (neighbouring segments of a row,
+        // i.e. neighbouring column ranges, stay on one XCD)
+        int32_t posx = 0;
+        for (int x = 0; x < 8; ++x) {
+          lp.xcd_start[x] = posx;
+          for (int32_t s = 0; s < n_seg; ++s)
+            if ((s / 4) % 8 == x) seg_exec[posx++] = s;
+        }
+        lp.xcd_start[8] = n_seg;
       }
+      lp.n_long = n_plan;
+      lp.n_seg = n_seg;
+      lp.seg_exec.upload(seg_exec.data(), seg_exec.size());
+      lp.row_seg.upload(row_seg.data(), row_seg.size());
+      lp.seg_row.upload(seg_row.data(), seg_row.size());
+      lp.seg_begin.upload(seg_begin.data(), seg_begin.size());
+      lp.seg_end.upload(seg_end.data(), seg_end.size());
+    };
+    build_plan(n_long, m->plan_all);
+    // rows within reach of the cluster-resident kernels (als_cg_cluster.hip) leave the streamed plan of the f = 64 / 128 path
+    for (int i = 0; i < 3; ++i) {
+      int32_t longer = 0;  // rows strictly longer than kClusterRow >> i (order is sorted by descending length)
+      for (int32_t len = max_len; len > (imp_csr::kClusterRow >> i); --len) longer += count[len];
+      m->cluster_cut[i] = longer;
     }
-    row_seg[n_long] = (int32_t)seg_row.size();
-    const int32_t n_seg = (int32_t)seg_row.size();
-    std::vector<int32_t> seg_exec((size_t)n_seg);
-    if (striped) {
-      const int32_t n_stripes = (cols + stripe - 1) / stripe;
-      std::vector<int64_t> weight((size_t)n_stripes, 0);
-      for (int32_t s = 0; s < n_seg; ++s) weight[seg_stripe[s]] += seg_end[s] - seg_begin[s] + 16;  // + per-segment overhead
-      std::vector<int32_t> by_weight((size_t)n_stripes);
-      for (int32_t i = 0; i < n_stripes; ++i) by_weight[i] = i;
-      std::stable_sort(by_weight.begin(), by_weight.end(), [&](int32_t a, int32_t b) { return weight[a] > weight[b]; });
-      int64_t load[8] = {0};
-      std::vector<int32_t> stripe_xcd((size_t)n_stripes, 0), stripe_rank((size_t)n_stripes, 0);
-      int32_t per_xcd[8] = {0};
-      for (int32_t st : by_weight) {  // heaviest first onto the least loaded XCD
-        int x = (int)(std::min_element(load, load + 8) - load);
-        load[x] += weight[st];
-        stripe_xcd[st] = x;
-        stripe_rank[st] = per_xcd[x]++;
-      }
-      std::vector<int32_t> ids((size_t)n_seg);
-      for (int32_t s = 0; s < n_seg; ++s) ids[s] = s;
-      std::stable_sort(ids.begin(), ids.end(), [&](int32_t a, int32_t b) {
-        const int32_t sa = seg_stripe[a], sb = seg_stripe[b];
-        if (stripe_xcd[sa] != stripe_xcd[sb]) return stripe_xcd[sa] < stripe_xcd[sb];
-        return stripe_rank[sa] < stripe_rank[sb];  // equal stripe: ascending segment id = ascending row
-      });
-      seg_exec = ids;
-      int32_t posx = 0;
-      for (int x = 0; x < 8; ++x) {
-        m->xcd_start[x] = posx;
-        while (posx < n_seg && stripe_xcd[seg_stripe[seg_exec[posx]]] == x) ++posx;
-      }
-      m->xcd_start[8] = n_seg;
-      m->stripe = stripe;
-    } else {
-      // plain plan: runs of 4 consecutive segments dealt round-robin to the XCDs (neighbouring segments of a row,
-      // i.e. neighbouring column ranges, stay on one XCD)
-      int32_t posx = 0;
-      for (int x = 0; x < 8; ++x) {
-        m->xcd_start[x] = posx;
-        for (int32_t s = 0; s < n_seg; ++s)
-          if ((s / 4) % 8 == x) seg_exec[posx++] = s;
-      }
-      m->xcd_start[8] = n_seg;
-    }
-    m->n_long = n_long;
-    m->n_seg = n_seg;
-    m->seg_exec.upload(seg_exec.data(), seg_exec.size());
-    m->row_seg.upload(row_seg.data(), row_seg.size());
-    m->seg_row.upload(seg_row.data(), seg_row.size());
-    m->seg_begin.upload(seg_begin.data(), seg_begin.size());
-    m->seg_end.upload(seg_end.data(), seg_end.size());
+    m->cluster_cut[3] = n_long;
+    build_plan(m->cluster_cut[0], m->plan_xl);
     sync();
     *out = m.release();
   });

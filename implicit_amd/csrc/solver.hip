@@ -217,6 +217,8 @@ int imp_solver_least_squares(imp_solver *, const imp_csr *cui, imp_matrix *X, co
         least_squares_cg(part, const_cast<imp_matrix *>(xp), YtY, y, cg_steps);
       });
       sync();
+      if (cluster_fault_pending())
+        throw std::runtime_error("least_squares: a cluster exchange timed out (als_cg_cluster.hip); results are invalid");
     };
     // fp16 factor storage: the f = 64 / 128 kernels load and store it directly (half the gather bytes, fp32 arithmetic, as
     // als.cu:41,55,109); other factor counts go through an fp32 copy.  IMP_FP16_CONVERT=1 forces the copy (A/B, parity)

@@ -184,7 +184,7 @@ print("switch ok")
 
 
 @pytest.mark.parametrize("switch", ["IMP_SHORT_TEAM1=1", "IMP_SHORT_TEAM1=0", "IMP_STRIPE=0", "IMP_SEGMENT=128",
-                                    "IMP_CHOL_NO_MFMA=1", "IMP_CHOL_NO_WAVE=1", "IMP_TOPK_NO_FAST=1"])
+                                    "IMP_CHOL_NO_MFMA=1", "IMP_CHOL_NO_WAVE=1", "IMP_TOPK_NO_FAST=1", "IMP_NO_CLUSTER=1"])
 def test_ab_switch_paths_keep_parity(gpu, switch):
     """Every debug / A-B environment switch selects kernels the default run does not take (they are read once per
     process, hence the subprocess): CG both orientations at f = 64 / 128, Cholesky f = 64 and top-k against the oracle."""
@@ -336,3 +336,69 @@ def test_native_fp16_factor_storage(gpu, oracle, f):
         assert rel(got.astype(np.float32), want) < 1e-3
         empty = np.diff(M.indptr) == 0
         assert not got[empty].any()
+
+
+def _cg_fp64_row(row, x0, Y, A0, cg_steps):
+    """One row of the oracle's CG (implicit/cpu/_als.pyx:179-244) in float64; A0 = YtY + reg I."""
+    idx, c = row.indices, row.data.astype(np.float64)
+    Yu, A0, x = Y[idx].astype(np.float64), A0.astype(np.float64), x0.astype(np.float64)
+    cm1 = np.abs(c) - 1.0
+    r = -A0 @ x + Yu.T @ (np.where(c > 0, c, 0.0) - cm1 * (Yu @ x))
+    p, rsold = r.copy(), r @ r
+    if rsold < 1e-20:
+        return x
+    for _ in range(cg_steps):
+        Ap = A0 @ p + Yu.T @ (cm1 * (Yu @ p))
+        alpha = rsold / (p @ Ap)
+        x += alpha * p
+        r -= alpha * Ap
+        rsnew = r @ r
+        if rsnew < 1e-20:
+            break
+        p, rsold = r + (rsnew / rsold) * p, rsnew
+    return x
+
+
+@pytest.mark.parametrize("f", [64, 128])
+@pytest.mark.parametrize("cg_steps", [3, 0])
+def test_cluster_resident_long_rows(gpu, oracle, f, cg_steps):
+    """Rows of 513 .. 4096 nonzeros are solved resident across a cluster of 4 / 8 / 16 workgroups that exchange one f-vector
+    per workgroup and pass through L2 (als_cg_cluster.hip); longer rows stay on the streamed path.  Row lengths sit on and
+    around every class boundary; more rows than clusters in every class, so the persistent loop and the double-buffered
+    exchange slots are exercised; an already-solved row (residual 0) takes the early exit in the whole cluster.  Checked per
+    row against the oracle's CG evaluated in float64 and, as a whole, against the oracle itself."""
+    rng = np.random.default_rng(11)
+    lens = np.concatenate([np.arange(500, 530), [1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096, 4097, 5000, 9000],
+                           rng.integers(513, 1025, 150), rng.integers(1025, 2049, 90), rng.integers(2049, 4097, 70),
+                           rng.integers(1, 400, 300), [0, 0]])
+    rng.shuffle(lens)
+    cols = 12_000
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    indices = np.concatenate([np.sort(rng.choice(cols, int(n), replace=False)) for n in lens] + [[]]).astype(np.int32)
+    data = (1.0 + 4.0 * rng.random(len(indices), dtype=np.float32)).astype(np.float32)
+    data[rng.random(len(data)) < 0.03] *= -1
+    C = sp.csr_matrix((data, indices, indptr), shape=(len(lens), cols))
+    X0 = rng.random((C.shape[0], f), dtype=np.float32) * 0.2 - 0.1
+    Y0 = rng.random((cols, f), dtype=np.float32) * 0.2 - 0.1
+    solver = gpu.LeastSquaresSolver()
+    Xd, Yd, gram = gpu.Matrix(X0), gpu.Matrix(Y0), gpu.Matrix.zeros(f, f)
+    solver.calculate_yty(Yd, gram, 0.05)
+    Cd = gpu.CSRMatrix(C)
+    solver.least_squares(Cd, Xd, gram, Yd, cg_steps)
+    got = Xd.to_numpy()
+    gram_h = gram.to_numpy()
+    long_rows = np.flatnonzero(lens > 512)
+    worst = 0.0
+    for r in long_rows:
+        exact = _cg_fp64_row(C[int(r)], X0[r], Y0, gram_h, cg_steps)
+        worst = max(worst, rel(got[r], exact))
+    assert worst < 1e-4, worst
+    want = X0.copy()
+    oracle.least_squares_cg(C, want, Y0, 0.05, cg_steps=cg_steps, YtY=gram_h)
+    assert rel(got, want) < 1e-4
+    assert not got[lens == 0].any()
+    # a second sweep from the solution: deterministic (same bits on a re-run from the same start)
+    Xa, Xb = gpu.Matrix(got), gpu.Matrix(got)
+    solver.least_squares(Cd, Xa, gram, Yd, 3)
+    solver.least_squares(Cd, Xb, gram, Yd, 3)
+    np.testing.assert_array_equal(Xa.to_numpy(), Xb.to_numpy())
