@@ -33,11 +33,23 @@ constexpr int kClusterWaves = 8;       // wavefronts per workgroup
 constexpr int kSpinLimit = 1 << 19;    // polls of one exchange before giving up (~1 s)
 }  // namespace
 
-template <int F, int CL, typename ST>
+// STATS (debug, IMP_CG_STATS=1): s_memtime ticks summed over waves -- [0] row start -> tile resident  [1] passes
+//   [2] exchanges (barriers, publish, poll, sum)  [3] dots / CG update  [7] wave-rows
+template <int F, int CL, bool STATS, typename ST>
 __global__ __launch_bounds__(64 * kClusterWaves, 4) void als_cg_cluster_kernel(
     const int32_t *__restrict__ order, int first, int count, const int32_t *__restrict__ indptr,
     const int32_t *__restrict__ indices, const float *__restrict__ data, ST *__restrict__ X, const ST *__restrict__ Y,
-    const float *__restrict__ A0, int cg_steps, unsigned long long *xchg, unsigned *fault, int allow_plain) {
+    const float *__restrict__ A0, int cg_steps, unsigned long long *xchg, unsigned *fault, int allow_plain, unsigned long long *__restrict__ stats = nullptr) {
+  unsigned long long tk[4] = {0, 0, 0, 0}, t_last = 0, t_rows = 0;
+  auto tick = [&](int slot) {  // charge the time since the previous tick to `slot`
+    if constexpr (STATS) {
+      __builtin_amdgcn_sched_barrier(0);
+      unsigned long long now = __builtin_amdgcn_s_memtime();
+      if (slot >= 0) tk[slot] += now - t_last;
+      t_last = now;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   constexpr int FC = F / 64, FE = F / 16, T = 32, WAVES = kClusterWaves, W = WAVES * CL;
   constexpr int WD = W < F / 4 ? W : F / 4;  // wavefronts of the cluster that share the dense product: 4 NJ gramian rows each
   constexpr int NJ = F / WD / 4;
@@ -189,13 +201,21 @@ __global__ __launch_bounds__(64 * kClusterWaves, 4) void als_cg_cluster_kernel(
     const int cnt = cnt_next;  // this wave's slice of the row (may be empty)
     QTile<F> tile;
     load_compact<F>(xrow, lane, x);
+    tick(-1);
     load_qtile_staged<F>(tile, col_next, c_next, Y, lane, cnt);
     slice(rb1, re1, k0_next, cnt_next);
     fetch_entries(indices, data, lane, k0_next, max(k0_next + cnt_next, rb1 + 1), col_next, c_next);  // entries of row i + ncl
+    if constexpr (STATS) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      tick(0);
+      t_rows += 1;
+    }
 
     // r = -(A0 x) + sum_k (c+ - (|c|-1) y.x) y        (_als.pyx:187-201)
     pass(std::true_type{}, tile, x, r, true);
+    tick(1);
     combine(r);
+    tick(2);
 #pragma unroll
     for (int c = 0; c < FC; ++c) p[c] = r[c];
     float rsold = dot_compact<F>(r, r);
@@ -203,8 +223,11 @@ __global__ __launch_bounds__(64 * kClusterWaves, 4) void als_cg_cluster_kernel(
     const bool store = active && g == 0;
 
     for (int it = 0; it < cg_steps; ++it) {
+      tick(3);
       pass(std::false_type{}, tile, p, Ap, active);
+      tick(1);
       combine(Ap);
+      tick(2);
       if (active) {
         float alpha = rsold / dot_compact<F>(p, Ap);
 #pragma unroll
@@ -224,6 +247,13 @@ __global__ __launch_bounds__(64 * kClusterWaves, 4) void als_cg_cluster_kernel(
       }
     }
     if (store) store_compact<F>(xrow, lane, x);
+    tick(3);
+  }
+  if constexpr (STATS) {
+    if (lane == 0) {
+      for (int i = 0; i < 4; ++i) atomicAdd(&stats[i], tk[i]);
+      atomicAdd(&stats[7], t_rows);
+    }
   }
 }
 
@@ -233,7 +263,7 @@ static void launch_cluster(const imp_csr *C, int first, int count, T *X, const T
   if (count <= 0) return;
   constexpr int FC = F / 64, BLOCK = 64 * kClusterWaves;
   const size_t lds = ((size_t)F * F + (size_t)kClusterWaves * F + (size_t)CL * F) * sizeof(float);
-  auto kern = als_cg_cluster_kernel<F, CL, T>;
+  auto kern = als_cg_cluster_kernel<F, CL, false, T>;
   IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // co-resident workgroups: what the occupancy query admits per CU (2 by design), never more than 2; the cluster
   // protocol only needs ONE complete cluster resident, which any grid in dispatch order provides
@@ -245,9 +275,26 @@ static void launch_cluster(const imp_csr *C, int first, int count, T *X, const T
   const int grid = 8 * CL * clusters_per_xcd;
   (void)FC;
   static const bool allow_plain = getenv("IMP_CLUSTER_SC1") == nullptr;  // IMP_CLUSTER_SC1=1: write-through stores always (A/B)
+  static const bool want_stats = getenv("IMP_CG_STATS") != nullptr;
+  if (want_stats) {  // debug: per-phase tick sums of this launch, printed to stderr
+    static unsigned long long *stats = nullptr;
+    if (!stats) IMP_CHECK_HIP(hipMalloc(&stats, 8 * sizeof(unsigned long long)));
+    IMP_CHECK_HIP(hipMemsetAsync(stats, 0, 8 * sizeof(unsigned long long), stream()));
+    auto skern = als_cg_cluster_kernel<F, CL, true, T>;
+    IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(skern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    skern<<<grid, BLOCK, lds, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(), C->data.data(), X, Y,
+                                         A0, cg_steps, xchg, ctx().cluster_fault, allow_plain ? 1 : 0, stats);
+    unsigned long long h[8];
+    IMP_CHECK_HIP(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, stream()));
+    IMP_CHECK_HIP(hipStreamSynchronize(stream()));
+    const double n = h[7] ? (double)h[7] : 1.0;
+    fprintf(stderr, "[cg-stats] %s rows=%d grid=%d wave-rows=%.0f  cycles/wave-row: gather %.1f passes %.1f exchanges %.1f update %.1f\n",
+            name, count, grid, n, h[0] / n, h[1] / n, h[2] / n, h[3] / n);
+    return;
+  }
   IMP_PROF(name);
   kern<<<grid, BLOCK, lds, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(), C->data.data(), X, Y,
-                                      A0, cg_steps, xchg, ctx().cluster_fault, allow_plain ? 1 : 0);
+                                      A0, cg_steps, xchg, ctx().cluster_fault, allow_plain ? 1 : 0, nullptr);
   IMP_CHECK_HIP(hipGetLastError());
 }
 

@@ -1,8 +1,12 @@
 #!/bin/bash
-# A/B of one environment switch on the C3 bench: ab_env.sh <tag> <VAR> <v1> <v2> ... ; optional EXTRA_ARGS env
-set -u
-O=gpurun_out/$1; VAR=$2; shift 2; mkdir -p $O
-B="python bench.py --no-cpu-baseline --no-topk --steps 8 --warmup 2 ${EXTRA_ARGS:-}"
-for v in "$@"; do
-env $VAR=$v timeout 300 $B > $O/${VAR}_$v.json 2> $O/${VAR}_$v.err
+# A/B of environment switches on the headline bench: ab_env.sh <tag> "VAR=val" "VAR2=val" ...  ("" = default)
+out=gpurun_out/${1:-ab}; shift
+mkdir -p $out
+i=0
+for setting in "$@"; do
+  i=$((i+1))
+  env $setting timeout 600 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-topk ${BENCH_ARGS:---no-extras} > $out/b$i.json 2> $out/b$i.err
+  echo "== $setting" >> $out/summary.txt
+  python profiles/scripts/show.py $out 2>/dev/null | grep -A2 "b$i.json" >> $out/summary.txt
 done
+cat $out/summary.txt

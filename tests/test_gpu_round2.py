@@ -158,6 +158,7 @@ for f in (64, 128):
         Y0 = rng.random((M.shape[1], f), dtype=np.float32) * 0.2 - 0.1
         Xd, Yd, gram = gpu.Matrix(X0), gpu.Matrix(Y0), gpu.Matrix.zeros(f, f)
         solver.calculate_yty(Yd, gram, 0.05)
+        assert rel(gram.to_numpy(), oracle.gramian(Y0) + np.float32(0.05) * np.eye(f, dtype=np.float32)) < 1e-6
         solver.least_squares(gpu.CSRMatrix(M), Xd, gram, Yd, 3)
         want = X0.copy()
         oracle.least_squares_cg(M, want, Y0, 0.05, cg_steps=3, YtY=gram.to_numpy())
@@ -184,7 +185,8 @@ print("switch ok")
 
 
 @pytest.mark.parametrize("switch", ["IMP_SHORT_TEAM1=1", "IMP_SHORT_TEAM1=0", "IMP_STRIPE=0", "IMP_SEGMENT=128",
-                                    "IMP_CHOL_NO_MFMA=1", "IMP_CHOL_NO_WAVE=1", "IMP_TOPK_NO_FAST=1", "IMP_NO_CLUSTER=1"])
+                                    "IMP_CHOL_NO_MFMA=1", "IMP_CHOL_NO_WAVE=1", "IMP_TOPK_NO_FAST=1", "IMP_NO_CLUSTER=1", "IMP_CLUSTER_SC1=1",
+                                    "IMP_GRAM_NO_VEC=1"])
 def test_ab_switch_paths_keep_parity(gpu, switch):
     """Every debug / A-B environment switch selects kernels the default run does not take (they are read once per
     process, hence the subprocess): CG both orientations at f = 64 / 128, Cholesky f = 64 and top-k against the oracle."""
