@@ -282,7 +282,11 @@ template <int VPL, bool VEC> __device__ __forceinline__ void load_xrow(const __h
 }
 template <typename T> __device__ __forceinline__ void store_x(T *p, float v) { store1(p, v); }
 
-template <int VPL, bool VEC, int BLOCK, bool A_LDS, int PHASE, typename T>
+// ROWBLOCK: one WORKGROUP per row instead of one wavefront -- for plans of few, very long rows (the rows beyond the cluster
+// kernels' reach: 98 rows with up to 288 + segment partials each at C3), where a single wavefront walking a row's partials
+// is the launch's critical path.  The wavefronts sum strided subsets of the partials, wavefront 0 adds the subset sums
+// in a fixed order and carries on alone.
+template <int VPL, bool VEC, int BLOCK, bool A_LDS, int PHASE, bool ROWBLOCK, typename T>
 __global__ __launch_bounds__(BLOCK) void cg_long_combine_kernel(const LongPlanDev plan, T *__restrict__ X,
                                                                 const float *__restrict__ A0, int f,
                                                                 const float *__restrict__ partial, float *__restrict__ rvec,
@@ -298,12 +302,51 @@ __global__ __launch_bounds__(BLOCK) void cg_long_combine_kernel(const LongPlanDe
   const float *Amat = stage_gramian<VPL, VEC, BLOCK, A_LDS>(smem, A0, f);
   const int lda = A_LDS ? LD : f;
   const int vld = VEC ? LD : f;  // logical length for guarded loads from the LD-strided workspaces
-  for (int li = blockIdx.x * WAVES + wave; li < plan.n_long; li += gridDim.x * WAVES) {
-    if (PHASE == 1 && scal[2 * li + 1] != 0.f) continue;
+  float *red = smem + (A_LDS ? (size_t)f * LD : 0);  // [WAVES][LD], ROWBLOCK only
+  for (int li = ROWBLOCK ? (int)blockIdx.x : (int)blockIdx.x * WAVES + wave; li < plan.n_long;
+       li += ROWBLOCK ? (int)gridDim.x : (int)gridDim.x * WAVES) {
+    if (PHASE == 1 && scal[2 * li + 1] != 0.f) continue;  // ROWBLOCK: the same for the whole workgroup
     T *xrow = X + (size_t)plan.rows[li] * f;
     float acc[VPL];
     const int s0 = plan.row_seg[li], s1 = plan.row_seg[li + 1];
-    {  // fixed association: NS interleaved running sums, folded pairwise (a 147 K-nnz row has 288 segment partials;
+    if constexpr (ROWBLOCK) {
+      constexpr int NS = 4;
+      float a4[NS][VPL];
+#pragma unroll
+      for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) a4[i][v] = 0.f;
+      int s = s0 + wave;
+      for (; s + (NS - 1) * WAVES < s1; s += NS * WAVES) {
+        float t[NS][VPL];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) load_row<VPL, VEC>(partial + (size_t)(s + i * WAVES) * LD, vld, lane, t[i]);
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
+#pragma unroll
+          for (int v = 0; v < VPL; ++v) a4[i][v] += t[i][v];
+      }
+      for (; s < s1; s += WAVES) {
+        float t[VPL];
+        load_row<VPL, VEC>(partial + (size_t)s * LD, vld, lane, t);
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) a4[0][v] += t[v];
+      }
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) red[wave * LD + elem<VPL, VEC>(lane, v)] = (a4[0][v] + a4[1][v]) + (a4[2][v] + a4[3][v]);
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          float t = 0.f;
+#pragma unroll
+          for (int w = 0; w < WAVES; ++w) t += red[w * LD + elem<VPL, VEC>(lane, v)];
+          acc[v] = t;
+        }
+      }
+      __syncthreads();  // `red` is free again
+      if (wave != 0) continue;
+    } else {  // fixed association: NS interleaved running sums, folded pairwise (a 147 K-nnz row has 288 segment partials;
        // one dependent chain of loads + adds would make that row the launch's critical path)
       constexpr int NS = 8;
       float a8[NS][VPL];
@@ -443,15 +486,17 @@ static void launch_long(const imp_csr *C, const LongPlan &lp, T *X, const T *Y, 
   float *xvec = kHalf ? scal + 2 * (size_t)n_long : nullptr;
   LongPlanDev plan = lp.dev(C->order.data());
 
-  size_t lds = (A_LDS ? (size_t)f * LD : 0) * sizeof(float);
-  auto comb0 = cg_long_combine_kernel<VPL, VEC, BLOCK, A_LDS, 0, T>;
-  auto comb1 = cg_long_combine_kernel<VPL, VEC, BLOCK, A_LDS, 1, T>;
+  // few rows (the streamed remainder of the f = 64 / 128 path): one workgroup per row in the combine kernel
+  const bool rowblock = n_long <= ctx().num_cus * 2;
+  size_t lds = ((A_LDS ? (size_t)f * LD : 0) + (rowblock ? (size_t)(BLOCK / 64) * LD : 0)) * sizeof(float);
+  auto comb0 = rowblock ? cg_long_combine_kernel<VPL, VEC, BLOCK, A_LDS, 0, true, T> : cg_long_combine_kernel<VPL, VEC, BLOCK, A_LDS, 0, false, T>;
+  auto comb1 = rowblock ? cg_long_combine_kernel<VPL, VEC, BLOCK, A_LDS, 1, true, T> : cg_long_combine_kernel<VPL, VEC, BLOCK, A_LDS, 1, false, T>;
   IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(comb0), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)std::max<size_t>(lds, 16)));
   IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(comb1), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)std::max<size_t>(lds, 16)));
   int grid_part = std::min(((n_seg + 3) / 4 + 7) / 8 * 8, ctx().num_cus * 8);  // a multiple of 8: blockIdx % 8 = XCD
-  int grid_comb = std::min((n_long + BLOCK / 64 - 1) / (BLOCK / 64), ctx().num_cus * 2);
+  int grid_comb = rowblock ? n_long : std::min((n_long + BLOCK / 64 - 1) / (BLOCK / 64), ctx().num_cus * 2);
   {
     IMP_PROF("als_cg_long_partial");
     if constexpr (VEC && (VPL == 1 || VPL == 2))
