@@ -298,14 +298,24 @@ static void launch_cluster(const imp_csr *C, int first, int count, T *X, const T
   IMP_CHECK_HIP(hipGetLastError());
 }
 
+// rows of (256, 512] nonzeros fit one 16-wave workgroup (als_cg_q.hip, team16) -- but that kernel holds a CU with a single
+// workgroup, whose gather and combine phases nothing overlaps; as a cluster of TWO 8-wave workgroups the row shares its CUs
+// with another row.  IMP_TEAM16_CLUSTER=1 selects it (A/B).
+bool team16_as_cluster() {
+  static const bool on = getenv("IMP_TEAM16_CLUSTER") != nullptr && getenv("IMP_NO_CLUSTER") == nullptr;
+  return on;
+}
+
 template <int F, typename T> static void run_clusters(const imp_csr *C, T *X, const T *Y, const float *A0, int cg_steps) {
   const int32_t *cut = C->cluster_cut;  // rows longer than 4096 / 2048 / 1024 / 512: classes (2048,4096] (1024,2048] (512,1024]
-  if (cut[3] - cut[0] <= 0) return;
+  const int32_t *b = C->bin_start;
+  const bool with16 = team16_as_cluster() && b[2] - b[1] > 0;
+  if (cut[3] - cut[0] <= 0 && !with16) return;
   auto &c = ctx();
   // exchange slots: [class][cluster][2][CL][64 FC] granules; clusters * CL <= workgroups in flight <= 2 per CU
   constexpr size_t FC = F / 64;
   const size_t per_class = (size_t)c.num_cus * 2 * 2 * 64 * FC;
-  if (c.cluster_xchg.size < 3 * per_class) c.cluster_xchg.alloc(3 * per_class);
+  if (c.cluster_xchg.size < 4 * per_class) c.cluster_xchg.alloc(4 * per_class);
   if (!c.cluster_fault) {
     IMP_CHECK_HIP(hipHostMalloc(reinterpret_cast<void **>(&c.cluster_fault), sizeof(unsigned), hipHostMallocMapped));
     *c.cluster_fault = 0u;
@@ -313,11 +323,12 @@ template <int F, typename T> static void run_clusters(const imp_csr *C, T *X, co
   unsigned long long *xchg = c.cluster_xchg.data();
   {
     IMP_PROF("als_cg_cluster_reset");
-    IMP_CHECK_HIP(hipMemsetAsync(xchg, 0, 3 * per_class * sizeof(unsigned long long), stream()));
+    IMP_CHECK_HIP(hipMemsetAsync(xchg, 0, 4 * per_class * sizeof(unsigned long long), stream()));
   }
   launch_cluster<F, 16, T>(C, cut[0], cut[1] - cut[0], X, Y, A0, cg_steps, xchg, "als_cg_cluster16_rows");
   launch_cluster<F, 8, T>(C, cut[1], cut[2] - cut[1], X, Y, A0, cg_steps, xchg + per_class, "als_cg_cluster8_rows");
   launch_cluster<F, 4, T>(C, cut[2], cut[3] - cut[2], X, Y, A0, cg_steps, xchg + 2 * per_class, "als_cg_cluster4_rows");
+  if (with16) launch_cluster<F, 2, T>(C, b[1], b[2] - b[1], X, Y, A0, cg_steps, xchg + 3 * per_class, "als_cg_team16_rows");
 }
 
 // true if a cluster kernel of an earlier launch on this device gave up on an exchange (checked by the solver entry point

@@ -392,7 +392,7 @@ static void launch_qteam(const imp_csr *C, int first, int count, T *X, const T *
 
 template <int F, typename T> static void run_classes_q(const imp_csr *C, T *X, const T *Y, const float *A0, int cg_steps) {
   const int32_t *b = C->bin_start;  // classes: 1 (256,512]  2 (128,256]  3 (64,128]  4 (32,64]  5 (16,32]  6 (0,16]
-  launch_qteam<F, 16, 1024, T>(C, b[1], b[2] - b[1], X, Y, A0, cg_steps, "als_cg_team16_rows");
+  if (!team16_as_cluster()) launch_qteam<F, 16, 1024, T>(C, b[1], b[2] - b[1], X, Y, A0, cg_steps, "als_cg_team16_rows");
   launch_qteam<F, 8, 512, T>(C, b[2], b[3] - b[2], X, Y, A0, cg_steps, "als_cg_team8_rows");
   launch_qteam<F, 4, 512, T>(C, b[3], b[4] - b[3], X, Y, A0, cg_steps, "als_cg_team4_rows");
   launch_qteam<F, 2, 512, T>(C, b[4], b[5] - b[4], X, Y, A0, cg_steps, "als_cg_team2_rows");

@@ -16,6 +16,8 @@
 
 namespace imp {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 constexpr int kCholTile = 8;
 
 __device__ __forceinline__ float bcast_lane(float v, int lane) {
@@ -374,12 +376,14 @@ __global__ __launch_bounds__(256, 2) void als_cholesky_f64_kernel(const int32_t 
     const float b_even_src = __shfl(be, lane >> 1, 64), b_odd_src = __shfl(bo, lane >> 1, 64);
     float b = (lane_v & 1) ? b_odd_src : b_even_src;  // b[lane]
     // row-per-lane registers: A[lane][j] = image + G for j <= lane (beyond: other rows' words, never used)
-    float A[F];
+    // kept as register PAIRS: the dot products below run on v_pk_fma_f32 (two FMAs per issue slot)
+    f32x2 A2[F / 2];
+#define A(j) A2[(j) >> 1][(j) & 1]
 #pragma unroll
     for (int j = 0; j < F; j += 4) {
       const float4 t = *reinterpret_cast<const float4 *>(As + my_off + j);
       const float4 g = *reinterpret_cast<const float4 *>(Gs + lane * GLD + j);
-      A[j] = t.x + g.x, A[j + 1] = t.y + g.y, A[j + 2] = t.z + g.z, A[j + 3] = t.w + g.w;
+      A(j) = t.x + g.x, A(j + 1) = t.y + g.y, A(j + 2) = t.z + g.z, A(j + 3) = t.w + g.w;
     }
     tick(2);
     bool ok = true;
@@ -391,23 +395,25 @@ __global__ __launch_bounds__(256, 2) void als_cholesky_f64_kernel(const int32_t 
     float4 lrow[F / 4];
     static_for<F>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
-      // s = A[lane][k] - sum_{j<k} L[lane][j] L[k][j], 4 independent accumulators
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      // s = A[lane][k] - sum_{j<k} L[lane][j] L[k][j], 4 independent accumulators in two packed pairs
+      f32x2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < k; j += 4) {
         const float4 l = lrow[j / 4];
-        s0 = fmaf(A[j], l.x, s0);
-        if (j + 1 < k) s1 = fmaf(A[j + 1], l.y, s1);  // compile-time conditions: the last chunk of a row is partial
-        if (j + 2 < k) s2 = fmaf(A[j + 2], l.z, s2);
-        if (j + 3 < k) s3 = fmaf(A[j + 3], l.w, s3);
+        // compile-time conditions: the last chunk of a row is partial
+        if (j + 1 < k) s01 = __builtin_elementwise_fma(A2[j / 2], (f32x2){l.x, l.y}, s01);
+        else s01.x = fmaf(A(j), l.x, s01.x);
+        if (j + 3 < k) s23 = __builtin_elementwise_fma(A2[j / 2 + 1], (f32x2){l.z, l.w}, s23);
+        else if (j + 2 < k) s23.x = fmaf(A(j + 2), l.z, s23.x);
       }
+      const float s0 = s01.x, s1 = s01.y, s2 = s23.x, s3 = s23.y;
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (k + 1 < F) {  // row k+1, chunks below the one that holds column k
 #pragma unroll
         for (int c = 0; c < k / 4; ++c) lrow[c] = *reinterpret_cast<const float4 *>(As + chol_rowoff(k + 1) + 4 * c);
       }
       __builtin_amdgcn_sched_barrier(0);
-      const float s = A[k] - ((s0 + s1) + (s2 + s3));
+      const float s = A(k) - ((s0 + s1) + (s2 + s3));
       const float d = bcast_lane(s, k);  // pivot
       if (!(d > 0.f)) ok = false;
       // 1 / sqrt(d): v_rsq_f32 (1 ulp) + one Newton step -- as accurate as sqrt followed by a true division (two roundings)
@@ -416,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void als_cholesky_f64_kernel(const int32_t 
       const float r0 = __builtin_amdgcn_rsqf(d);
       const float inv = fmaf(r0, fmaf(-0.5f * d * r0, r0, 0.5f), r0);  // r0 + r0 (1/2 - d r0^2 / 2)
       const float lik = s * inv;  // L[i][k] for i >= k
-      A[k] = lik;
+      A(k) = lik;
       if (lane_v >= k) As[my_off + k] = lik;  // rows above k have no column k in the triangular image
       if constexpr (k + 1 < F) lrow[k / 4] = *reinterpret_cast<const float4 *>(As + chol_rowoff(k + 1) + 4 * (k / 4));
       const float zk = bcast_lane(b, k) * inv;  // z_k = b_k / L_kk; the forward substitution rides along
@@ -433,15 +439,16 @@ __global__ __launch_bounds__(256, 2) void als_cholesky_f64_kernel(const int32_t 
     // row k of the image read ACROSS the lanes (contiguous, conflict-free) -- one FMA per unknown.  The 64 reads do not
     // depend on the chain: they are all issued first (into the registers the row of L no longer needs).
 #pragma unroll
-    for (int k = 0; k < F; ++k) A[k] = As[chol_rowoff(k) + lane];  // L[k][lane] (meaningful for lane < k; beyond: other rows' words)
+    for (int k = 0; k < F; ++k) A(k) = As[chol_rowoff(k) + lane];  // L[k][lane] (meaningful for lane < k; beyond: other rows' words)
     __builtin_amdgcn_sched_barrier(0);
     b *= dinv;  // lane k now holds z_k / L[k][k]; the pending corrections are scaled the same way as they arrive
     static_for<F>([&](auto kc) {
       constexpr int k = F - 1 - decltype(kc)::value;
       const float xk = bcast_lane(b, k);  // x_k: lane k's value is final once all x_j, j > k, have been applied
-      b = lane_v < k ? fmaf(-A[k] * dinv, xk, b) : b;
+      b = lane_v < k ? fmaf(-A(k) * dinv, xk, b) : b;
     });
     X[(size_t)u * F + lane] = b;
+#undef A
     tick(4);
     if constexpr (STATS) tk[7] += 1;
   }

@@ -65,6 +65,7 @@ template <typename F> int guarded(F &&body) {
 
 inline hipStream_t stream();
 void sync();  // hipStreamSynchronize on the library stream
+bool team16_as_cluster();    // als_cg_cluster.hip: rows of (256,512] nnz on clusters of two workgroups instead of team16
 bool cluster_fault_pending();  // als_cg_cluster.hip: a cluster exchange timed out since the last check (clears the flag)
 
 // ---- launch-time profiler (HIP events on the library stream) ------------------------------------
