@@ -59,6 +59,7 @@ __global__ __launch_bounds__(64 * kClusterWaves, 4) void als_cg_cluster_kernel(
   float *A0s = smem;                     // [F][F]  (only in the workgroups that own dense rows)
   float *scratch = A0s + (size_t)F * F;  // [WAVES][F]  wave partials of the combine; between combines: wave-private operand copy
   float *xb = scratch + (size_t)WAVES * F;  // [CL][F]  the cluster's workgroup partials after the exchange
+  int *xflag = reinterpret_cast<int *>(xb + (size_t)CL * F);  // [CL]  tag of member m's granules in the last exchange
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
@@ -78,7 +79,11 @@ __global__ __launch_bounds__(64 * kClusterWaves, 4) void als_cg_cluster_kernel(
   unsigned seq = 0;
   int parity = 0;
   bool faulted = false;
-  bool same_xcd = false;  // until verified below
+  // Placement check: every granule's tag carries the sender's XCC id (HW_REG_XCC_ID[3:0]) in its top four bits.  The
+  // first exchange of the kernel is written through; once a workgroup has seen that all CL members report its own id --
+  // every member sees the same CL tags, hence takes the same decision -- later exchanges use plain stores.
+  const unsigned xcc_tag = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 28;
+  bool same_xcd = false;
   auto combine = [&](float (&acc)[FC]) {
     // addresses of the exchange are re-derived per call: hoisted out of the row loop they would cost registers the
     // kernel does not have (the tile fills the file) and come back as scratch reloads
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(64 * kClusterWaves, 4) void als_cg_cluster_kernel(
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) s += scratch[w * F + QL<F>::cfactor(ln, c)];
-        const unsigned long long granule = ((unsigned long long)seq << 32) | (unsigned long long)__float_as_uint(s);
+        const unsigned long long granule = ((unsigned long long)(seq | xcc_tag) << 32) | (unsigned long long)__float_as_uint(s);
         // members on one XCD share its L2: a plain store lands there and the readers' sc1 loads (which bypass only
         // their L1) hit it; an sc1 store writes through to the fabric and drops the line, which the readers then
         // fetch at the cross-XCD latency -- required when the members sit on different XCDs, whose L2s are not coherent
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(64 * kClusterWaves, 4) void als_cg_cluster_kernel(
           for (int c = 0; c < FC; ++c) {
             granule[k][c] = __hip_atomic_load(slot + (((wave + k * WAVES) * 64 + ln) * FC + c), __ATOMIC_RELAXED,
                                               __HIP_MEMORY_SCOPE_AGENT);
-            ok = ok && (unsigned)(granule[k][c] >> 32) == seq;
+            ok = ok && ((unsigned)(granule[k][c] >> 32) & 0x0FFFFFFFu) == seq;
           }
         if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
         if (faulted || ++spins > kSpinLimit) {  // never expected: give up instead of hanging the device
@@ -129,6 +134,8 @@ __global__ __launch_bounds__(64 * kClusterWaves, 4) void als_cg_cluster_kernel(
       for (int k = 0; k < PER; ++k)
 #pragma unroll
         for (int c = 0; c < FC; ++c) xb[(wave + k * WAVES) * F + QL<F>::cfactor(ln, c)] = __uint_as_float((unsigned)granule[k][c]);
+#pragma unroll
+      for (int k = 0; k < PER; ++k) xflag[wave + k * WAVES] = (int)(granule[k][0] >> 32);  // the tag: read by the placement check
     }
     __syncthreads();  // B2: all CL partials in LDS; wave 0 has finished reading the wave partials
 #pragma unroll
@@ -162,19 +169,6 @@ __global__ __launch_bounds__(64 * kClusterWaves, 4) void als_cg_cluster_kernel(
     }
     reduce_expanded<F>(ae, acc);
   };
-
-  // Placement check (once per workgroup): the members exchange their XCC ids with write-through stores; only if all CL
-  // ids are equal -- sum and sum of squares of the ids, exact in fp32 -- do later exchanges use plain stores.  Every member
-  // sees the same CL values, hence takes the same decision.
-  if (allow_plain) {
-    const float xcc = (float)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID[3:0]
-    float s1[FC], s2[FC];
-#pragma unroll
-    for (int c = 0; c < FC; ++c) s1[c] = wave == 0 ? xcc : 0.f, s2[c] = wave == 0 ? xcc * xcc : 0.f;
-    combine(s1);
-    combine(s2);
-    same_xcd = (float)CL * s2[0] == s1[0] * s1[0];
-  }
 
   // this cluster's rows: i = cid + k ncl; the loop bounds depend on cid alone, so all members run the same exchanges
   auto row_id = [&](int i) { return order[first + min(i, count - 1)]; };  // uniform address: scalar load
@@ -215,6 +209,10 @@ __global__ __launch_bounds__(64 * kClusterWaves, 4) void als_cg_cluster_kernel(
     pass(std::true_type{}, tile, x, r, true);
     tick(1);
     combine(r);
+    if (seq == 1u && allow_plain) {  // after the kernel's first exchange: did every member report this workgroup's XCC?
+      const bool agree = lane < CL ? ((unsigned)xflag[lane] & 0xF0000000u) == xcc_tag : true;
+      same_xcd = __builtin_amdgcn_ballot_w64(!agree) == 0ull;
+    }
     tick(2);
 #pragma unroll
     for (int c = 0; c < FC; ++c) p[c] = r[c];
@@ -262,7 +260,7 @@ static void launch_cluster(const imp_csr *C, int first, int count, T *X, const T
                            unsigned long long *xchg, const char *name) {
   if (count <= 0) return;
   constexpr int FC = F / 64, BLOCK = 64 * kClusterWaves;
-  const size_t lds = ((size_t)F * F + (size_t)kClusterWaves * F + (size_t)CL * F) * sizeof(float);
+  const size_t lds = ((size_t)F * F + (size_t)kClusterWaves * F + (size_t)CL * F + 16) * sizeof(float);
   auto kern = als_cg_cluster_kernel<F, CL, false, T>;
   IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // co-resident workgroups: what the occupancy query admits per CU (2 by design), never more than 2; the cluster
