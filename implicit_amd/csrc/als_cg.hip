@@ -462,7 +462,7 @@ static void launch_fused(const imp_csr *C, int first, int count, float *X, const
   IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)std::max<size_t>(lds, 16)));
   int blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / BLOCK, (160 * 1024) / std::max<size_t>(lds, 1)));
-  int grid = std::min((count + BLOCK / 64 - 1) / (BLOCK / 64), ctx().num_cus * blocks_per_cu);
+  int grid = std::min((count + BLOCK / 64 - 1) / (BLOCK / 64), ctx().num_cus * blocks_per_cu * ctx().oversub);
   IMP_PROF(name);
   kern<<<grid, BLOCK, lds, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(), C->data.data(), X, Y,
                                        A0, f, cg_steps);

@@ -268,7 +268,7 @@ static void launch_cluster(const imp_csr *C, int first, int count, T *X, const T
   int per_cu = 0;
   IMP_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, BLOCK, lds));
   per_cu = std::max(1, std::min(per_cu, 2));
-  const int max_clusters_per_xcd = std::max(1, ctx().num_cus * per_cu / 8 / CL);
+  const int max_clusters_per_xcd = std::max(1, ctx().num_cus * per_cu / 8 / CL) * ctx().oversub;
   const int clusters_per_xcd = std::min(max_clusters_per_xcd, (count + 7) / 8);
   const int grid = 8 * CL * clusters_per_xcd;
   (void)FC;
@@ -312,7 +312,7 @@ template <int F, typename T> static void run_clusters(const imp_csr *C, T *X, co
   auto &c = ctx();
   // exchange slots: [class][cluster][2][CL][64 FC] granules; clusters * CL <= workgroups in flight <= 2 per CU
   constexpr size_t FC = F / 64;
-  const size_t per_class = (size_t)c.num_cus * 2 * 2 * 64 * FC;
+  const size_t per_class = (size_t)c.num_cus * 2 * c.oversub * 2 * 64 * FC;
   if (c.cluster_xchg.size < 4 * per_class) c.cluster_xchg.alloc(4 * per_class);
   if (!c.cluster_fault) {
     IMP_CHECK_HIP(hipHostMalloc(reinterpret_cast<void **>(&c.cluster_fault), sizeof(unsigned), hipHostMallocMapped));

@@ -348,7 +348,7 @@ static void launch_qgroup(const imp_csr *C, int first, int count, T *X, const T 
   size_t lds = QGroupCfg<F>::lds_floats * sizeof(float);
   auto kern = als_cg_qgroup_kernel<F, T>;
   IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  int grid = std::min((count + 15) / 16, ctx().num_cus * 2);
+  int grid = std::min((count + 15) / 16, ctx().num_cus * 2 * ctx().oversub);
   IMP_PROF(name);
   kern<<<grid, 1024, lds, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(), C->data.data(), X, Y, A0,
                                       cg_steps);
@@ -364,7 +364,12 @@ static void launch_qteam(const imp_csr *C, int first, int count, T *X, const T *
   auto kern = als_cg_qteam_kernel<F, WPR, BLOCK, false, T>;
   IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / BLOCK, (160 * 1024) / lds));
-  int grid = std::min((count + TEAMS - 1) / TEAMS, ctx().num_cus * per_cu);
+  // workgroups per resident slot: fixed shares of a length-sorted schedule leave the slots unevenly loaded towards the end
+  // of the launch; smaller shares dealt by the hardware dispatcher even that out (C3: (32,64] 1.11 -> 1.04 ms at 4x,
+  // (64,128] 0.88 -> 0.84 at 4x, (128,256] 0.585 -> 0.574 at 2x; the one-workgroup-per-CU kernels lose: each new
+  // workgroup stages the gramian again).  The multi-GPU driver's factor (Context::oversub) is a floor, not a multiplier
+  constexpr int kBaseOversub = WPR <= 4 ? 4 : (WPR == 8 ? 2 : 1);
+  int grid = std::min((count + TEAMS - 1) / TEAMS, ctx().num_cus * per_cu * std::max(kBaseOversub, ctx().oversub));
   static const bool want_stats = getenv("IMP_CG_STATS") != nullptr;
   if (want_stats) {  // debug: per-phase tick sums of this launch, printed to stderr
     static unsigned long long *stats = nullptr;

@@ -476,7 +476,7 @@ int64_t least_squares_cholesky(const imp_csr *C, imp_matrix *X, const imp_matrix
   if (nonempty > 0 && f == 64 && !no_mfma && !no_wave) {
     // every non-empty row: MFMA A-build + left-looking Cholesky, one wavefront per row
     const size_t lds_m = ((size_t)64 * 68 + 4 * kCholTri) * sizeof(float);  // 52 KB: 3 workgroups per CU
-    const int grid = std::min((nonempty + 3) / 4, ctx().num_cus * 2);  // ~190 VGPRs: 2 waves per SIMD
+    const int grid = std::min((nonempty + 3) / 4, ctx().num_cus * 2 * ctx().oversub);  // ~190 VGPRs: 2 waves per SIMD
     static const bool want_stats = getenv("IMP_CHOL_STATS") != nullptr;
     if (want_stats) {  // debug: per-phase tick sums of this launch, printed to stderr
       IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(als_cholesky_f64_kernel<true>),

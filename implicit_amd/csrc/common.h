@@ -110,6 +110,12 @@ struct Context {
   int device = 0;
   hipStream_t stream = nullptr;
   int num_cus = 256;
+  // Persistent row kernels launch `slots()` workgroups, each with a fixed share of the rows.  oversub > 1 (multi-GPU
+  // driver, imp_set_oversubscribe) launches that many times more workgroups with proportionally smaller shares: when part
+  // of the device is held by another stream's kernels (RCCL send / recv) the workgroups that have to wait for a slot no
+  // longer carry a full share, and the hardware dispatcher balances the rest.
+  int oversub = 1;
+  hipStream_t occupy_stream = nullptr;  // imp_debug_occupy
   std::recursive_mutex mutex;
   DeviceArray<float> gram_ws;     // split-K partial gramians (gramian.hip)
   DeviceArray<float> long_ws;     // partial vectors / CG state of the long rows (als_cg.hip)

@@ -34,6 +34,7 @@ Context &ctx() {
     hipDeviceProp_t prop;
     IMP_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
     c->num_cus = prop.multiProcessorCount;
+    if (const char *e = getenv("IMP_OVERSUB")) c->oversub = std::max(1, atoi(e));
     it = g_contexts.emplace(dev, std::move(c)).first;
   }
   return *it->second;
@@ -198,6 +199,15 @@ static int grid_for(size_t work_items, int block = 256) {
   return (int)std::max<size_t>(1, std::min(blocks, cap));
 }
 
+// stand-in for a resident collective kernel (imp_debug_occupy): 256 threads and 32 KB of LDS per workgroup, spinning on the
+// constant-rate wall clock
+__global__ __launch_bounds__(256) void occupy_kernel(long long ticks) {
+  extern __shared__ float pad[];
+  pad[threadIdx.x] = 0.f;
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 static imp_matrix *new_matrix(size_t rows, size_t cols, size_t itemsize, bool zero) {
   if (itemsize != 4 && itemsize != 2) throw std::invalid_argument("invalid itemsize for Matrix (must be 2 or 4)");
   auto m = std::make_unique<imp_matrix>();
@@ -235,6 +245,24 @@ int imp_get_device_count(int *count) {
 
 int imp_set_device(int device) {
   return guarded([&] { IMP_CHECK_HIP(hipSetDevice(device)); });
+}
+int imp_set_oversubscribe(int factor) {
+  return guarded([&] {
+    if (factor < 1 || factor > 64) throw std::invalid_argument("oversubscription factor must be in [1, 64]");
+    ctx().oversub = factor;
+  });
+}
+int imp_debug_occupy(int workgroups, int microseconds) {
+  return guarded([&] {
+    if (workgroups <= 0 || microseconds <= 0) return;
+    auto &c = ctx();
+    if (!c.occupy_stream) IMP_CHECK_HIP(hipStreamCreateWithFlags(&c.occupy_stream, hipStreamNonBlocking));
+    int rate_khz = 100000;  // wall_clock64 ticks per millisecond
+    IMP_CHECK_HIP(hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, c.device));
+    const long long ticks = (long long)microseconds * rate_khz / 1000;
+    occupy_kernel<<<workgroups, 256, 32 * 1024, c.occupy_stream>>>(ticks);
+    IMP_CHECK_HIP(hipGetLastError());
+  });
 }
 int imp_get_device(int *device) {
   return guarded([&] { IMP_CHECK_HIP(hipGetDevice(device)); });

@@ -392,6 +392,17 @@ def set_device(device):
     check(lib().imp_set_device(int(device)))
 
 
+def set_oversubscribe(factor):
+    """Workgroups launched per resident slot by the persistent row kernels (1 = exactly what the device holds; the
+    multi-GPU driver uses 4 so that slots held by RCCL's kernels only delay small shares)."""
+    check(lib().imp_set_oversubscribe(int(factor)))
+
+
+def debug_occupy(workgroups, microseconds):
+    """Measurement aid: park `workgroups` spinning workgroups on the device for about `microseconds`."""
+    check(lib().imp_debug_occupy(int(workgroups), int(microseconds)))
+
+
 def synchronize():
     check(lib().imp_device_synchronize())
 

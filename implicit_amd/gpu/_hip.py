@@ -19,6 +19,8 @@ _SIGNATURES = {
     "imp_get_device_count": [ctypes.POINTER(ctypes.c_int)],
     "imp_set_device": [ctypes.c_int],
     "imp_get_device": [ctypes.POINTER(ctypes.c_int)],
+    "imp_set_oversubscribe": [ctypes.c_int],
+    "imp_debug_occupy": [ctypes.c_int, ctypes.c_int],
     "imp_device_synchronize": [],
     "imp_mem_get_info": [ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)],
     "imp_matrix_create": [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, c_void_pp],

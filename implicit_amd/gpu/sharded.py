@@ -47,11 +47,22 @@ def shard_offsets(n_rows, nranks, weights=None):
 
 
 class GpuBackend:
-    """The real thing: implicit_amd.gpu objects (HIP kernels through the C-ABI)."""
+    """The real thing: implicit_amd.gpu objects (HIP kernels through the C-ABI).
 
-    def __init__(self, gpu, solver=None):
+    With more than one rank the exchange of chunk k (RCCL send / recv kernels on the exchange stream) is resident on
+    the device while the kernels of chunk k + 1 run.  The row kernels are persistent -- one workgroup per slot the
+    device has, each with a fixed share of the rows -- so a workgroup that has to wait for a slot held by RCCL would do
+    its whole share after everybody else has finished.  `nranks > 1` therefore launches them 4x oversubscribed
+    (imp_set_oversubscribe; IMP_SHARD_OVERSUB overrides): shares a quarter the size, balanced by the hardware
+    dispatcher over whatever slots are free (measured with a stand-in resident kernel: profiles/micro/oversub.py)."""
+
+    def __init__(self, gpu, solver=None, nranks=1):
+        import os
+
         self.gpu = gpu
         self.solver = solver or gpu.LeastSquaresSolver()
+        if nranks > 1:
+            gpu.set_oversubscribe(int(os.environ.get("IMP_SHARD_OVERSUB", "4")))
 
     def calculate_yty(self, rows, gram, reg):
         self.solver.calculate_yty(rows, gram, reg)
@@ -131,7 +142,7 @@ def fit_sharded(model, Cui, Ciu, comm, callback=None, chunks=None):
         Ci = [gpu.CSRMatrix(c) for c in split_rows(mine_i, chunks)]
     else:
         Cu, Ci = gpu.CSRMatrix(mine_u), gpu.CSRMatrix(mine_i)
-    backend = GpuBackend(gpu, solver=model.solver)
+    backend = GpuBackend(gpu, solver=model.solver, nranks=n)
     gram = gpu.Matrix.zeros(model.factors, model.factors)
     X, Y = model.user_factors, model.item_factors
     for it in range(model.iterations):
@@ -197,7 +208,7 @@ def bench(args, gpu, shapes, factors, reg, cg_steps, roofline_fn=None):
     Cui, Ciu, u_off, i_off = grid_shards(rank, world, users_total, items_total, nnz_total, grid, gamma=gamma, seed=42)
     t_gen = time.time() - t0
 
-    backend = GpuBackend(gpu)
+    backend = GpuBackend(gpu, nranks=world)
     # K row chunks per half sweep: chunk k is exchanged over xGMI while chunk k+1 is solved (one chunk = blocking form)
     pipelined = world > 1 or os.environ.get("IMP_FORCE_SHARDED")
     chunks = max(1, int(os.environ.get("IMP_SHARD_CHUNKS", "4"))) if pipelined else 1

@@ -52,6 +52,13 @@ const char *imp_last_error(void);
 int imp_get_device_count(int *count);
 int imp_set_device(int device);
 int imp_get_device(int *device);
+/* NEW (multi-GPU robustness).  The row kernels are persistent: by default exactly as many workgroups as the device holds at
+ * once, each with a fixed share of the rows.  While another stream's kernels (RCCL send / recv) hold part of the device, the
+ * workgroups that must wait for a slot would do their whole share late.  factor > 1 launches factor x as many workgroups
+ * with proportionally smaller shares; the hardware dispatcher then balances them over the slots that are free. */
+int imp_set_oversubscribe(int factor);
+/* Measurement aid: occupies `workgroups` x (256 threads, 32 KB LDS) for about `microseconds` on a stream of its own. */
+int imp_debug_occupy(int workgroups, int microseconds);
 int imp_device_synchronize(void);
 int imp_mem_get_info(size_t *free_bytes, size_t *total_bytes);
 const char *imp_version(void);
