@@ -404,3 +404,38 @@ def test_cluster_resident_long_rows(gpu, oracle, f, cg_steps):
     solver.least_squares(Cd, Xa, gram, Yd, 3)
     solver.least_squares(Cd, Xb, gram, Yd, 3)
     np.testing.assert_array_equal(Xa.to_numpy(), Xb.to_numpy())
+
+
+@pytest.mark.parametrize("f", [64, 128])
+def test_oversubscribed_launches_are_bitwise_identical(gpu, f):
+    """imp_set_oversubscribe only changes how many workgroups share the row schedule (the multi-GPU driver uses 4x so that
+    slots held by RCCL's kernels delay small shares only): every row's arithmetic is unchanged, with or without a foreign
+    kernel parked on the device (imp_debug_occupy) -- cluster exchanges included."""
+    rng = np.random.default_rng(5)
+    lens = np.concatenate([rng.integers(1, 600, 4000), rng.integers(513, 4097, 200), [5000, 7000], [0, 0, 0]])
+    rng.shuffle(lens)
+    cols = 9000
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    indices = np.concatenate([np.sort(rng.choice(cols, int(n), replace=False)) for n in lens] + [[]]).astype(np.int32)
+    data = (1.0 + 4.0 * rng.random(len(indices), dtype=np.float32)).astype(np.float32)
+    C = gpu.CSRMatrix(sp.csr_matrix((data, indices, indptr), shape=(len(lens), cols)))
+    X0 = rng.random((len(lens), f), dtype=np.float32) * 0.2 - 0.1
+    Yd = gpu.Matrix(rng.random((cols, f), dtype=np.float32) * 0.2 - 0.1)
+    solver, gram = gpu.LeastSquaresSolver(), gpu.Matrix.zeros(f, f)
+    solver.calculate_yty(Yd, gram, 0.05)
+    results = []
+    try:
+        for factor, occupy in ((1, 0), (4, 0), (4, 24), (1, 24)):
+            gpu.set_oversubscribe(factor)
+            if occupy:
+                gpu.debug_occupy(occupy, 30_000)
+            Xd = gpu.Matrix(X0)
+            solver.least_squares(C, Xd, gram, Yd, 3)
+            results.append(Xd.to_numpy())
+    finally:
+        gpu.set_oversubscribe(1)
+        gpu.synchronize()
+    for other in results[1:]:
+        np.testing.assert_array_equal(results[0], other)
+    with pytest.raises(ValueError):
+        gpu.set_oversubscribe(0)
