@@ -348,7 +348,8 @@ static void launch_qgroup(const imp_csr *C, int first, int count, T *X, const T 
   size_t lds = QGroupCfg<F>::lds_floats * sizeof(float);
   auto kern = als_cg_qgroup_kernel<F, T>;
   IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  int grid = std::min((count + 15) / 16, ctx().num_cus * 2 * ctx().oversub);
+  static const int per_cu = getenv("IMP_QGROUP_PER_CU") ? std::max(1, atoi(getenv("IMP_QGROUP_PER_CU"))) : 2;
+  int grid = std::min((count + 15) / 16, ctx().num_cus * std::max(per_cu, ctx().oversub));
   IMP_PROF(name);
   kern<<<grid, 1024, lds, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(), C->data.data(), X, Y, A0,
                                       cg_steps);
