@@ -257,7 +257,7 @@ __host__ __device__ constexpr int chol_rowoff(int i) { return 4 * ((i >> 2) + 1)
 constexpr int kCholTri = chol_rowoff(63) + 64;  // 2176 floats
 
 template <bool STATS>
-__global__ __launch_bounds__(256, 2) void als_cholesky_f64_kernel(const int32_t *__restrict__ order, int first, int count,
+__global__ __launch_bounds__(256, 3) void als_cholesky_f64_kernel(const int32_t *__restrict__ order, int first, int count,
                                                                   const int32_t *__restrict__ indptr,
                                                                   const int32_t *__restrict__ indices,
                                                                   const float *__restrict__ data, float *__restrict__ X,
@@ -429,6 +429,9 @@ __global__ __launch_bounds__(256, 2) void als_cholesky_f64_kernel(const int32_t 
       // rows above k are finished (z_i final) and their column-k value is not a matrix element in the triangular image
       b = lane_v == k ? zk : (lane_v > k ? fmaf(-lik, zk, b) : b);
       dinv = lane_v == k ? inv : dinv;
+      // here and now: left to the scheduler, the 64 selects sink below the loop and keep 64 `inv` values alive (231 registers
+      // instead of 172: the difference between two and three waves per SIMD)
+      asm volatile("" : "+v"(dinv));
     });
     tick(3);
     if (!ok) {
@@ -476,7 +479,7 @@ int64_t least_squares_cholesky(const imp_csr *C, imp_matrix *X, const imp_matrix
   if (nonempty > 0 && f == 64 && !no_mfma && !no_wave) {
     // every non-empty row: MFMA A-build + left-looking Cholesky, one wavefront per row
     const size_t lds_m = ((size_t)64 * 68 + 4 * kCholTri) * sizeof(float);  // 52 KB: 3 workgroups per CU
-    const int grid = std::min((nonempty + 3) / 4, ctx().num_cus * 2 * ctx().oversub);  // ~190 VGPRs: 2 waves per SIMD
+    const int grid = std::min((nonempty + 3) / 4, ctx().num_cus * 3 * ctx().oversub);  // 168 VGPRs, 52 KB LDS: 3 workgroups per CU
     static const bool want_stats = getenv("IMP_CHOL_STATS") != nullptr;
     if (want_stats) {  // debug: per-phase tick sums of this launch, printed to stderr
       IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(als_cholesky_f64_kernel<true>),
