@@ -256,6 +256,94 @@ template <int N, int I = 0, typename Body> __device__ __forceinline__ void stati
 __host__ __device__ constexpr int chol_rowoff(int i) { return 4 * ((i >> 2) + 1) * (2 * (i >> 2) + (i & 3)); }
 constexpr int kCholTri = chol_rowoff(63) + 64;  // 2176 floats
 
+// A-build over the nonzeros [row_begin, row_end) of one row: T_ee / T_oe / T_oo += Y^T diag(|c| - 1) Y (even / odd factor
+// split, see the kernel), be / bo += sum c+ y.  Shared by the row kernel and by the segment kernel of the long rows.
+__device__ __forceinline__ void chol_syrk_range(const int32_t *__restrict__ indices, const float *__restrict__ data,
+                                                const float *__restrict__ Y, int row_begin, int row_end, int lane, f32x16 &Tee,
+                                                f32x16 &Toe, f32x16 &Too, float &be, float &bo) {
+  constexpr int F = 64, KS = 4;
+  const int r = lane & 31, h = lane >> 5;
+  // one trip = KS k-steps = 2 KS nonzeros; lane (r, h) handles nonzero 2 q + h of every k-step q
+  float2 y[2][KS];
+  float w[2][KS], cp[2][KS];
+  auto fetch = [&](int buf, int my_idx, float my_c, int s0, int cnt) {
+#pragma unroll
+    for (int q = 0; q < KS; ++q) {
+      const int t = s0 + 2 * q + h;
+      const int tc = min(t, cnt - 1);
+      const unsigned col = (unsigned)__shfl(my_idx, tc, 64);
+      const float c = __shfl(my_c, tc, 64);
+      const bool ok = t < cnt;
+      w[buf][q] = ok ? fabsf(c) - 1.f : 0.f;
+      cp[buf][q] = (ok && c > 0.f) ? c : 0.f;
+      y[buf][q] = *reinterpret_cast<const float2 *>(Y + (size_t)col * F + 2 * r);
+    }
+  };
+  auto multiply = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < KS; ++q) {
+      const float ae = w[buf][q] * y[buf][q].x, ao = w[buf][q] * y[buf][q].y;
+      Tee = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, y[buf][q].x, Tee, 0, 0, 0);
+      Toe = __builtin_amdgcn_mfma_f32_32x32x2f32(ao, y[buf][q].x, Toe, 0, 0, 0);
+      Too = __builtin_amdgcn_mfma_f32_32x32x2f32(ao, y[buf][q].y, Too, 0, 0, 0);
+      be = fmaf(cp[buf][q], y[buf][q].x, be);
+      bo = fmaf(cp[buf][q], y[buf][q].y, bo);
+    }
+  };
+  if (row_begin < row_end) {
+    int idx_next = indices[row_begin + min(lane, row_end - row_begin - 1)];
+    float c_next = row_begin + lane < row_end ? data[row_begin + lane] : 1.f;  // confidence 1 -> weight 0, c+ masked
+    for (int k0 = row_begin; k0 < row_end; k0 += 64) {
+      const int cnt = min(64, row_end - k0);
+      const int my_idx = idx_next;
+      const float my_c = c_next;
+      if (k0 + 64 < row_end) {  // entries of the next 64 nonzeros
+        idx_next = indices[k0 + 64 + min(lane, row_end - k0 - 65)];
+        c_next = k0 + 64 + lane < row_end ? data[k0 + 64 + lane] : 1.f;
+      }
+      fetch(0, my_idx, my_c, 0, cnt);
+      for (int s0 = 0; s0 < cnt; s0 += 4 * KS) {  // two trips per round: the other buffer's gathers fly during the MFMAs
+        if (s0 + 2 * KS < cnt) fetch(1, my_idx, my_c, s0 + 2 * KS, cnt);
+        multiply(0);
+        if (s0 + 2 * KS < cnt) {
+          if (s0 + 4 * KS < cnt) fetch(0, my_idx, my_c, s0 + 4 * KS, cnt);
+          multiply(1);
+        }
+      }
+    }
+  }
+}
+
+// Rows of more than kCholLongRow nonzeros: the A-build of a row is serial in its wavefront (96 matrix-pipe cycles per
+// nonzero), and a popular item's row has tens of thousands of them -- the 79 K-nnz row of the configs[1] shape kept one
+// wavefront busy for 12.5 ms of a 15.6 ms launch.  Their nonzeros are therefore cut into segments of kCholSegment
+// (imp_csr::plan_chol), one wavefront per segment builds a partial (T_ee, T_oe, T_oo, b) here, and the row kernel sums a long
+// row's partials in segment order instead of walking its nonzeros.   workspace: [segment][50][64 lanes]
+constexpr int kCholPartial = 50 * 64;
+__global__ __launch_bounds__(256) void als_cholesky_f64_partial_kernel(const LongPlanDev plan, const int32_t *__restrict__ indices,
+                                                                       const float *__restrict__ data, const float *__restrict__ Y,
+                                                                       float *__restrict__ ws) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int sg = wave; sg < plan.n_seg; sg += nwaves) {
+    f32x16 Tee, Toe, Too;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Tee[e] = Toe[e] = Too[e] = 0.f;
+    float be = 0.f, bo = 0.f;
+    chol_syrk_range(indices, data, Y, plan.seg_begin[sg], plan.seg_end[sg], lane, Tee, Toe, Too, be, bo);
+    float *out = ws + (size_t)sg * kCholPartial + lane;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      out[e * 64] = Tee[e];
+      out[(16 + e) * 64] = Toe[e];
+      out[(32 + e) * 64] = Too[e];
+    }
+    out[48 * 64] = be;
+    out[49 * 64] = bo;
+  }
+}
+
 template <bool STATS>
 __global__ __launch_bounds__(256, 3) void als_cholesky_f64_kernel(const int32_t *__restrict__ order, int first, int count,
                                                                   const int32_t *__restrict__ indptr,
@@ -263,8 +351,9 @@ __global__ __launch_bounds__(256, 3) void als_cholesky_f64_kernel(const int32_t 
                                                                   const float *__restrict__ data, float *__restrict__ X,
                                                                   const float *__restrict__ Y, const float *__restrict__ YtY,
                                                                   float reg, unsigned long long *failed_row,
-                                                                  unsigned long long *stats) {
-  constexpr int F = 64, KS = 4, GLD = 68;
+                                                                  unsigned long long *stats, const LongPlanDev plan,
+                                                                  const float *__restrict__ partials) {
+  constexpr int F = 64, GLD = 68;
   // STATS (debug, IMP_CHOL_STATS=1): s_memtime ticks per phase summed over waves -- [1] SYRK loop (entries + gathers + MFMA)
   // [2] tiles -> LDS image -> row registers  [3] factorisation  [4] back substitution + store  [7] rows
   unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = 0;
@@ -290,7 +379,6 @@ __global__ __launch_bounds__(256, 3) void als_cholesky_f64_kernel(const int32_t 
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
-  const int r = lane & 31, h = lane >> 5;
   const int my_off = chol_rowoff(lane);
 
   for (int ri = wave; ri < count; ri += nwaves) {
@@ -307,54 +395,20 @@ __global__ __launch_bounds__(256, 3) void als_cholesky_f64_kernel(const int32_t 
     float be = 0.f, bo = 0.f;  // b partials of this lane's half: factors 2r and 2r+1
     tick(-1);
 
-    // one trip = KS k-steps = 2 KS nonzeros; lane (r, h) handles nonzero 2 q + h of every k-step q
-    float2 y[2][KS];
-    float w[2][KS], cp[2][KS];
-    auto fetch = [&](int buf, int my_idx, float my_c, int s0, int cnt) {
+    if (ri < plan.n_long) {  // long row (the first plan.n_long entries of the schedule): partials of its segments, in order
+      for (int sg = plan.row_seg[ri]; sg < plan.row_seg[ri + 1]; ++sg) {
+        const float *in = partials + (size_t)sg * kCholPartial + lane;
 #pragma unroll
-      for (int q = 0; q < KS; ++q) {
-        const int t = s0 + 2 * q + h;
-        const int tc = min(t, cnt - 1);
-        const unsigned col = (unsigned)__shfl(my_idx, tc, 64);
-        const float c = __shfl(my_c, tc, 64);
-        const bool ok = t < cnt;
-        w[buf][q] = ok ? fabsf(c) - 1.f : 0.f;
-        cp[buf][q] = (ok && c > 0.f) ? c : 0.f;
-        y[buf][q] = *reinterpret_cast<const float2 *>(Y + (size_t)col * F + 2 * r);
-      }
-    };
-    auto multiply = [&](int buf) {
-#pragma unroll
-      for (int q = 0; q < KS; ++q) {
-        const float ae = w[buf][q] * y[buf][q].x, ao = w[buf][q] * y[buf][q].y;
-        Tee = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, y[buf][q].x, Tee, 0, 0, 0);
-        Toe = __builtin_amdgcn_mfma_f32_32x32x2f32(ao, y[buf][q].x, Toe, 0, 0, 0);
-        Too = __builtin_amdgcn_mfma_f32_32x32x2f32(ao, y[buf][q].y, Too, 0, 0, 0);
-        be = fmaf(cp[buf][q], y[buf][q].x, be);
-        bo = fmaf(cp[buf][q], y[buf][q].y, bo);
-      }
-    };
-    if (row_begin < row_end) {
-      int idx_next = indices[row_begin + min(lane, row_end - row_begin - 1)];
-      float c_next = row_begin + lane < row_end ? data[row_begin + lane] : 1.f;  // confidence 1 -> weight 0, c+ masked
-      for (int k0 = row_begin; k0 < row_end; k0 += 64) {
-        const int cnt = min(64, row_end - k0);
-        const int my_idx = idx_next;
-        const float my_c = c_next;
-        if (k0 + 64 < row_end) {  // entries of the next 64 nonzeros
-          idx_next = indices[k0 + 64 + min(lane, row_end - k0 - 65)];
-          c_next = k0 + 64 + lane < row_end ? data[k0 + 64 + lane] : 1.f;
+        for (int e = 0; e < 16; ++e) {
+          Tee[e] += in[e * 64];
+          Toe[e] += in[(16 + e) * 64];
+          Too[e] += in[(32 + e) * 64];
         }
-        fetch(0, my_idx, my_c, 0, cnt);
-        for (int s0 = 0; s0 < cnt; s0 += 4 * KS) {  // two trips per round: the other buffer's gathers fly during the MFMAs
-          if (s0 + 2 * KS < cnt) fetch(1, my_idx, my_c, s0 + 2 * KS, cnt);
-          multiply(0);
-          if (s0 + 2 * KS < cnt) {
-            if (s0 + 4 * KS < cnt) fetch(0, my_idx, my_c, s0 + 4 * KS, cnt);
-            multiply(1);
-          }
-        }
+        be += in[48 * 64];
+        bo += in[49 * 64];
       }
+    } else {
+      chol_syrk_range(indices, data, Y, row_begin, row_end, lane, Tee, Toe, Too, be, bo);
     }
     tick(1);
     // tiles -> lower triangle of the image (C/D layout: col j' = lane & 31, row i' = (e&3) + 8 (e>>2) + 4 h)
@@ -480,28 +534,60 @@ int64_t least_squares_cholesky(const imp_csr *C, imp_matrix *X, const imp_matrix
     // every non-empty row: MFMA A-build + left-looking Cholesky, one wavefront per row
     const size_t lds_m = ((size_t)64 * 68 + 4 * kCholTri) * sizeof(float);  // 52 KB: 3 workgroups per CU
     const int grid = std::min((nonempty + 3) / 4, ctx().num_cus * 3 * ctx().oversub);  // 168 VGPRs, 52 KB LDS: 3 workgroups per CU
+    // long rows: segment partials of the A-build first (see als_cholesky_f64_partial_kernel).  IMP_CHOL_NO_SPLIT=1: every row
+    // walked by its own wavefront (A/B)
+    static const bool no_split = getenv("IMP_CHOL_NO_SPLIT") != nullptr;
+    LongPlanDev plan = C->plan_chol.dev(C->order.data());
+    if (no_split) plan.n_long = 0, plan.n_seg = 0;
+    const float *partials = nullptr;
+    if (plan.n_seg > 0) {
+      auto &ws = ctx().long_ws;
+      const size_t need = (size_t)plan.n_seg * kCholPartial;
+      if (ws.size < need) ws.alloc(need);
+      partials = ws.data();
+      IMP_PROF("als_cholesky_long_partials");
+      const int pgrid = std::min((plan.n_seg + 3) / 4, ctx().num_cus * 8);
+      als_cholesky_f64_partial_kernel<<<pgrid, 256, 0, stream()>>>(plan, C->indices.data(), C->data.data(), Y->f32(), ws.data());
+      IMP_CHECK_HIP(hipGetLastError());
+    }
     static const bool want_stats = getenv("IMP_CHOL_STATS") != nullptr;
     if (want_stats) {  // debug: per-phase tick sums of this launch, printed to stderr
       IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(als_cholesky_f64_kernel<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
       DeviceArray<unsigned long long> st;
       st.alloc(8, true);
+      int occ_stats = 0, occ = 0;
+      IMP_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_stats, als_cholesky_f64_kernel<true>, 256, lds_m));
+      IMP_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, als_cholesky_f64_kernel<false>, 256, lds_m));
+      hipEvent_t e0, e1;
+      IMP_CHECK_HIP(hipEventCreate(&e0));
+      IMP_CHECK_HIP(hipEventCreate(&e1));
+      IMP_CHECK_HIP(hipEventRecord(e0, stream()));
       als_cholesky_f64_kernel<true><<<grid, 256, lds_m, stream()>>>(C->order.data(), 0, nonempty, C->indptr.data(), C->indices.data(),
                                                                     C->data.data(), X->f32(), Y->f32(), YtY->f32(), (float)reg,
-                                                                    g_failed, st.data());
+                                                                    g_failed, st.data(), plan, partials);
+      IMP_CHECK_HIP(hipEventRecord(e1, stream()));
       unsigned long long h[8];
       IMP_CHECK_HIP(hipMemcpyAsync(h, st.data(), sizeof(h), hipMemcpyDeviceToHost, stream()));
       sync();
+      float ms = 0.f;
+      IMP_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+      IMP_CHECK_HIP(hipEventDestroy(e0));
+      IMP_CHECK_HIP(hipEventDestroy(e1));
       const double n = h[7] ? (double)h[7] : 1.0;
-      fprintf(stderr, "[chol-stats] rows=%d cycles/row: SYRK %.0f  image+rows %.0f  factorise %.0f  back-subst %.0f\n", nonempty, h[1] / n,
-              h[2] / n, h[3] / n, h[4] / n);
+      const double ticks = (double)(h[1] + h[2] + h[3] + h[4]);
+      const double slots = (double)std::min(grid, ctx().num_cus * occ_stats) * 4.0;  // resident wavefronts
+      fprintf(stderr,
+              "[chol-stats] rows=%d cycles/row: SYRK %.0f  image+rows %.0f  factorise %.0f  back-subst %.0f | this launch %.2f ms, "
+              "workgroups per CU (occupancy query) %d (instrumented) / %d, ticks per resident wavefront / time = %.2f GHz\n",
+              nonempty, h[1] / n, h[2] / n, h[3] / n, h[4] / n, ms, occ_stats, occ, ticks / slots / (ms * 1e6));
     } else {
       IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(als_cholesky_f64_kernel<false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
       IMP_PROF("als_cholesky_mfma_rows");
       als_cholesky_f64_kernel<false><<<grid, 256, lds_m, stream()>>>(C->order.data(), 0, nonempty, C->indptr.data(), C->indices.data(),
                                                                      C->data.data(), X->f32(), Y->f32(), YtY->f32(), (float)reg,
-                                                                     g_failed, nullptr);
+                                                                     g_failed, nullptr, plan, partials);
       IMP_CHECK_HIP(hipGetLastError());
     }
     zero_rows(C->order.data(), C->first_empty(), C->n_empty(), X->f32(), f);

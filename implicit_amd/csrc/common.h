@@ -202,6 +202,10 @@ struct imp_csr {
   // order[cluster_cut[i] .. cluster_cut[i + 1]).
   static constexpr int kClusterRow = 4096;
   LongPlan plan_all, plan_xl;
+  // rows of more than kCholLongRow nonzeros (the first cluster_cut[2] entries of `order`) cut into plain runs of
+  // kCholSegment: the A-build of the f = 64 Cholesky kernel is segment-parallel for them (als_cholesky.hip)
+  static constexpr int kCholLongRow = 1024, kCholSegment = 1024;
+  LongPlan plan_chol;
   int32_t cluster_cut[4] = {0, 0, 0, 0};
   // A matrix with more than 2^31 - 1 nonzeros (imp_csr_create64) is held as consecutive row blocks, each a complete
   // imp_csr of its own with int32 offsets; the top-level object then only carries rows / cols / nnz and the solver

@@ -533,7 +533,7 @@ int imp_csr_create(int32_t rows, int32_t cols, int64_t nnz, const int32_t *indpt
     if (const char *e = getenv("IMP_STRIPE")) stripe = std::max(0, atoi(e));
     double stripe_reuse = 4.0;  // minimum gathers per column of the gathered matrix for the striped plan
     if (const char *e = getenv("IMP_STRIPE_REUSE")) stripe_reuse = atof(e);
-    auto build_plan = [&](int32_t n_plan, LongPlan &lp, double stripe_reuse) {
+    auto build_plan = [&](int32_t n_plan, LongPlan &lp, double stripe_reuse, int32_t segment) {
       int64_t long_nnz = 0;
       bool sorted = true;
       for (int32_t li = 0; li < n_plan; ++li) {
@@ -619,7 +619,7 @@ int imp_csr_create(int32_t rows, int32_t cols, int64_t nnz, const int32_t *indpt
       lp.seg_begin.upload(seg_begin.data(), seg_begin.size());
       lp.seg_end.upload(seg_end.data(), seg_end.size());
     };
-    build_plan(n_long, m->plan_all, stripe_reuse);
+    build_plan(n_long, m->plan_all, stripe_reuse, segment);
     // rows within reach of the cluster-resident kernels (als_cg_cluster.hip) leave the streamed plan of the f = 64 / 128 path
     for (int i = 0; i < 3; ++i) {
       int32_t longer = 0;  // rows strictly longer than kClusterRow >> i (order is sorted by descending length)
@@ -629,7 +629,9 @@ int imp_csr_create(int32_t rows, int32_t cols, int64_t nnz, const int32_t *indpt
     m->cluster_cut[3] = n_long;
     // the few very long rows that remain streamed re-use the gathered matrix less often, yet their segments stay long
     // enough for the striped plan to pay from 2 gathers per column on (C3 item side: partial kernel 0.36 -> 0.28 ms)
-    build_plan(m->cluster_cut[0], m->plan_xl, std::min(stripe_reuse, 2.0));
+    build_plan(m->cluster_cut[0], m->plan_xl, std::min(stripe_reuse, 2.0), segment);
+    static_assert(imp_csr::kCholLongRow == imp_csr::kClusterRow >> 2, "plan_chol covers order[0 .. cluster_cut[2])");
+    build_plan(m->cluster_cut[2], m->plan_chol, 1e30, imp_csr::kCholSegment);  // never striped
     sync();
     *out = m.release();
   });

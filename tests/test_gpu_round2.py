@@ -186,7 +186,7 @@ print("switch ok")
 
 @pytest.mark.parametrize("switch", ["IMP_SHORT_TEAM1=1", "IMP_SHORT_TEAM1=0", "IMP_STRIPE=0", "IMP_SEGMENT=128",
                                     "IMP_CHOL_NO_MFMA=1", "IMP_CHOL_NO_WAVE=1", "IMP_TOPK_NO_FAST=1", "IMP_NO_CLUSTER=1", "IMP_CLUSTER_SC1=1",
-                                    "IMP_GRAM_NO_VEC=1"])
+                                    "IMP_GRAM_NO_VEC=1", "IMP_CHOL_NO_SPLIT=1"])
 def test_ab_switch_paths_keep_parity(gpu, switch):
     """Every debug / A-B environment switch selects kernels the default run does not take (they are read once per
     process, hence the subprocess): CG both orientations at f = 64 / 128, Cholesky f = 64 and top-k against the oracle."""
@@ -439,3 +439,31 @@ def test_oversubscribed_launches_are_bitwise_identical(gpu, f):
         np.testing.assert_array_equal(results[0], other)
     with pytest.raises(ValueError):
         gpu.set_oversubscribe(0)
+
+
+def test_cholesky_long_rows_are_segment_parallel(gpu, oracle):
+    """f = 64 Cholesky: the A-build of a row with more than 1024 nonzeros is cut into 1024-nnz segments built by separate
+    wavefronts and summed by the row's wavefront (als_cholesky_f64_partial_kernel) -- lengths on both sides of the
+    threshold and of the segment boundaries, negative confidences, against the oracle's Cholesky solve."""
+    rng = np.random.default_rng(21)
+    lens = np.concatenate([[1023, 1024, 1025, 2047, 2048, 2049, 3000, 5000, 9000], rng.integers(1025, 4000, 40),
+                           rng.integers(1, 1024, 400), [0]])
+    rng.shuffle(lens)
+    cols, f = 12_000, 64
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    indices = np.concatenate([np.sort(rng.choice(cols, int(n), replace=False)) for n in lens] + [[]]).astype(np.int32)
+    data = (1.0 + 4.0 * rng.random(len(indices), dtype=np.float32)).astype(np.float32)
+    data[rng.random(len(data)) < 0.03] *= -1
+    C = sp.csr_matrix((data, indices, indptr), shape=(len(lens), cols))
+    Y0 = rng.random((cols, f), dtype=np.float32) * 0.2 - 0.1
+    solver = gpu.LeastSquaresSolver()
+    Yd, gram, Xd = gpu.Matrix(Y0), gpu.Matrix.zeros(f, f), gpu.Matrix.zeros(C.shape[0], f)
+    solver.calculate_yty(Yd, gram, 0.0)
+    solver.least_squares_cholesky(gpu.CSRMatrix(C), Xd, gram, Yd, 0.05)
+    got = Xd.to_numpy()
+    want = np.zeros((C.shape[0], f), dtype=np.float32)
+    oracle.least_squares(C, want, Y0, 0.05)
+    long_rows = np.flatnonzero(lens > 1024)
+    assert max(rel(got[r], want[r]) for r in long_rows) < 2e-4
+    assert rel(got, want) < 1e-4
+    assert not got[lens == 0].any()
