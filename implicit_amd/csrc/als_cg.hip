@@ -170,6 +170,108 @@ __global__ __launch_bounds__(BLOCK, (A_LDS && VPL == 2) ? 4 : 2) void als_cg_ker
   }
 }
 
+// ---- f = 256: one wavefront per row, the gramian shared by the workgroup --------------------------------------------
+// 256 KB of gramian fit no LDS, and read from L2 by every wavefront for every pass they are two thirds of the generic
+// kernel's traffic (a 140-nnz row gathers 140 KB per pass and reads 256 KB of gramian).  Here the 8 wavefronts of a workgroup
+// run the passes of their 8 rows in lock step and stage the gramian through LDS in slices of 32 rows (32 KB): one L2 read
+// per workgroup and pass instead of eight.  Early exits become per-wave predicates (every wave takes every barrier); the
+// arithmetic per row is the generic kernel's, operation for operation.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK, BLOCK / 128) void als_cg_f256_kernel(const int32_t *__restrict__ order, int first, int count,
+                                                                       const int32_t *__restrict__ indptr,
+                                                                       const int32_t *__restrict__ indices,
+                                                                       const float *__restrict__ data, float *__restrict__ X,
+                                                                       const float *__restrict__ Y, const float *__restrict__ A0,
+                                                                       int cg_steps) {
+  constexpr int VPL = 4, F = 256, WAVES = BLOCK / 64, SL = 32;
+  __shared__ __attribute__((aligned(16))) float slice[SL * F];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // acc += A0 vec (factor j of the operand lives in lane j / 4, slot j % 4), all waves together
+  auto dense = [&](const float (&vec)[VPL], float (&acc)[VPL], bool work) {
+    for (int s = 0; s < F / SL; ++s) {
+      __syncthreads();  // the previous slice has been consumed
+      for (int e = threadIdx.x; e < SL * F / 4; e += BLOCK)
+        reinterpret_cast<float4 *>(slice)[e] = reinterpret_cast<const float4 *>(A0 + (size_t)SL * s * F)[e];
+      __syncthreads();
+      if (work) {  // wave-uniform
+#pragma unroll 1
+        for (int jj0 = 0; jj0 < SL; jj0 += 8) {  // 8 rows of the slice in flight (all 32 at once cost 128 registers)
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int jj = jj0 + q;
+            const float pj = lane_bcast(vec[q & 3], (SL / 4) * s + (jj >> 2));
+            const float4 row = reinterpret_cast<const float4 *>(slice + jj * F)[lane];
+            acc[0] = fmaf(pj, row.x, acc[0]);
+            acc[1] = fmaf(pj, row.y, acc[1]);
+            acc[2] = fmaf(pj, row.z, acc[2]);
+            acc[3] = fmaf(pj, row.w, acc[3]);
+          }
+        }
+      }
+    }
+  };
+  for (int i0 = blockIdx.x * WAVES; i0 < count; i0 += gridDim.x * WAVES) {
+    const bool valid = i0 + wave < count;
+    const int u = __builtin_amdgcn_readfirstlane(order[first + min(i0 + wave, count - 1)]);
+    const int row_begin = __builtin_amdgcn_readfirstlane(indptr[u]);
+    const int row_end = __builtin_amdgcn_readfirstlane(indptr[u + 1]);
+    float *xrow = X + (size_t)u * F;
+    float x[VPL], r[VPL], p[VPL], Ap[VPL];
+    load_row<VPL, true>(xrow, F, lane, x);
+    // r = -(A0 x) + sum_k (c+ - (|c|-1) y.x) y        (_als.pyx:187-201)
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) Ap[v] = 0.f;
+    dense(x, Ap, valid);
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) r[v] = -Ap[v];
+    if (valid) sparse_pass<VPL, true, true>(indices, data, Y, F, lane, row_begin, row_end, x, r);
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) p[v] = r[v];
+    float rsold = wave_allsum(dot_local<VPL>(r, r));
+    bool active = valid && rsold >= 1e-20f;  // else: leave x untouched (_als.pyx:206)
+    const bool store = active;
+    for (int it = 0; it < cg_steps; ++it) {
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) Ap[v] = 0.f;
+      dense(p, Ap, active);
+      if (active) {
+        sparse_pass<VPL, true, false>(indices, data, Y, F, lane, row_begin, row_end, p, Ap);
+        float alpha = rsold / wave_allsum(dot_local<VPL>(p, Ap));
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          x[v] = fmaf(alpha, p[v], x[v]);
+          r[v] = fmaf(-alpha, Ap[v], r[v]);
+        }
+        float rsnew = wave_allsum(dot_local<VPL>(r, r));
+        if (rsnew < 1e-20f) {
+          active = false;  // the oracle breaks here (_als.pyx:235)
+        } else {
+          float beta = rsnew / rsold;
+#pragma unroll
+          for (int v = 0; v < VPL; ++v) p[v] = fmaf(beta, p[v], r[v]);
+          rsold = rsnew;
+        }
+      }
+    }
+    if (store) {
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) xrow[elem<VPL, true>(lane, v)] = x[v];
+    }
+  }
+}
+
+static void launch_f256(const imp_csr *C, int first, int count, float *X, const float *Y, const float *A0, int cg_steps,
+                        const char *name) {
+  if (count <= 0) return;
+  constexpr int BLOCK = 512;
+  int grid = std::min((count + BLOCK / 64 - 1) / (BLOCK / 64), ctx().num_cus * 2 * ctx().oversub);
+  IMP_PROF(name);
+  als_cg_f256_kernel<BLOCK><<<grid, BLOCK, 0, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(),
+                                                         C->data.data(), X, Y, A0, cg_steps);
+  IMP_CHECK_HIP(hipGetLastError());
+}
+
 // ---- long rows: every CG pass = segment-parallel partial kernel + per-row combine/update kernel -------------
 // workspace (floats): partial[n_seg][LD] | rvec[n_long][LD] | pvec[n_long][LD] | scal[n_long][2] (rsold, done)
 template <int VPL, bool VEC, bool FIRST>
@@ -544,6 +646,14 @@ static void launch_all(const imp_csr *C, T *X, const T *Y, const float *A0, int 
     least_squares_cg_q<T>(C, X, Y, A0, f, cg_steps);  // quarter-layout register tiles, wave teams (als_cg_q.hip)
   } else if constexpr (std::is_same<T, float>::value) {
     launch_long<VPL, VEC, A_LDS, T>(C, C->plan_all, X, Y, A0, f, cg_steps);
+    if constexpr (VEC && VPL == 4 && !A_LDS) {  // f = 256: workgroup-shared gramian.  IMP_F256_GENERIC=1: the generic kernel (A/B)
+      static const bool generic256 = getenv("IMP_F256_GENERIC") != nullptr;
+      if (!generic256) {
+        launch_f256(C, b[1], b[7] - b[1], X, Y, A0, cg_steps, "als_cg_mid_rows");
+        zero_rows_t<T>(C->order.data(), C->first_empty(), C->n_empty(), X, f);
+        return;
+      }
+    }
     bool resident_ok = false;
     if constexpr (VEC) resident_ok = tile_size<VPL>() >= imp_csr::kShortRow;
     if constexpr (VEC) {
