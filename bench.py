@@ -185,7 +185,23 @@ def cpu_baseline(Cui, Ciu, X0, Y0, seconds):
     }
 
 
+def protect_stdout():
+    """The contract is ONE JSON line on stdout.  librccl prints a version banner to the C-level stdout, which is buffered
+    and surfaces when the process exits -- after the JSON line.  So fd 1 is pointed at stderr for the lifetime of the
+    process (everything any library prints lands there) and the JSON line is written to a private duplicate of the
+    original stdout."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    return saved
+
+
+def emit(saved_stdout, obj):
+    os.write(saved_stdout, (json.dumps(obj) + "\n").encode())
+
+
 def main():
+    saved_stdout = protect_stdout()
     global FACTORS
     args = parse_args()
     FACTORS = args.factors
@@ -228,7 +244,7 @@ def main():
 
         result = sharded.bench(args, gpu, SHAPES, FACTORS, REG, CG_STEPS, rank0_roofline)
         if rank == 0:
-            print(json.dumps(result))
+            emit(saved_stdout, result)
         return
 
     # ---- single GPU ---------------------------------------------------------------------------------
@@ -386,7 +402,7 @@ def main():
             except Exception as e:  # an extra must never cost the headline line
                 out[name + "_error"] = f"{type(e).__name__}: {e}"
             out.setdefault("extras_s", {})[name] = round(time.time() - t0, 1)
-    print(json.dumps(out))
+    emit(saved_stdout, out)
 
 
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
