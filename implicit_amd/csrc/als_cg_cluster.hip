@@ -17,10 +17,13 @@
 // sequence number never repeats within a slot's lifetime.
 //
 // Placement: workgroup b runs on XCD b % 8 (observed; a speed matter only), so the CL members of a cluster are the
-// workgroups x + 8 (CL q + m) -- one XCD, one L2.  Residency: the grid never exceeds the number of workgroups the chip
-// holds at once (2 per CU), blocks are dispatched in index order, and a cluster's members are neighbours in that order, so
-// a complete cluster is always resident; every poll is bounded all the same (a timed-out exchange sets a host-visible
-// fault word and the call raises).
+// workgroups x + 8 (CL q + m) -- one XCD, one L2; the members verify it (XCC id in the tag bits of the first exchange)
+// before they rely on it.  Residency: a cluster's members are neighbours in the dispatch order of their XCD.  With a grid of
+// at most the resident capacity (2 workgroups per CU) every cluster is resident from the start; with an oversubscribed grid
+// (Context::oversub, multi-GPU driver) or with part of the device held by another stream's kernels, the slots a finished
+// cluster frees go to the next cluster as a whole, and a partly resident cluster merely waits for slots that complete
+// clusters keep freeing.  Every poll is bounded all the same (a timed-out exchange sets a host-visible fault word and the
+// call raises).
 #include <type_traits>
 
 #include "als_qtile.h"
