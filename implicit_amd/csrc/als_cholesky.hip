@@ -533,7 +533,9 @@ int64_t least_squares_cholesky(const imp_csr *C, imp_matrix *X, const imp_matrix
   if (nonempty > 0 && f == 64 && !no_mfma && !no_wave) {
     // every non-empty row: MFMA A-build + left-looking Cholesky, one wavefront per row
     const size_t lds_m = ((size_t)64 * 68 + 4 * kCholTri) * sizeof(float);  // 52 KB: 3 workgroups per CU
-    const int grid = std::min((nonempty + 3) / 4, ctx().num_cus * 3 * ctx().oversub);  // 168 VGPRs, 52 KB LDS: 3 workgroups per CU
+    // 159 VGPRs, 52 KB LDS: 3 workgroups per CU resident; 8x that many are launched -- smaller fixed shares of the length-sorted
+    // schedule, dealt by the hardware dispatcher as slots free up, even out the end of the launch (configs[1]: 14.8 -> 13.8 ms)
+    const int grid = std::min((nonempty + 3) / 4, ctx().num_cus * 3 * std::max(8, ctx().oversub));
     // long rows: segment partials of the A-build first (see als_cholesky_f64_partial_kernel).  IMP_CHOL_NO_SPLIT=1: every row
     // walked by its own wavefront (A/B)
     static const bool no_split = getenv("IMP_CHOL_NO_SPLIT") != nullptr;
