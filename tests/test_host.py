@@ -77,3 +77,24 @@ def test_grid_shards_compose_one_matrix_whatever_the_rank_count():
     assert per_shard.max() < 1.3 * per_shard.min()
     with pytest.raises(ValueError):
         grid_shards(0, 3, users, items, nnz, grid)
+
+
+def test_bench_keeps_stdout_for_the_json_line():
+    """bench.py's contract is ONE JSON line on stdout; whatever a library prints at C level (librccl's version banner
+    surfaces at process exit) must land on stderr: fd 1 is re-pointed at stderr and the line goes to a private duplicate
+    of the original stdout (bench.protect_stdout / emit)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import bench, os, sys\n"
+            "saved = bench.protect_stdout()\n"
+            "print('python-level noise')\n"
+            "os.write(1, b'C-level noise\\n')\n"
+            "bench.emit(saved, {'metric': 'x', 'value': 1})\n"
+            "os.write(1, b'late C-level noise\\n')\n")
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout == '{"metric": "x", "value": 1}\n'
+    assert "python-level noise" in out.stderr and "late C-level noise" in out.stderr
