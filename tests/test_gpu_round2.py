@@ -166,6 +166,16 @@ for f in (64, 128):
     if f == 64:
         Xd = gpu.Matrix.zeros(C.shape[0], f)
         solver.calculate_yty(Yd if Yd.shape[0] == C.shape[1] else gpu.Matrix(Y0), gram, 0.0)
+Cw = synthetic_csr(1200, 900, 60_000, seed=8, neg_frac=0.05)          # f = 256: workgroup-shared gramian / generic kernel
+rng = np.random.default_rng(3)
+X0 = rng.random((1200, 256), dtype=np.float32) * 0.2 - 0.1
+Y0 = rng.random((900, 256), dtype=np.float32) * 0.2 - 0.1
+Xd, Yd, gram = gpu.Matrix(X0), gpu.Matrix(Y0), gpu.Matrix.zeros(256, 256)
+solver.calculate_yty(Yd, gram, 0.05)
+solver.least_squares(gpu.CSRMatrix(Cw), Xd, gram, Yd, 3)
+want = X0.copy()
+oracle.least_squares_cg(Cw, want, Y0, 0.05, cg_steps=3, YtY=gram.to_numpy())
+assert rel(Xd.to_numpy(), want) < 1e-4, ("cg f=256", rel(Xd.to_numpy(), want))
 Cc = synthetic_csr(2000, 500, 60_000, seed=3)
 rng = np.random.default_rng(5)
 Y0 = rng.random((500, 64), dtype=np.float32) * 0.2 - 0.1
@@ -186,7 +196,8 @@ print("switch ok")
 
 @pytest.mark.parametrize("switch", ["IMP_SHORT_TEAM1=1", "IMP_SHORT_TEAM1=0", "IMP_STRIPE=0", "IMP_SEGMENT=128",
                                     "IMP_CHOL_NO_MFMA=1", "IMP_CHOL_NO_WAVE=1", "IMP_TOPK_NO_FAST=1", "IMP_NO_CLUSTER=1", "IMP_CLUSTER_SC1=1",
-                                    "IMP_GRAM_NO_VEC=1", "IMP_CHOL_NO_SPLIT=1"])
+                                    "IMP_GRAM_NO_VEC=1", "IMP_CHOL_NO_SPLIT=1", "IMP_TEAM16_CLUSTER=1", "IMP_F256_GENERIC=1",
+                                    "IMP_OVERSUB=3", "IMP_STRIPE_REUSE=1", "IMP_QGROUP_PER_CU=1"])
 def test_ab_switch_paths_keep_parity(gpu, switch):
     """Every debug / A-B environment switch selects kernels the default run does not take (they are read once per
     process, hence the subprocess): CG both orientations at f = 64 / 128, Cholesky f = 64 and top-k against the oracle."""
