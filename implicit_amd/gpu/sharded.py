@@ -253,6 +253,7 @@ def bench(args, gpu, shapes, factors, reg, cg_steps, roofline_fn=None):
     fence()
     gpu.Profiler.enable(False)
     kernels = {name: gpu.Profiler.get(name)[0] for name in gpu.Profiler.names()}
+    compute_ms = float(sum(ms for name, ms in kernels.items() if not name.startswith("rccl")))
     step_s = elapsed / args.steps
     result = {
         "metric": "ALS user+item updates/sec per iteration (factors=128)",
@@ -277,6 +278,12 @@ def bench(args, gpu, shapes, factors, reg, cg_steps, roofline_fn=None):
         "nnz_visits_per_s": 2 * int(total_nnz) / step_s,
         "roofline": roofline_fn(Cui, Ciu, timed, args.steps) if (roofline_fn and rank == 0) else None,
         "kernels_ms_per_step_rank0": kernels,
+        # how the step divides on rank 0: its own kernels (HIP events) against the wall time of the step; the difference is
+        # what the exchange (and launch gaps) left exposed after pipelining
+        "rank0_compute_ms_per_step": compute_ms,
+        "rank0_exposed_exchange_ms_per_step": max(0.0, 1e3 * step_s - compute_ms),
+        "exchange_GB_received_per_rank_per_step": 4.0 * factors * (users_total + items_total) * (world - 1) / world / 1e9,
+        "oversubscription": int(os.environ.get("IMP_SHARD_OVERSUB", "4")) if world > 1 else 1,
         "rank0_shard": {"user_rows": int(Cui.shape[0]), "item_rows": int(Ciu.shape[0]), "user_nnz": int(Cui.nnz),
                         "item_nnz": int(Ciu.nnz)},
         "setup_s": {"generate": t_gen},
