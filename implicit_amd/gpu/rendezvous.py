@@ -6,7 +6,7 @@ region -- goes through the RCCL communicator itself (implicit_amd.gpu.Comm).
 The launcher's environment is the one `python -m torch.distributed.run` / torchrun sets (the bench driver uses
 it): RANK, WORLD_SIZE, LOCAL_RANK, MASTER_ADDR, MASTER_PORT.  MASTER_PORT itself belongs to the launcher's own
 store, so the exchange listens on MASTER_PORT + 1 + IMP_RDZV_PORT_OFFSET (override the absolute port with
-IMP_RDZV_PORT).  No reference counterpart (implicit/gpu/als.cu:169 "TODO: multi-gpu support").
+IMP_RDZV_PORT) or, if that is taken, on one of the 7 ports after it; peers are recognised by a magic handshake.  No reference counterpart (implicit/gpu/als.cu:169 "TODO: multi-gpu support").
 """
 import os
 import socket
@@ -23,12 +23,19 @@ def env_world():
     return rank, world, int(os.environ.get("LOCAL_RANK", str(rank)))
 
 
-def _endpoint():
+_CANDIDATES = 8  # consecutive ports tried when the first choice is taken
+
+
+def _endpoints():
+    """(address, [candidate ports]).  Rank 0 listens on the first candidate it can bind; the others try the candidates in
+    turn and only accept a peer that answers with the protocol's magic, so a port that belongs to somebody else (the
+    launcher's own store sits on MASTER_PORT; anything may sit on MASTER_PORT + 1) is skipped, not trusted."""
     addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
     if "IMP_RDZV_PORT" in os.environ:
-        return addr, int(os.environ["IMP_RDZV_PORT"])
-    port = int(os.environ.get("MASTER_PORT", "29500")) + 1 + int(os.environ.get("IMP_RDZV_PORT_OFFSET", "0"))
-    return addr, 1024 + (port - 1024) % (65536 - 1024)
+        first = int(os.environ["IMP_RDZV_PORT"])
+    else:
+        first = int(os.environ.get("MASTER_PORT", "29500")) + 1 + int(os.environ.get("IMP_RDZV_PORT_OFFSET", "0"))
+    return addr, [1024 + (first + i - 1024) % (65536 - 1024) for i in range(_CANDIDATES)]
 
 
 def _recv_exact(conn, n):
@@ -45,13 +52,23 @@ def broadcast_bytes(payload, rank, world, timeout=300.0):
     """Rank 0 passes `payload` (bytes), the others pass None; every rank returns rank 0's bytes."""
     if world == 1:
         return payload
-    addr, port = _endpoint()
+    addr, ports = _endpoints()
     deadline = time.time() + timeout
     if rank == 0:
-        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-        srv.bind(("", port))
-        srv.listen(world)
+        srv, last = None, None
+        for port in ports:
+            cand = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            cand.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            try:
+                cand.bind(("", port))
+                cand.listen(world)
+                srv = cand
+                break
+            except OSError as e:  # taken: next candidate
+                last = e
+                cand.close()
+        if srv is None:
+            raise OSError(f"rendezvous: none of the ports {ports[0]}..{ports[-1]} could be bound: {last}")
         srv.settimeout(timeout)
         served = set()
         try:
@@ -59,27 +76,34 @@ def broadcast_bytes(payload, rank, world, timeout=300.0):
                 conn, _ = srv.accept()
                 with conn:
                     conn.settimeout(timeout)
-                    hello = _recv_exact(conn, len(_MAGIC) + 4)
+                    try:
+                        hello = _recv_exact(conn, len(_MAGIC) + 4)
+                    except (ConnectionError, OSError):
+                        continue
                     if hello[:len(_MAGIC)] != _MAGIC:
                         continue  # not one of ours
                     peer = struct.unpack("<i", hello[len(_MAGIC):])[0]
-                    conn.sendall(struct.pack("<q", len(payload)) + payload)
+                    conn.sendall(_MAGIC + struct.pack("<q", len(payload)) + payload)
                     served.add(peer)
         finally:
             srv.close()
         return payload
     last = None
     while time.time() < deadline:
-        try:
-            with socket.create_connection((addr, port), timeout=5.0) as conn:
-                conn.settimeout(timeout)
-                conn.sendall(_MAGIC + struct.pack("<i", rank))
-                n = struct.unpack("<q", _recv_exact(conn, 8))[0]
-                return _recv_exact(conn, n)
-        except (ConnectionError, OSError) as e:  # rank 0 is not listening yet
-            last = e
-            time.sleep(0.2)
-    raise TimeoutError(f"rendezvous with rank 0 at {addr}:{port} failed: {last}")
+        for port in ports:
+            try:
+                with socket.create_connection((addr, port), timeout=5.0) as conn:
+                    conn.settimeout(10.0)
+                    conn.sendall(_MAGIC + struct.pack("<i", rank))
+                    if _recv_exact(conn, len(_MAGIC)) != _MAGIC:
+                        continue  # somebody else's service on this port
+                    conn.settimeout(timeout)
+                    n = struct.unpack("<q", _recv_exact(conn, 8))[0]
+                    return _recv_exact(conn, n)
+            except (ConnectionError, OSError) as e:  # nobody there (yet), or a foreign service that does not answer
+                last = e
+        time.sleep(0.2)
+    raise TimeoutError(f"rendezvous with rank 0 at {addr}:{ports[0]}..{ports[-1]} failed: {last}")
 
 
 def init_comm(gpu, rank=None, world=None, local_rank=None):
