@@ -396,19 +396,42 @@ static void launch_qteam(const imp_csr *C, int first, int count, T *X, const T *
   IMP_CHECK_HIP(hipGetLastError());
 }
 
+// als_cg_qf.hip: the team kernels with fused passes and rolling gathers (round 3)
+template <typename T>
+void launch_team_fused(const imp_csr *C, int f, int width, int first, int count, T *X, const T *Y, const float *A0, int cg_steps,
+                       const char *name);
+
 template <int F, typename T> static void run_classes_q(const imp_csr *C, T *X, const T *Y, const float *A0, int cg_steps) {
   const int32_t *b = C->bin_start;  // classes: 1 (256,512]  2 (128,256]  3 (64,128]  4 (32,64]  5 (16,32]  6 (0,16]
-  if (!team16_as_cluster()) launch_qteam<F, 16, 1024, T>(C, b[1], b[2] - b[1], X, Y, A0, cg_steps, "als_cg_team16_rows");
-  launch_qteam<F, 8, 512, T>(C, b[2], b[3] - b[2], X, Y, A0, cg_steps, "als_cg_team8_rows");
-  launch_qteam<F, 4, 512, T>(C, b[3], b[4] - b[3], X, Y, A0, cg_steps, "als_cg_team4_rows");
-  launch_qteam<F, 2, 512, T>(C, b[4], b[5] - b[4], X, Y, A0, cg_steps, "als_cg_team2_rows");
+  // IMP_TEAM_FUSED=0: the round-2 team kernels (dense part, then tile part; gathers at the row start) -- A/B and the
+  // IMP_CG_STATS instrumentation; a bit mask selects the fused kernel per team width (1: 16 waves, 2: 8, 4: 4, 8: 2, 16: 1)
+  static const int fused = getenv("IMP_TEAM_FUSED") ? atoi(getenv("IMP_TEAM_FUSED")) : 31;
+  static const bool want_stats = getenv("IMP_CG_STATS") != nullptr;
+  auto team = [&](int bit, int width, int first, int count, const char *name, auto old) {
+    if ((fused & bit) && !want_stats) launch_team_fused<T>(C, F, width, first, count, X, Y, A0, cg_steps, name);
+    else old(first, count, name);
+  };
+  if (!team16_as_cluster())
+    team(1, 16, b[1], b[2] - b[1], "als_cg_team16_rows",
+         [&](int fr, int n, const char *nm) { launch_qteam<F, 16, 1024, T>(C, fr, n, X, Y, A0, cg_steps, nm); });
+  team(2, 8, b[2], b[3] - b[2], "als_cg_team8_rows",
+       [&](int fr, int n, const char *nm) { launch_qteam<F, 8, 512, T>(C, fr, n, X, Y, A0, cg_steps, nm); });
+  team(4, 4, b[3], b[4] - b[3], "als_cg_team4_rows",
+       [&](int fr, int n, const char *nm) { launch_qteam<F, 4, 512, T>(C, fr, n, X, Y, A0, cg_steps, nm); });
+  team(8, 2, b[4], b[5] - b[4], "als_cg_team2_rows",
+       [&](int fr, int n, const char *nm) { launch_qteam<F, 2, 512, T>(C, fr, n, X, Y, A0, cg_steps, nm); });
   // short rows.  f = 128: 16 rows per workgroup in lock step with the gramian product on fp32 MFMA (measured 1.16 ms per
   // C3 iteration against 1.38 ms for independent waves with the VALU product -- at f = 128 the product is 57 % of a short
   // row's arithmetic); f = 64: independent waves win (C2: 0.84 against 0.94 ms), the product is a quarter of the size
   // and the lock step costs more than the matrix pipe saves.  IMP_SHORT_TEAM1=0/1 forces one or the other (A/B).
   static const int short_team1 = getenv("IMP_SHORT_TEAM1") ? atoi(getenv("IMP_SHORT_TEAM1")) : -1;
   const bool team1 = short_team1 >= 0 ? short_team1 != 0 : F == 64;
-  if (team1) launch_qteam<F, 1, 512, T>(C, b[5], b[7] - b[5], X, Y, A0, cg_steps, "als_cg_short_rows");
+  if (team1) {
+    if constexpr (F == 64)
+      team(16, 1, b[5], b[7] - b[5], "als_cg_short_rows",
+           [&](int fr, int n, const char *nm) { launch_qteam<F, 1, 512, T>(C, fr, n, X, Y, A0, cg_steps, nm); });
+    else launch_qteam<F, 1, 512, T>(C, b[5], b[7] - b[5], X, Y, A0, cg_steps, "als_cg_short_rows");
+  }
   else launch_qgroup<F, T>(C, b[5], b[7] - b[5], X, Y, A0, cg_steps, "als_cg_short_rows");  // tile steps beyond cnt are skipped
 }
 
