@@ -1,20 +1,33 @@
-// K1f: the mid-row CG half sweep (a team of WPR wavefronts per row, whole row resident; als_cg_q.hip has the design) with the
-// passes re-scheduled around their two latencies -- round 3.
+// K1f: the mid-row CG half sweep (a team of WPR wavefronts per row, whole row resident in registers; als_cg_q.hip has the
+// tile design) rebuilt around the resource that actually bounds it -- round 3.
 //
-// Arithmetic contract: the oracle's CG (implicit/cpu/_als.pyx:152-248).  What changes against als_cg_qteam_kernel is the
-// ORDER of work inside a wavefront, not the work:
+// Arithmetic contract: the oracle's CG (implicit/cpu/_als.pyx:152-248).
 //
-//   * fused pass.  A pass adds two independent things into the same expanded accumulators: the dense part (this wave's
-//     gramian rows times the operand, LDS reads) and the tile part (dots and axpys over the resident entries, registers
-//     only).  Run one after the other, the dense part was a chain of dependent LDS round trips (the register file is full,
-//     so only a few reads can be in flight: 20 round trips per pass at two waves per row, 2.2 K of a pass's 7 K cycles) during
-//     which the wave issued nothing.  Here the gramian rows of a pass are dealt to 16 "ticks", and every tick's reads are
-//     issued BEFORE a tile half-step (the dots or the axpys of one entry per group) and consumed AFTER it: the LDS latency hides under the wave's own vector work.
-//   * rolling gather.  The last pass of a row frees the tile registers pair by pair; the gathers of the NEXT row's entries
-//     are issued into a pair as soon as its last axpy is done, so the rest of the pass, the team combine, the CG update and
-//     the store run under the next row's gather latency (it used to be exposed at every row start: 27 % of a wave's time).
-//     Row metadata therefore runs one row deeper (ids 4 rows ahead, nnz ranges 3, entries 2).
-//   * the first pass accumulates (A0 x - sum w y) and negates once in compact form.
+// What bounds these kernels (profiles/micro/valu_rate.hip, profiles/r03_micro_valu_rate.txt): a SIMD of this part retires
+// one vector instruction per ~3.1 ns whatever its kind (v_fma_f32, v_pk_fma_f32, DPP adds alike: 0.32 G wave-instructions
+// per second and SIMD, 330 G/s for the chip), and the round-2 team kernels executed 1.03 G of them per C3 iteration for the
+// mid-row classes -- 3.1 ms of pure issue time against the 3.3 ms measured.  They were instruction-issue bound at 100 %,
+// not at the 50 % round 2 derived from a 4-cycle issue model; hiding latencies (fused passes, rolling gathers: built first,
+// kept below) therefore changed nothing by itself.  Only ~55 % of those instructions were the FMAs of the dense part and
+// of the tile; the rest was per-wavefront bookkeeping, REPLICATED in every wavefront of a team:
+//   - the CG scalars (two wave-wide dot reductions, two IEEE divisions, the x / r / p updates) -- every wave of a team
+//     did the identical arithmetic on identical bits;
+//   - the operand's expansion from the compact to the quarter layout (6 v_permlane swaps + 12 register copies per pass)
+//     and the sum of the team's partial vectors in every wave.
+// This kernel gives that work to ONE wavefront per team (the leader, sub == 0) and turns the rest into LDS traffic, which
+// has issue slots of its own:
+//   * the leader alone sums the team's partial vectors, does the CG update and PUBLISHES the next operand in LDS (natural
+//     factor order) together with a go / last / stop word; the other waves wait on the team's generation counter (an idle
+//     wave costs no issue slots -- that is the point) and read the operand back already expanded: two ds_read_b128 per
+//     lane, no swaps.  Two counters per team (arrivals A, generation B), no workgroup barrier after the prologue;
+//   * a / b by v_rcp_f32 (1 ulp) instead of the 12-instruction IEEE sequence; the last CG step only updates x;
+//   * the dots of a pair of tile steps are reduced together (5 DPP adds for two values instead of 8) and the weight is
+//     applied straight from the lane that holds the total (row_newbcast operand of the multiply);
+//   * per-entry weights |c| - 1 and c+ live in an LDS table written once per row (gather_pair).
+// Kept from the first round-3 version: fused passes (the gramian rows of a pass are dealt to 16 ticks whose LDS reads are
+// issued before a tile half-step and consumed after it) and the rolling gather (the last pass of a row re-fills each pair
+// of tile registers with the next row's entries as soon as the pair is done; metadata runs ids 4 rows ahead, nnz ranges
+// 3, entries 2).
 #include <type_traits>
 
 #include "als_qtile.h"
@@ -30,6 +43,10 @@ __device__ __forceinline__ int opaque(int v) {
   return v;
 }
 
+// explicit packed math: pairs of adjacent expanded slots travel as one 64-bit register pair (v_pk_fma_f32); left to the
+// SLP vectoriser the dots came out as scalar v_fmac chains once the operand arrived by ds_read_b128
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 template <int I> using idx_t = std::integral_constant<int, I>;
 template <int N, typename Fn, int... Is> __device__ __forceinline__ void static_for_impl(Fn &&fn, std::integer_sequence<int, Is...>) {
   (fn(idx_t<Is>{}), ...);
@@ -38,30 +55,34 @@ template <int N, typename Fn> __device__ __forceinline__ void static_for(Fn &&fn
   static_for_impl<N>(fn, std::make_integer_sequence<int, N>{});
 }
 
-// The gramian rows of one wave and pass (NJ steps of 4 rows, one per 16-lane group) dealt to 16 ticks, four per pair of tile
-// steps; one step = FE/4 ds_read_b128 + one ds_read_b32 in flight per tick (9 registers at f = 128).
+// The gramian rows of one wave and pass dealt to 16 ticks, four per pair of tile steps.  The wave's F / WPR rows are cut
+// into four runs of NJ consecutive rows, one per 16-lane group: step s of group g is row j_begin + g NJ + s, so a group's
+// operand entries p_j are consecutive and travel two at a time (ds_read_b64 costs the LDS the same two cycles as a b32).
+// One step = FE/4 ds_read_b128 in flight per tick (8 registers at f = 128) + the operand pair.
 template <int F, int NJ> struct DenseTicks {
   static constexpr int FE = F / 16, Q4 = FE / 4;
   static constexpr int EVERY = 16 / NJ;  // ticks K with K % EVERY == 0 carry one step
   static_assert(NJ == 16 || NJ == 8 || NJ == 4 || NJ == 2 || NJ == 1, "steps per pass");
   float4 a[Q4];
-  float vj;
+  f32x2 vj2;
   template <int K> __device__ __forceinline__ void issue(const float *row, const float *vp) {
     if constexpr (K % EVERY == 0) {
       constexpr int s = K / EVERY;
-      vj = vp[4 * s];
+      if constexpr (NJ == 1) vj2 = f32x2{vp[0], 0.f};
+      else if constexpr (s % 2 == 0) vj2 = *reinterpret_cast<const f32x2 *>(vp + s);
 #pragma unroll
-      for (int e = 0; e < Q4; ++e) a[e] = *reinterpret_cast<const float4 *>(row + (size_t)4 * s * F + 64 * e);
+      for (int e = 0; e < Q4; ++e) a[e] = *reinterpret_cast<const float4 *>(row + (size_t)s * F + 64 * e);
     }
   }
-  template <int K> __device__ __forceinline__ void consume(float (&ae)[FE]) {
+  template <int K> __device__ __forceinline__ void consume(f32x2 (&ae)[FE / 2]) {
     if constexpr (K % EVERY == 0) {
+      constexpr int s = K / EVERY;
+      const float vj = (s % 2 == 0) ? vj2.x : vj2.y;
+      const f32x2 v2 = {vj, vj};
 #pragma unroll
       for (int e = 0; e < Q4; ++e) {
-        ae[4 * e] = fmaf(vj, a[e].x, ae[4 * e]);
-        ae[4 * e + 1] = fmaf(vj, a[e].y, ae[4 * e + 1]);
-        ae[4 * e + 2] = fmaf(vj, a[e].z, ae[4 * e + 2]);
-        ae[4 * e + 3] = fmaf(vj, a[e].w, ae[4 * e + 3]);
+        ae[2 * e] = __builtin_elementwise_fma(v2, f32x2{a[e].x, a[e].y}, ae[2 * e]);
+        ae[2 * e + 1] = __builtin_elementwise_fma(v2, f32x2{a[e].z, a[e].w}, ae[2 * e + 1]);
       }
     }
   }
@@ -73,7 +94,7 @@ template <int F, int NJ> struct DenseTicks {
 // ONCE to a wave-private LDS table by the lanes that hold the entries (cw[t] = |c| - 1, cw[32 + t] = c+) and read back
 // per step as a group-wide broadcast: 8 registers less than carrying them, and no per-pass abs / max.
 template <int F, int P, typename ST>
-__device__ __forceinline__ void gather_pair(float (&y)[8][F / 16], float *cw, int col_reg, float c_reg, int cnt,
+__device__ __forceinline__ void gather_pair(f32x2 (&y)[8][F / 32], float *cw, int col_reg, float c_reg, int cnt,
                                             const ST *__restrict__ Y, int lane) {
   constexpr int FE = F / 16;
   lane = opaque(lane);
@@ -90,23 +111,40 @@ __device__ __forceinline__ void gather_pair(float (&y)[8][F / 16], float *cw, in
 #pragma unroll
     for (int e = 0; e < FE; e += 4) {
       const float4 v = load4(p + 16 * e);
-      y[q][e] = v.x, y[q][e + 1] = v.y, y[q][e + 2] = v.z, y[q][e + 3] = v.w;
+      y[q][e / 2] = f32x2{v.x, v.y}, y[q][e / 2 + 1] = f32x2{v.z, v.w};
     }
   }
 }
 
-// One pass over this wave's share of a row: acc (compact) = [its gramian rows] . v  +  [its tile entries] weights.
-//   FIRST: v = x, weights c+ - (|c|-1) y.x, the dense part enters negated (_als.pyx:187-201)
+// the dots of two tile steps, reduced over the 16 lanes of each group TOGETHER: after the first level the lower half-row
+// carries d0's pair sums and the upper half d1's, the remaining three levels (half-row mirror, quad xor 1, quad xor 2: all
+// inside a half-row) then serve both.  Lanes 0-7 of every row end with the total of d0, lanes 8-15 with the total of d1.
+__device__ __forceinline__ float reduce_pair(float d0, float d1) {
+  float u = d1 + dpp_mov<0x128>(d1);  // row_ror:8
+  const float s0 = d0 + dpp_mov<0x128>(d0);
+  u = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, u), __builtin_bit_cast(int, s0), 0xE4, 0xF, 0x3,
+                                                            false));  // quad_perm:[0,1,2,3] into banks 0, 1 = lanes 0-7
+  u += dpp_mov<0x141>(u);  // row_half_mirror
+  u += dpp_mov<0xB1>(u);   // quad_perm:[1,0,3,2]
+  u += dpp_mov<0x4E>(u);   // quad_perm:[2,3,0,1]
+  return u;
+}
+template <int LANE> __device__ __forceinline__ float row_bcast_from(float v) {  // row_newbcast:LANE (gfx90a+)
+  return dpp_mov<0x150 + LANE>(v);
+}
+
+// One pass over this wave's share of a row: acc (compact) = [its gramian rows] . v  +  [its tile entries] weights, v being
+// the operand the team's leader published in LDS (`vt`, natural factor order).
+//   FIRST: v = x, weights c+ - (|c|-1) y.x, the dense part enters negated (_als.pyx:187-201): the pass accumulates
+//          A0 x - sum w y and the caller takes the sum of the team's partials with a minus sign
 //   else : weights (|c|-1) y.v (_als.pyx:214-222)
 //   LAST : the tile registers (and weight-table slots) of pair P are re-filled with the next row's entries once the pair is done
 template <int F, int NJ, bool FIRST, bool LAST, typename ST>
-__device__ __forceinline__ void fused_pass(float (&y)[8][F / 16], float *cw, int cnt, const float (&v)[F / 64],
-                                           float (&acc)[F / 64], const float *row, const float *vp, float *myvec, int lane,
-                                           int cnt_nx, int &col_nx, float &c_nx, const ST *__restrict__ Y,
-                                           const ST *__restrict__ x_next_row, float (&xn)[F / 64],
-                                           const int32_t *__restrict__ indices, const float *__restrict__ data, int k0_nx2,
-                                           int end_nx2) {
-  constexpr int FE = F / 16, FC = F / 64;
+__device__ __forceinline__ void fused_pass(f32x2 (&y)[8][F / 32], float *cw, int cnt, const float *vt, int j_begin,
+                                           const float *A0s, float (&acc)[F / 64], int lane, int cnt_nx, int &col_nx,
+                                           float &c_nx, const ST *__restrict__ Y, const int32_t *__restrict__ indices,
+                                           const float *__restrict__ data, int k0_nx2, int end_nx2) {
+  constexpr int FE = F / 16, H = FE / 2;
   if constexpr (LAST) {
     // The staged entries were requested a row ago.  Passing them through an opaque copy makes the compiler wait for them
     // HERE, once, while nothing else is in flight; without it every use inside the pass would wait for "all loads so far"
@@ -115,30 +153,33 @@ __device__ __forceinline__ void fused_pass(float (&y)[8][F / 16], float *cw, int
     col_nx = opaque(col_nx);
     c_nx = __int_as_float(opaque(__float_as_int(c_nx)));
   }
+  f32x2 ve[H], ae[H];
+  const float *row, *vp, *cwg;
   {
     const int ln = opaque(lane);
+    const int g = ln >> 4, m = ln & 15;
 #pragma unroll
-    for (int cc = 0; cc < FC; ++cc) myvec[QL<F>::cfactor(ln, cc)] = v[cc];  // wave-private copy for the p_j reads: no barrier
-  }
-  float ve[FE], ae[FE];
-  expand_vector<F>(v, ve);
-#pragma unroll
-  for (int e = 0; e < FE; ++e) ae[e] = 0.f;
-  DenseTicks<F, NJ> dt;
-  auto partial = [&](int q) {
-    float lo = 0.f, hi = 0.f;
-#pragma unroll
-    for (int e = 0; e < FE; e += 2) {
-      lo = fmaf(y[q][e], ve[e], lo);
-      hi = fmaf(y[q][e + 1], ve[e + 1], hi);
+    for (int e = 0; e < FE; e += 4) {  // the operand, expanded: slot e of lane (g, m) is factor 64 (e / 4) + 4 m + (e & 3)
+      const float4 t = *reinterpret_cast<const float4 *>(vt + 16 * e + 4 * m);
+      ve[e / 2] = f32x2{t.x, t.y}, ve[e / 2 + 1] = f32x2{t.z, t.w};
     }
-    return lo + hi;
-  };
-  const float *cwg = cw + (opaque(lane) >> 4);  // this group's entries: t = 4 q + g
-  auto axpy = [&](int q, float d, float cm1, float cp) {
-    const float w = FIRST ? fmaf(cm1, d, -cp) : cm1 * d;  // the whole first pass is accumulated negated
+    vp = vt + j_begin + g * NJ;
+    row = A0s + (size_t)(j_begin + g * NJ) * F + 4 * m;
+    cwg = cw + g;  // this group's entries: t = 4 q + g
+  }
 #pragma unroll
-    for (int e = 0; e < FE; ++e) ae[e] = fmaf(w, y[q][e], ae[e]);
+  for (int h = 0; h < H; ++h) ae[h] = f32x2{0.f, 0.f};
+  DenseTicks<F, NJ> dt;
+  auto partial = [&](int q) {  // this lane's share of y_q . v: even / odd slots in the two halves of one packed accumulator
+    f32x2 s = y[q][0] * ve[0];
+#pragma unroll
+    for (int h = 1; h < H; ++h) s = __builtin_elementwise_fma(y[q][h], ve[h], s);
+    return s.x + s.y;
+  };
+  auto axpy = [&](int q, float w) {
+    const f32x2 w2 = {w, w};
+#pragma unroll
+    for (int h = 0; h < H; ++h) ae[h] = __builtin_elementwise_fma(w2, y[q][h], ae[h]);
   };
   static_for<4>([&](auto Pc) {
     constexpr int P = decltype(Pc)::value;
@@ -148,29 +189,33 @@ __device__ __forceinline__ void fused_pass(float (&y)[8][F / 16], float *cw, int
       float cp_0 = 0.f, cp_1 = 0.f;
       if constexpr (FIRST) cp_0 = cwg[32 + 8 * P], cp_1 = cwg[32 + 8 * P + 4];
       __builtin_amdgcn_sched_barrier(0);
-      float d0 = partial(2 * P);
+      const float d0 = partial(2 * P);
       __builtin_amdgcn_sched_barrier(0);
       dt.template consume<4 * P>(ae);
       dt.template issue<4 * P + 1>(row, vp);
       __builtin_amdgcn_sched_barrier(0);
-      float d1 = partial(2 * P + 1);
-      d0 += dpp_mov<0x128>(d0), d1 += dpp_mov<0x128>(d1);  // row_ror:8
-      d0 += dpp_mov<0x124>(d0), d1 += dpp_mov<0x124>(d1);  // row_ror:4
-      d0 += dpp_mov<0x122>(d0), d1 += dpp_mov<0x122>(d1);  // row_ror:2
-      d0 += dpp_mov<0x121>(d0), d1 += dpp_mov<0x121>(d1);  // row_ror:1
-      __builtin_amdgcn_sched_barrier(0);
+      const float d1 = partial(2 * P + 1);
+      // no fence between the reduction and the packed FMAs of the tick: they fill the wait states of its dependent DPP chain
+      const float u = reduce_pair(d0, d1);
       dt.template consume<4 * P + 1>(ae);
+      // the whole first pass is accumulated negated: w' = (|c|-1) d - c+
+      const float w0 = FIRST ? fmaf(cm1_0, row_bcast_from<0>(u), -cp_0) : cm1_0 * row_bcast_from<0>(u);
+      const float w1 = FIRST ? fmaf(cm1_1, row_bcast_from<8>(u), -cp_1) : cm1_1 * row_bcast_from<8>(u);
+      __builtin_amdgcn_sched_barrier(0);
       dt.template issue<4 * P + 2>(row, vp);
       __builtin_amdgcn_sched_barrier(0);
-      axpy(2 * P, d0, cm1_0, cp_0);
+      axpy(2 * P, w0);
       __builtin_amdgcn_sched_barrier(0);
       dt.template consume<4 * P + 2>(ae);
       dt.template issue<4 * P + 3>(row, vp);
       __builtin_amdgcn_sched_barrier(0);
-      axpy(2 * P + 1, d1, cm1_1, cp_1);
+      axpy(2 * P + 1, w1);
       __builtin_amdgcn_sched_barrier(0);
       dt.template consume<4 * P + 3>(ae);
     } else {  // no entries left: the remaining gramian rows
+      // (the empty statement keeps the two branches from starting alike: the compiler otherwise hoists "read, wait,
+      // consume" of the first tick above the branch and the tick's LDS latency is exposed again)
+      asm volatile("" ::: "memory");
       static_for<4>([&](auto Kc) {
         constexpr int K = 4 * P + decltype(Kc)::value;
         dt.template issue<K>(row, vp);
@@ -183,18 +228,19 @@ __device__ __forceinline__ void fused_pass(float (&y)[8][F / 16], float *cw, int
     }
     __builtin_amdgcn_sched_barrier(0);
   });
-  reduce_expanded<F>(ae, acc);
-  if constexpr (LAST) {
-    // the staged entries are used up: stage those of the row after the next, THEN request the next row's iterate -- loads
-    // complete in order, and the iterate is the first thing the next row waits for
-    fetch_entries(indices, data, opaque(lane), k0_nx2, end_nx2, col_nx, c_nx);
-    load_compact<F>(x_next_row, opaque(lane), xn);
-  }
-  if constexpr (FIRST) {
+  float aes[FE];
 #pragma unroll
-    for (int cc = 0; cc < FC; ++cc) acc[cc] = -acc[cc];
+  for (int h = 0; h < H; ++h) aes[2 * h] = ae[h].x, aes[2 * h + 1] = ae[h].y;
+  reduce_expanded<F>(aes, acc);
+  if constexpr (LAST) {
+    // the staged entries are used up: stage those of the row after the next (loads complete in order: before the leader's
+    // request for the next row's iterate, which is the first thing the next row waits for)
+    fetch_entries(indices, data, opaque(lane), k0_nx2, end_nx2, col_nx, c_nx);
   }
 }
+
+// control word the leader publishes with every operand
+enum : unsigned { kGo = 1u, kLast = 2u };
 
 template <int F, int WPR, int BLOCK, typename ST>
 __global__ __launch_bounds__(BLOCK, 4) void als_cg_qfteam_kernel(const int32_t *__restrict__ order, int first, int count,
@@ -207,57 +253,103 @@ __global__ __launch_bounds__(BLOCK, 4) void als_cg_qfteam_kernel(const int32_t *
   constexpr bool ROLL = std::is_same<ST, float>::value;  // fp16 storage converts at the load: no rolling gather
   static_assert(WPR <= WAVES && (F / WPR) % 4 == 0, "team width");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *A0s = smem;                              // [F][F]
-  float *scratch = A0s + (size_t)F * F;           // [2][WAVES][F]  partial vectors of the combine, double-buffered
-  float *vecs = scratch + (size_t)2 * WAVES * F;  // [WAVES][F]  wave-private copy of the operand vector (natural order)
-  float *cws = vecs + (size_t)WAVES * F;          // [WAVES][64]  per-entry weights |c| - 1 and c+ of the resident tile (gather_pair)
-  unsigned *arrivals = reinterpret_cast<unsigned *>(cws + (size_t)WAVES * 64);  // [TEAMS] monotonic team-barrier counters
+  float *A0s = smem;                            // [F][F]
+  float *parts = A0s + (size_t)F * F;           // [WAVES][F]  partial vectors of the waves (compact slots at their natural index)
+  float *vts = parts + (size_t)WAVES * F;       // [TEAMS][F]  the operand the leader published (natural factor order)
+  float *cws = vts + (size_t)TEAMS * F;         // [WAVES][64]  per-entry weights |c| - 1 and c+ of the resident tile (gather_pair)
+  unsigned *ctl = reinterpret_cast<unsigned *>(cws + (size_t)WAVES * 64);  // [TEAMS][4]  arrivals A, generation B, control words
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int team = wave / WPR, sub = wave % WPR;
+  const bool leader = sub == 0;
   for (int e = threadIdx.x; e < F * F; e += BLOCK) A0s[e] = A0[e];
-  if (threadIdx.x < TEAMS) arrivals[threadIdx.x] = 0u;
+  if (threadIdx.x < 4 * TEAMS) ctl[threadIdx.x] = 0u;
   __syncthreads();  // the only workgroup-wide barrier: from here on the teams run their rows independently
   const int j_begin = F * sub / WPR;
-  float *myvec = vecs + (size_t)wave * F;
+  float *vt = vts + (size_t)team * F;
   float *cw = cws + (size_t)wave * 64;
+  unsigned *arrivals = ctl + 4 * team, *generation = arrivals + 1, *words = arrivals + 2;
 
-  unsigned arrive_target = 0;
-  auto team_sync = [&]() {  // als_cg_q.hip: a team meets on a monotonic LDS counter, teams stay independent
-    if constexpr (WPR == WAVES) {
-      __syncthreads();
+  // ---- team protocol ---------------------------------------------------------------------------------------------------
+  // worker (every wave, the leader included): wait for generation g -> read word + operand -> pass -> partial to LDS -> arrive
+  // leader: wait for WPR arrivals -> sum the partials in wave order -> CG update -> operand + word to LDS -> generation + 1
+  // Both counters are monotonic; a wave's LDS operations execute in order, so a partial is in place before its arrival is
+  // counted and an operand before its generation is.  The operand slot and the partial slots are single-buffered: the
+  // leader overwrites the operand only after all WPR arrivals of the pass that read it, and a wave overwrites its partial
+  // only after the next generation, which the leader publishes after having summed it.  The control word has two slots
+  // (generation parity): a "stop" generation expects no arrivals, so the leader may publish the next row's first generation
+  // before a slow wave has read the stop word -- but never a second one, which needs that wave's arrival.
+  unsigned gen = 0, pub = 0, arr_target = 0;
+  // LDS byte offsets (the low half of a flat LDS address is the offset inside the workgroup's allocation)
+  auto lds_off = [](const void *ptr) { return (unsigned)(size_t)ptr; };
+  const unsigned arrivals_off = lds_off(arrivals), generation_off = lds_off(generation), words_off = lds_off(words);
+  // the one lane-derived value that stays in a register for the whole kernel: byte offset of this lane's compact slots
+  // inside a natural-order vector (the other lane-derived addresses are rebuilt where they are used)
+  const unsigned cf4 = 4u * (unsigned)QL<F>::cfactor(lane, 0);
+  // The counters are bumped with a bare ds_add_u32 from lane 0: the LDS executes a wave's operations in order, so the
+  // partial vector / operand written just before is in place when the counter moves -- no release fence (s_waitcnt), and
+  // none of the lane-counting code the compiler wraps around an atomic add inside a divergent branch.
+  auto publish = [&](unsigned w) {  // leader
+    ++pub;
+    if (lane == 0)
+      asm volatile("ds_write_b32 %0, %1\n\tds_add_u32 %2, %3" ::"v"(words_off + 4u * (pub & 1u)), "v"(w), "v"(generation_off), "v"(1u)
+                   : "memory");
+  };
+  auto poll = [&](unsigned off) {  // one ds_read_b32 of a counter, made wave-uniform
+    typedef __attribute__((address_space(3))) volatile unsigned lds_word;
+    return (unsigned)__builtin_amdgcn_readfirstlane(*(lds_word *)(size_t)off);
+  };
+  auto await_operand = [&]() -> unsigned {  // every wave; returns the control word
+    ++gen;
+    if constexpr (WPR > 1) {
+      // every poll costs two vector-issue slots (address + readfirstlane): the first nap covers most of the leader's update
+      if (poll(generation_off) < gen) {
+        __builtin_amdgcn_s_sleep(6);
+        while (poll(generation_off) < gen) __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    return poll(words_off + 4u * (gen & 1u));
+  };
+  auto arrive = [&](const float (&acc)[FC]) {  // every wave: partial vector to LDS, then count the arrival
+    float *slot = reinterpret_cast<float *>(reinterpret_cast<char *>(parts + (size_t)wave * F) + cf4);
+    if constexpr (FC == 2) *reinterpret_cast<float2 *>(slot) = make_float2(acc[0], acc[1]);
+    else slot[0] = acc[0];
+    if constexpr (WPR > 1) {
+      if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(arrivals_off), "v"(1u) : "memory");
+    }
+  };
+  auto collect = [&](float (&acc)[FC]) {  // leader: wait for the team, sum its partials in wave order
+    arr_target += WPR;
+    if constexpr (WPR > 1) {
+      while (poll(arrivals_off) < arr_target) __builtin_amdgcn_s_sleep(1);
+    }
+    const float *slot = reinterpret_cast<const float *>(reinterpret_cast<const char *>(parts + (size_t)(team * WPR) * F) + cf4);
+#pragma unroll
+    for (int c = 0; c < FC; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int w = 0; w < WPR; ++w) {
+      if constexpr (FC == 2) {
+        const float2 t = *reinterpret_cast<const float2 *>(slot + (size_t)w * F);
+        acc[0] += t.x, acc[1] += t.y;
+      } else {
+        acc[0] += slot[(size_t)w * F];
+      }
+    }
+  };
+  auto operand_slot = [&]() { return reinterpret_cast<float *>(reinterpret_cast<char *>(vt) + cf4); };
+  auto put_operand = [&](const float (&v)[FC]) {  // leader: compact -> natural order in the team's operand slot
+    float *slot = operand_slot();
+    if constexpr (FC == 2) *reinterpret_cast<float2 *>(slot) = make_float2(v[0], v[1]);
+    else slot[0] = v[0];
+  };
+  auto get_operand = [&](float (&v)[FC]) {  // leader: the operand is still in its slot -- no registers across the pass
+    const float *slot = operand_slot();
+    if constexpr (FC == 2) {
+      const float2 t = *reinterpret_cast<const float2 *>(slot);
+      v[0] = t.x, v[1] = t.y;
     } else {
-      arrive_target += WPR;
-      if (lane == 0) __hip_atomic_fetch_add(&arrivals[team], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      while (__builtin_amdgcn_readfirstlane(
-                 __hip_atomic_load(&arrivals[team], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < arrive_target)
-        __builtin_amdgcn_s_sleep(1);
+      v[0] = slot[0];
     }
-  };
-  int parity = 0;
-  auto combine = [&](float (&acc)[FC]) {  // sum of the team's WPR partial vectors in a fixed order (als_cg_q.hip)
-    if constexpr (WPR == 1) return;
-    const int ln = opaque(lane);
-    float *buf = scratch + (size_t)parity * WAVES * F;
-    parity ^= 1;
-#pragma unroll
-    for (int c = 0; c < FC; ++c) buf[wave * F + QL<F>::cfactor(ln, c)] = acc[c];
-    team_sync();
-#pragma unroll
-    for (int c = 0; c < FC; ++c) {
-      float s = 0.f;
-#pragma unroll
-      for (int w = 0; w < WPR; ++w) s += buf[(team * WPR + w) * F + QL<F>::cfactor(ln, c)];
-      acc[c] = s;
-    }
-  };
-  // LDS addresses of the dense part, re-derived per pass
-  auto dense_ptrs = [&](const float *&row, const float *&vp, float *&mv) {
-    const int ln = opaque(lane);
-    const int g = ln >> 4;
-    vp = myvec + j_begin + g;
-    row = A0s + (size_t)(j_begin + g) * F + 4 * (ln & 15);
-    mv = myvec;
   };
 
   // this team's rows: i = (blockIdx.x + k gridDim.x) TEAMS + team; rows past the end re-read the last row
@@ -277,12 +369,20 @@ __global__ __launch_bounds__(BLOCK, 4) void als_cg_qfteam_kernel(const int32_t *
   float ent_c;
   slice(b0, e0, k0, ent_cnt);
   fetch_entries(indices, data, opaque(lane), k0, max(k0 + ent_cnt, b0 + 1), ent_col, ent_c);
-  bool tile_ready = false;  // the tile and the iterate of the row at the top of the loop body are already on their way
+  // x is only meaningful between a load and the top of the next row; every other path overwrites it, so that the compiler
+  // does not carry (and spill) the old value across the passes
+  auto kill = [](float (&v)[FC]) {
+#pragma unroll
+    for (int cc = 0; cc < FC; ++cc) v[cc] = 0.f;
+  };
+  bool tile_ready = false;  // the tile (and, in the leader, the iterate) of the row at the top of the body are on their way
   int cnt = 0;
-  float y[8][FE], x[FC];
+  f32x2 y[8][FE / 2];
+  float x[FC];  // x: the leader's loop-carried iterate registers (the last step loads the NEXT row's into them)
+#pragma unroll
+  for (int cc = 0; cc < FC; ++cc) x[cc] = 0.f;
   for (int i = i_first; i < count; i += i_step) {
     ST *xrow = X + (size_t)id0 * F;
-    float r[FC], p[FC], Ap[FC];
     if (!tile_ready) {  // first row of the wave, or the previous row ended before its last pass: plain row start
       cnt = ent_cnt;
       ent_col = opaque(ent_col);  // one wait for the staged entries, before the gathers (see fused_pass)
@@ -293,68 +393,101 @@ __global__ __launch_bounds__(BLOCK, 4) void als_cg_qfteam_kernel(const int32_t *
       });
       slice(b1, e1, k0, ent_cnt);
       fetch_entries(indices, data, opaque(lane), k0, max(k0 + ent_cnt, b1 + 1), ent_col, ent_c);
-      load_compact<F>(xrow, opaque(lane), x);  // last: loads complete in order and the first pass starts with x
+      if (leader) load_compact<F>(xrow, opaque(lane), x);  // last: loads complete in order and the row starts with x
+      else kill(x);
     }
     // ent_* now describe row i + i_step
-    const float *row, *vp;
-    float *mv;
-    dense_ptrs(row, vp, mv);
-    fused_pass<F, NJ, true, false, ST>(y, cw, cnt, x, r, row, vp, mv, lane, 0, ent_col, ent_c, Y, nullptr, x, nullptr, nullptr, 0, 0);
-    // `x` is the loop-carried register pair the last pass loads the NEXT row's iterate into; this row's iterate moves on
-    // as xc (copying the loaded value at the end of the row instead would wait for every gather issued before it)
-    float xc[FC];
+    float xc[FC], r[FC], p[FC], Ap[FC], rsold = 0.f;  // leader state
 #pragma unroll
-    for (int cc = 0; cc < FC; ++cc) xc[cc] = x[cc];
-    combine(r);
+    for (int cc = 0; cc < FC; ++cc) xc[cc] = r[cc] = 0.f;
+    bool store = false;
+    if (leader) {
+      put_operand(x);
 #pragma unroll
-    for (int cc = 0; cc < FC; ++cc) p[cc] = r[cc];
-    float rsold = dot_compact<F>(r, r);
-    bool active = rsold >= 1e-20f;  // else: x untouched (_als.pyx:206)
-    const bool store = active && sub == 0;
-    for (int it = 0; it + 1 < cg_steps && active; ++it) {
-      dense_ptrs(row, vp, mv);
-      fused_pass<F, NJ, false, false, ST>(y, cw, cnt, p, Ap, row, vp, mv, lane, 0, ent_col, ent_c, Y, nullptr, x, nullptr, nullptr, 0, 0);
-      combine(Ap);
-      // the operand's wave-private LDS copy is still in place: reading it back frees p's registers across the pass
-      load_compact<F>(static_cast<const float *>(mv), opaque(lane), p);
-      const float alpha = rsold / dot_compact<F>(p, Ap);
+      for (int cc = 0; cc < FC; ++cc) xc[cc] = x[cc];  // this row's iterate moves on as xc; x is re-loaded for the next row
+      publish(kGo);
+    }
+    unsigned w = await_operand();
+    {
+      float acc[FC];
+      fused_pass<F, NJ, true, false, ST>(y, cw, cnt, vt, j_begin, A0s, acc, lane, 0, ent_col, ent_c, Y, nullptr, nullptr, 0, 0);
+      arrive(acc);
+    }
+    if (leader) {
+      collect(r);
 #pragma unroll
-      for (int cc = 0; cc < FC; ++cc) {
-        xc[cc] = fmaf(alpha, p[cc], xc[cc]);
-        r[cc] = fmaf(-alpha, Ap[cc], r[cc]);
-      }
-      const float rsnew = dot_compact<F>(r, r);
-      if (rsnew < 1e-20f) {
-        active = false;  // the oracle breaks here (_als.pyx:235); the whole team takes the same branch
+      for (int cc = 0; cc < FC; ++cc) r[cc] = -r[cc], p[cc] = r[cc];
+      rsold = dot_compact<F>(r, r);
+      store = rsold >= 1e-20f;  // else: x untouched (_als.pyx:206)
+      if (store && cg_steps > 0) {
+        put_operand(p);
+        publish(kGo | (cg_steps == 1 ? kLast : 0u));
       } else {
-        const float beta = rsnew / rsold;
-#pragma unroll
-        for (int cc = 0; cc < FC; ++cc) p[cc] = fmaf(beta, p[cc], r[cc]);
-        rsold = rsnew;
+        publish(0u);
       }
     }
-    // The last step stands outside the loop: its pass rolls the next row's tile in, and only its x update is evaluated --
-    // the oracle's r, rsnew and p of the last step (_als.pyx:226-241) are never read again.
-    const bool rolled = ROLL && active && cg_steps > 0;
-    if (active && cg_steps > 0) {
-      dense_ptrs(row, vp, mv);
+    w = await_operand();
+    for (int it = 0; (w & (kGo | kLast)) == kGo; ++it) {  // all steps but the last
+      float acc[FC];
+      fused_pass<F, NJ, false, false, ST>(y, cw, cnt, vt, j_begin, A0s, acc, lane, 0, ent_col, ent_c, Y, nullptr, nullptr, 0, 0);
+      arrive(acc);
+      if (leader) {
+        collect(Ap);
+        get_operand(p);
+        const float alpha = rsold * __builtin_amdgcn_rcpf(dot_compact<F>(p, Ap));
+#pragma unroll
+        for (int cc = 0; cc < FC; ++cc) {
+          xc[cc] = fmaf(alpha, p[cc], xc[cc]);
+          r[cc] = fmaf(-alpha, Ap[cc], r[cc]);
+        }
+        const float rsnew = dot_compact<F>(r, r);
+        if (rsnew < 1e-20f) {
+          publish(0u);  // the oracle breaks here (_als.pyx:235)
+        } else {
+          const float beta = rsnew * __builtin_amdgcn_rcpf(rsold);
+#pragma unroll
+          for (int cc = 0; cc < FC; ++cc) p[cc] = fmaf(beta, p[cc], r[cc]);
+          rsold = rsnew;
+          put_operand(p);
+          publish(kGo | (it + 2 >= cg_steps ? kLast : 0u));
+        }
+      }
+      w = await_operand();
+    }
+    // The last step stands outside the loop (the compiler must see that nothing of the row follows it): its pass rolls
+    // the next row's tile in, and only its x update is evaluated -- the oracle's r, rsnew and p of the last step
+    // (_als.pyx:226-241) are never read again.
+    const bool rolled = ROLL && (w & kGo) != 0u;
+    if (w & kGo) {
+      float acc[FC];
       if constexpr (ROLL) {  // the tile of row i + i_step rolls in; the entries of row i + 2 i_step get staged
         int k2, cnt2;
         slice(b2, e2, k2, cnt2);
         if (i + i_step >= count) ent_cnt = 0;  // no next row (the schedule index is clamped): nothing to gather
-        fused_pass<F, NJ, false, true, ST>(y, cw, cnt, p, Ap, row, vp, mv, lane, ent_cnt, ent_col, ent_c, Y, X + (size_t)id1 * F, x,
-                                           indices, data, k2, max(k2 + cnt2, b2 + 1));
+        fused_pass<F, NJ, false, true, ST>(y, cw, cnt, vt, j_begin, A0s, acc, lane, ent_cnt, ent_col, ent_c, Y, indices, data, k2,
+                                           max(k2 + cnt2, b2 + 1));
         cnt = ent_cnt;
         ent_cnt = cnt2;
-      } else
-        fused_pass<F, NJ, false, false, ST>(y, cw, cnt, p, Ap, row, vp, mv, lane, 0, ent_col, ent_c, Y, nullptr, x, nullptr, nullptr, 0, 0);
-      combine(Ap);
-      load_compact<F>(static_cast<const float *>(mv), opaque(lane), p);
-      const float alpha = rsold / dot_compact<F>(p, Ap);
+        if (leader) load_compact<F>(X + (size_t)id1 * F, opaque(lane), x);  // the next row's iterate, into the carried registers
+        else kill(x);
+      } else {
+        kill(x);
+        fused_pass<F, NJ, false, false, ST>(y, cw, cnt, vt, j_begin, A0s, acc, lane, 0, ent_col, ent_c, Y, nullptr, nullptr, 0, 0);
+      }
+      arrive(acc);
+      if (leader) {
+        collect(Ap);
+        get_operand(p);
+        const float alpha = rsold * __builtin_amdgcn_rcpf(dot_compact<F>(p, Ap));
 #pragma unroll
-      for (int cc = 0; cc < FC; ++cc) xc[cc] = fmaf(alpha, p[cc], xc[cc]);
+        for (int cc = 0; cc < FC; ++cc) xc[cc] = fmaf(alpha, p[cc], xc[cc]);
+        publish(0u);
+      }
+      (void)await_operand();  // the stop generation: keeps every wave's count in step with the leader's
+    } else {
+      kill(x);
     }
-    if (store) store_compact<F>(xrow, opaque(lane), xc);
+    if (leader && store) store_compact<F>(xrow, opaque(lane), xc);
     tile_ready = rolled;
     id0 = id1, id1 = id2, id2 = id3, id3 = row_id(i + 4 * i_step);
     b0 = b1, e0 = e1, b1 = b2, e1 = e2, b2 = indptr[id2], e2 = indptr[id2 + 1];
@@ -366,7 +499,7 @@ static void launch_qfteam(const imp_csr *C, int first, int count, T *X, const T 
                           const char *name) {
   if (count <= 0) return;
   constexpr int WAVES = BLOCK / 64, TEAMS = WAVES / WPR;
-  size_t lds = ((size_t)F * F + 3 * WAVES * F + 64 * WAVES + TEAMS) * sizeof(float);
+  size_t lds = ((size_t)F * F + (size_t)WAVES * F + (size_t)TEAMS * F + 64 * WAVES + 4 * TEAMS) * sizeof(float);
   auto kern = als_cg_qfteam_kernel<F, WPR, BLOCK, T>;
   IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / BLOCK, (160 * 1024) / lds));

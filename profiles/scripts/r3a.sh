@@ -1,0 +1,16 @@
+#!/bin/bash
+# round 3, first GPU call: environment facts, VALU issue-rate micro-benchmark, parity of the fused team kernels, A/B bench
+set -u
+TAG=${1:-r3a}; O=gpurun_out/$TAG; mkdir -p $O
+{ rocm-smi --showid 2>&1 | head -20; python -c "
+import warnings; warnings.simplefilter('ignore')
+import implicit_amd.gpu as g; print('get_device_count', g.get_device_count())"; nproc; } > $O/env.txt 2>&1
+timeout 120 ./build/valu_rate > $O/valu_rate.txt 2>&1
+timeout 900 python -m pytest tests/test_gpu_als.py tests/test_gpu_golden.py tests/test_gpu_round2.py tests/test_gpu_model.py -x -q -m gpu > $O/tests.log 2>&1; echo "tests rc=$?" >> $O/tests.log
+B="python bench.py --no-cpu-baseline --no-topk --no-extras --steps 10 --warmup 3"
+IMP_TEAM_FUSED=0 timeout 300 $B > $O/b0_old.json 2> $O/b0.err
+timeout 300 $B > $O/b1_fused.json 2> $O/b1.err
+IMP_TEAM_FUSED=0 timeout 300 $B --shape c2 --factors 64 --solver cg --steps 4 --warmup 1 > $O/c2_old.json 2> $O/c2_old.err
+timeout 300 $B --shape c2 --factors 64 --solver cg --steps 4 --warmup 1 > $O/c2_fused.json 2> $O/c2_fused.err
+python profiles/scripts/show.py $O > $O/summary.txt 2>&1
+cat $O/env.txt $O/valu_rate.txt $O/summary.txt
