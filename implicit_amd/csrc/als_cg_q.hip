@@ -401,11 +401,14 @@ template <typename T>
 void launch_team_fused(const imp_csr *C, int f, int width, int first, int count, T *X, const T *Y, const float *A0, int cg_steps,
                        const char *name);
 
+template <typename T>
+void launch_group_fused(const imp_csr *C, int f, int first, int count, T *X, const T *Y, const float *A0, int cg_steps, const char *name);
+
 template <int F, typename T> static void run_classes_q(const imp_csr *C, T *X, const T *Y, const float *A0, int cg_steps) {
   const int32_t *b = C->bin_start;  // classes: 1 (256,512]  2 (128,256]  3 (64,128]  4 (32,64]  5 (16,32]  6 (0,16]
   // IMP_TEAM_FUSED=0: the round-2 team kernels (dense part, then tile part; gathers at the row start) -- A/B and the
-  // IMP_CG_STATS instrumentation; a bit mask selects the fused kernel per team width (1: 16 waves, 2: 8, 4: 4, 8: 2, 16: 1)
-  static const int fused = getenv("IMP_TEAM_FUSED") ? atoi(getenv("IMP_TEAM_FUSED")) : 31;
+  // IMP_CG_STATS instrumentation; a bit mask selects the round-3 kernel per team width (1: 16 waves, 2: 8, 4: 4, 8: 2, 16: 1, 32: the lock-step short-row kernel)
+  static const int fused = getenv("IMP_TEAM_FUSED") ? atoi(getenv("IMP_TEAM_FUSED")) : 63;
   static const bool want_stats = getenv("IMP_CG_STATS") != nullptr;
   auto team = [&](int bit, int width, int first, int count, const char *name, auto old) {
     if ((fused & bit) && !want_stats) launch_team_fused<T>(C, F, width, first, count, X, Y, A0, cg_steps, name);
@@ -432,6 +435,7 @@ template <int F, typename T> static void run_classes_q(const imp_csr *C, T *X, c
            [&](int fr, int n, const char *nm) { launch_qteam<F, 1, 512, T>(C, fr, n, X, Y, A0, cg_steps, nm); });
     else launch_qteam<F, 1, 512, T>(C, b[5], b[7] - b[5], X, Y, A0, cg_steps, "als_cg_short_rows");
   }
+  else if (fused & 32) launch_group_fused<T>(C, F, b[5], b[7] - b[5], X, Y, A0, cg_steps, "als_cg_short_rows");
   else launch_qgroup<F, T>(C, b[5], b[7] - b[5], X, Y, A0, cg_steps, "als_cg_short_rows");  // tile steps beyond cnt are skipped
 }
 

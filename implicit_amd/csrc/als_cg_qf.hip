@@ -511,6 +511,266 @@ static void launch_qfteam(const imp_csr *C, int first, int count, T *X, const T 
   IMP_CHECK_HIP(hipGetLastError());
 }
 
+// ---- short rows (<= 32 nnz): one wave per row, 16 rows per workgroup in lock step, the dense part as ONE fp32 MFMA product --
+// (als_cg_q.hip als_cg_qgroup_kernel has the product's layout: waves publish their operand in LDS, the 16-factor output
+// tiles x K-slices of A0 . P^T are dealt to the 16 waves, results return through LDS.)  Round 3 on top of it:
+//   * the operand a wave has just published is read back EXPANDED (two ds_read_b128) instead of 6 permlane swaps;
+//   * weight table, pair-wise DPP reduction, v_rcp divisions, x-only last step as in the team kernel above;
+//   * rolling gather: a workgroup holds its CU alone (96 KB of LDS), so while its 16 waves waited for the gathers of a
+//     new group of rows the CU did nothing; the last pass of a group now re-fills each pair of tile registers with the next
+//     group's entries as soon as the pair is done.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int F> struct QFGroupCfg {
+  static constexpr int LD = F + 8;          // A0 / P / Out row stride in LDS (conflict-free b128 fragment reads)
+  static constexpr int NT = F / 16;         // 16-factor output tiles
+  static constexpr int KH = 16 / NT;        // K-slices so that NT * KH == 16 waves
+  static constexpr int KB = (F / 16) / KH;  // 16-factor k-blocks per wave
+  static constexpr size_t lds_floats = (size_t)F * LD + 16 * LD + (size_t)KH * 16 * LD + 16 * 64;
+};
+
+// tile part of a pass: acc (compact) = sum over the resident entries of w y, operand read expanded from `vrow` (natural order)
+//   FIRST: w = c+ - (|c|-1) y.x   else: w = (|c|-1) y.v
+template <int F, bool FIRST, bool LAST, typename ST>
+__device__ __forceinline__ void tile_pass(f32x2 (&y)[8][F / 32], float *cw, int cnt, const float *vrow, float (&acc)[F / 64], int lane,
+                                          int cnt_nx, int &col_nx, float &c_nx, const ST *__restrict__ Y) {
+  constexpr int FE = F / 16, H = FE / 2;
+  if constexpr (LAST) {  // one wait for the staged entries, before any rolling gather (fused_pass)
+    col_nx = opaque(col_nx);
+    c_nx = __int_as_float(opaque(__float_as_int(c_nx)));
+  }
+  f32x2 ve[H], ae[H];
+  const float *cwg;
+  {
+    const int ln = opaque(lane);
+    const int g = ln >> 4, m = ln & 15;
+#pragma unroll
+    for (int e = 0; e < FE; e += 4) {
+      const float4 t = *reinterpret_cast<const float4 *>(vrow + 16 * e + 4 * m);
+      ve[e / 2] = f32x2{t.x, t.y}, ve[e / 2 + 1] = f32x2{t.z, t.w};
+    }
+    cwg = cw + g;
+  }
+#pragma unroll
+  for (int h = 0; h < H; ++h) ae[h] = f32x2{0.f, 0.f};
+  auto partial = [&](int q) {
+    f32x2 s = y[q][0] * ve[0];
+#pragma unroll
+    for (int h = 1; h < H; ++h) s = __builtin_elementwise_fma(y[q][h], ve[h], s);
+    return s.x + s.y;
+  };
+  auto axpy = [&](int q, float w) {
+    const f32x2 w2 = {w, w};
+#pragma unroll
+    for (int h = 0; h < H; ++h) ae[h] = __builtin_elementwise_fma(w2, y[q][h], ae[h]);
+  };
+  static_for<4>([&](auto Pc) {
+    constexpr int P = decltype(Pc)::value;
+    if (8 * P < cnt) {  // wave-uniform
+      const float cm1_0 = cwg[8 * P], cm1_1 = cwg[8 * P + 4];
+      float cp_0 = 0.f, cp_1 = 0.f;
+      if constexpr (FIRST) cp_0 = cwg[32 + 8 * P], cp_1 = cwg[32 + 8 * P + 4];
+      const float u = reduce_pair(partial(2 * P), partial(2 * P + 1));
+      const float w0 = FIRST ? fmaf(-cm1_0, row_bcast_from<0>(u), cp_0) : cm1_0 * row_bcast_from<0>(u);
+      const float w1 = FIRST ? fmaf(-cm1_1, row_bcast_from<8>(u), cp_1) : cm1_1 * row_bcast_from<8>(u);
+      axpy(2 * P, w0);
+      axpy(2 * P + 1, w1);
+    }
+    if constexpr (LAST) {
+      if (8 * P < cnt_nx) gather_pair<F, P>(y, cw, col_nx, c_nx, cnt_nx, Y, lane);
+    }
+  });
+  float aes[FE];
+#pragma unroll
+  for (int h = 0; h < H; ++h) aes[2 * h] = ae[h].x, aes[2 * h + 1] = ae[h].y;
+  reduce_expanded<F>(aes, acc);
+}
+
+template <int F, typename ST>
+__global__ __launch_bounds__(1024) void als_cg_qfgroup_kernel(const int32_t *__restrict__ order, int first, int count,
+                                                              const int32_t *__restrict__ indptr,
+                                                              const int32_t *__restrict__ indices,
+                                                              const float *__restrict__ data, ST *__restrict__ X,
+                                                              const ST *__restrict__ Y, const float *__restrict__ A0, int cg_steps) {
+  using Cfg = QFGroupCfg<F>;
+  constexpr int FC = F / 64, FE = F / 16, LD = Cfg::LD;
+  constexpr bool ROLL = std::is_same<ST, float>::value;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *A0s = smem;                                   // [F][LD]
+  float *Ps = A0s + (size_t)F * LD;                    // [16][LD]  operands of the 16 rows (natural factor order)
+  float *Outs = Ps + 16 * LD;                          // [KH][16][LD]  K-slice partial products
+  float *cws = Outs + (size_t)Cfg::KH * 16 * LD;       // [16][64]  per-entry weights (gather_pair)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int e = threadIdx.x; e < F * F; e += 1024) {
+    int r = e / F, c = e - r * F;
+    A0s[r * LD + c] = A0[e];
+  }
+  __syncthreads();
+  float *prow = Ps + (size_t)wave * LD;
+  float *cw = cws + (size_t)wave * 64;
+  const unsigned cf = (unsigned)QL<F>::cfactor(lane, 0);  // this lane's compact slots inside a natural-order vector
+
+  // out (compact) = A0 . vec for this wave's row; every wave of the workgroup takes both barriers (inactive rows publish 0)
+  auto dense = [&](const float (&vec)[FC], bool valid, float (&out)[FC]) {
+    if constexpr (FC == 2) *reinterpret_cast<float2 *>(prow + cf) = valid ? make_float2(vec[0], vec[1]) : make_float2(0.f, 0.f);
+    else prow[cf] = valid ? vec[0] : 0.f;
+    __syncthreads();
+    const int ti = wave % Cfg::NT, kh = wave / Cfg::NT;
+    const int ln = opaque(lane);
+    const int i = ln & 15, kq = ln >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < Cfg::KB; ++kb) {
+      const int k0 = (kh * Cfg::KB + kb) * 16 + 4 * kq;
+      const float4 a = *reinterpret_cast<const float4 *>(A0s + (16 * ti + i) * LD + k0);
+      const float4 b = *reinterpret_cast<const float4 *>(Ps + i * LD + k0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+    }
+    *reinterpret_cast<float4 *>(Outs + (kh * 16 + i) * LD + 16 * ti + 4 * kq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < FC; ++c) out[c] = 0.f;
+#pragma unroll
+    for (int h = 0; h < Cfg::KH; ++h) {
+      const float *o = Outs + (h * 16 + wave) * LD + cf;
+      if constexpr (FC == 2) {
+        const float2 t = *reinterpret_cast<const float2 *>(o);
+        out[0] += t.x, out[1] += t.y;
+      } else {
+        out[0] += o[0];
+      }
+    }
+  };
+
+  const int groups = (count + 15) / 16, g_step = gridDim.x;
+  // row of this wave in group g (groups past the end and rows past the count re-read the last row and stay invalid)
+  auto row_id = [&](int g) { return order[first + min(g * 16 + wave, count - 1)]; };  // uniform address: scalar load
+  auto row_valid = [&](int g) { return g < groups && g * 16 + wave < count; };
+  int id0 = row_id(blockIdx.x), id1 = row_id(blockIdx.x + g_step), id2 = row_id(blockIdx.x + 2 * g_step), id3 = row_id(blockIdx.x + 3 * g_step);
+  int b0 = indptr[id0], e0 = indptr[id0 + 1], b1 = indptr[id1], e1 = indptr[id1 + 1], b2 = indptr[id2], e2 = indptr[id2 + 1];
+  int ent_col, ent_cnt = row_valid(blockIdx.x) ? e0 - b0 : 0;
+  float ent_c;
+  fetch_entries(indices, data, opaque(lane), b0, max(e0, b0 + 1), ent_col, ent_c);
+  bool tile_ready = false;
+  int cnt = 0;
+  f32x2 y[8][FE / 2];
+  float x[FC];
+  auto kill = [](float (&v)[FC]) {
+#pragma unroll
+    for (int cc = 0; cc < FC; ++cc) v[cc] = 0.f;
+  };
+  kill(x);
+  for (int g = blockIdx.x; g < groups; g += g_step) {
+    const bool valid = row_valid(g);
+    ST *xrow = X + (size_t)id0 * F;
+    if (!tile_ready) {  // first group, or this wave's previous row ended before its last pass
+      cnt = ent_cnt;
+      ent_col = opaque(ent_col);
+      ent_c = __int_as_float(opaque(__float_as_int(ent_c)));
+      static_for<4>([&](auto Pc) {
+        constexpr int P = decltype(Pc)::value;
+        if (8 * P < cnt) gather_pair<F, P>(y, cw, ent_col, ent_c, cnt, Y, lane);
+      });
+      ent_cnt = row_valid(g + g_step) ? e1 - b1 : 0;
+      fetch_entries(indices, data, opaque(lane), b1, max(e1, b1 + 1), ent_col, ent_c);
+      load_compact<F>(xrow, opaque(lane), x);
+    }
+    // ent_* now describe this wave's row of group g + g_step
+    float xc[FC], r[FC], p[FC], Ap[FC], sp[FC];
+#pragma unroll
+    for (int cc = 0; cc < FC; ++cc) xc[cc] = x[cc];
+    // r = -(A0 x) + sum_k (c+ - (|c|-1) y.x) y        (_als.pyx:187-201)
+    dense(xc, valid, Ap);
+    tile_pass<F, true, false, ST>(y, cw, cnt, prow, sp, lane, 0, ent_col, ent_c, Y);
+#pragma unroll
+    for (int cc = 0; cc < FC; ++cc) p[cc] = r[cc] = sp[cc] - Ap[cc];
+    float rsold = dot_compact<F>(r, r);
+    bool active = valid && rsold >= 1e-20f;  // else: x untouched (_als.pyx:206)
+    const bool store = active;
+    for (int it = 0; it + 1 < cg_steps; ++it) {  // all steps but the last; every wave takes the barriers of dense()
+      dense(p, active, Ap);
+      if (active) {  // wave-uniform
+        tile_pass<F, false, false, ST>(y, cw, cnt, prow, sp, lane, 0, ent_col, ent_c, Y);
+#pragma unroll
+        for (int cc = 0; cc < FC; ++cc) Ap[cc] += sp[cc];
+        const float alpha = rsold * __builtin_amdgcn_rcpf(dot_compact<F>(p, Ap));
+#pragma unroll
+        for (int cc = 0; cc < FC; ++cc) {
+          xc[cc] = fmaf(alpha, p[cc], xc[cc]);
+          r[cc] = fmaf(-alpha, Ap[cc], r[cc]);
+        }
+        const float rsnew = dot_compact<F>(r, r);
+        if (rsnew < 1e-20f) {
+          active = false;  // the oracle breaks here (_als.pyx:235); the wave keeps taking the barriers
+        } else {
+          const float beta = rsnew * __builtin_amdgcn_rcpf(rsold);
+#pragma unroll
+          for (int cc = 0; cc < FC; ++cc) p[cc] = fmaf(beta, p[cc], r[cc]);
+          rsold = rsnew;
+        }
+      }
+    }
+    // last step: only its x update is evaluated (_als.pyx:226-241 compute r, rsnew, p that nothing reads); its tile pass
+    // rolls the next group's entries in
+    bool rolled = false;
+    if (cg_steps > 0) {
+      dense(p, active, Ap);
+      if (active) {
+        if constexpr (ROLL) {
+          tile_pass<F, false, true, ST>(y, cw, cnt, prow, sp, lane, ent_cnt, ent_col, ent_c, Y);
+          cnt = ent_cnt;
+          ent_cnt = row_valid(g + 2 * g_step) ? e2 - b2 : 0;
+          fetch_entries(indices, data, opaque(lane), b2, max(e2, b2 + 1), ent_col, ent_c);
+          load_compact<F>(X + (size_t)id1 * F, opaque(lane), x);
+          rolled = true;
+        } else {
+          tile_pass<F, false, false, ST>(y, cw, cnt, prow, sp, lane, 0, ent_col, ent_c, Y);
+          kill(x);
+        }
+#pragma unroll
+        for (int cc = 0; cc < FC; ++cc) Ap[cc] += sp[cc];
+        const float alpha = rsold * __builtin_amdgcn_rcpf(dot_compact<F>(p, Ap));
+#pragma unroll
+        for (int cc = 0; cc < FC; ++cc) xc[cc] = fmaf(alpha, p[cc], xc[cc]);
+      } else {
+        kill(x);
+      }
+    } else {
+      kill(x);
+    }
+    if (store) store_compact<F>(xrow, opaque(lane), xc);
+    tile_ready = rolled;
+    id0 = id1, id1 = id2, id2 = id3, id3 = row_id(g + 4 * g_step);
+    b0 = b1, e0 = e1, b1 = b2, e1 = e2, b2 = indptr[id2], e2 = indptr[id2 + 1];
+  }
+}
+
+template <int F, typename T>
+static void launch_qfgroup(const imp_csr *C, int first, int count, T *X, const T *Y, const float *A0, int cg_steps, const char *name) {
+  if (count <= 0) return;
+  size_t lds = QFGroupCfg<F>::lds_floats * sizeof(float);
+  auto kern = als_cg_qfgroup_kernel<F, T>;
+  IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  static const int per_cu = getenv("IMP_QGROUP_PER_CU") ? std::max(1, atoi(getenv("IMP_QGROUP_PER_CU"))) : 2;
+  int grid = std::min((count + 15) / 16, ctx().num_cus * std::max(per_cu, ctx().oversub));
+  IMP_PROF(name);
+  kern<<<grid, 1024, lds, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(), C->data.data(), X, Y, A0,
+                                      cg_steps);
+  IMP_CHECK_HIP(hipGetLastError());
+}
+
+template <typename T>
+void launch_group_fused(const imp_csr *C, int f, int first, int count, T *X, const T *Y, const float *A0, int cg_steps, const char *name) {
+  if (f == 128) launch_qfgroup<128, T>(C, first, count, X, Y, A0, cg_steps, name);
+  else if (f == 64) launch_qfgroup<64, T>(C, first, count, X, Y, A0, cg_steps, name);
+  else throw std::invalid_argument("launch_group_fused: f must be 64 or 128");
+}
+template void launch_group_fused<float>(const imp_csr *, int, int, int, float *, const float *, const float *, int, const char *);
+template void launch_group_fused<__half>(const imp_csr *, int, int, int, __half *, const __half *, const float *, int, const char *);
+
 // width: 1 (f = 64 short rows), 2, 4, 8, 16
 template <typename T>
 void launch_team_fused(const imp_csr *C, int f, int width, int first, int count, T *X, const T *Y, const float *A0, int cg_steps,

@@ -93,6 +93,42 @@ int imp_comm_allreduce_sum(imp_comm *c, imp_matrix *m) {
     if (m->itemsize != 4) throw std::invalid_argument("allreduce_sum needs a float32 matrix");
     IMP_PROF("rccl_allreduce");
     IMP_CHECK_NCCL(ncclAllReduce(m->data, m->data, m->rows * m->cols, ncclFloat, ncclSum, c->comm, stream()));
+    sync_call();
+  });
+}
+
+// Personalised exchange of row ranges (set-up path: every rank hands every other rank the piece of its transposed shard
+// that falls into the other's item range).  Rows [send_lo[p], send_hi[p]) of `send` go to rank p and arrive there as rows
+// [recv_lo[me], recv_hi[me]) of its `recv`; the piece a rank keeps for itself is a device copy.  Payload bytes travel
+// untouched (ncclChar), so int32 columns may ride in an fp32 matrix.
+int imp_comm_alltoall_rows(imp_comm *c, const imp_matrix *send, const int64_t *send_lo, const int64_t *send_hi, imp_matrix *recv,
+                           const int64_t *recv_lo, const int64_t *recv_hi) {
+  return guarded([&] {
+    const size_t sb = send->cols * send->itemsize, rb = recv->cols * recv->itemsize;
+    if (sb != rb) throw std::invalid_argument("alltoall_rows: send and recv rows differ in size");
+    for (int p = 0; p < c->nranks; ++p) {
+      if (send_lo[p] < 0 || send_hi[p] < send_lo[p] || (size_t)send_hi[p] > send->rows)
+        throw std::invalid_argument("alltoall_rows: send range outside the matrix");
+      if (recv_lo[p] < 0 || recv_hi[p] < recv_lo[p] || (size_t)recv_hi[p] > recv->rows)
+        throw std::invalid_argument("alltoall_rows: recv range outside the matrix");
+    }
+    if (send_hi[c->rank] - send_lo[c->rank] != recv_hi[c->rank] - recv_lo[c->rank])
+      throw std::invalid_argument("alltoall_rows: the piece a rank keeps must have the same size on both sides");
+    IMP_PROF("rccl_alltoall_rows");
+    const char *sbase = reinterpret_cast<const char *>(send->data);
+    char *rbase = reinterpret_cast<char *>(recv->data);
+    const size_t own = (size_t)(send_hi[c->rank] - send_lo[c->rank]) * sb;
+    if (own)
+      IMP_CHECK_HIP(hipMemcpyAsync(rbase + (size_t)recv_lo[c->rank] * rb, sbase + (size_t)send_lo[c->rank] * sb, own,
+                                   hipMemcpyDeviceToDevice, stream()));
+    IMP_CHECK_NCCL(ncclGroupStart());
+    for (int peer = 0; peer < c->nranks; ++peer) {
+      if (peer == c->rank) continue;
+      const size_t out = (size_t)(send_hi[peer] - send_lo[peer]) * sb, in = (size_t)(recv_hi[peer] - recv_lo[peer]) * rb;
+      if (out) IMP_CHECK_NCCL(ncclSend(sbase + (size_t)send_lo[peer] * sb, out, ncclChar, peer, c->comm, stream()));
+      if (in) IMP_CHECK_NCCL(ncclRecv(rbase + (size_t)recv_lo[peer] * rb, in, ncclChar, peer, c->comm, stream()));
+    }
+    IMP_CHECK_NCCL(ncclGroupEnd());
     sync();
   });
 }

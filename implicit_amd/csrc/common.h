@@ -65,6 +65,9 @@ template <typename F> int guarded(F &&body) {
 
 inline hipStream_t stream();
 void sync();  // hipStreamSynchronize on the library stream
+// end of a C-ABI call that only queues device work (solver sweeps, gramian, all-reduce): host wait unless the device is in
+// deferred mode (imp_set_deferred_sync), where the caller orders a whole iteration with ONE imp_device_synchronize
+void sync_call();
 bool team16_as_cluster();    // als_cg_cluster.hip: rows of (256,512] nnz on clusters of two workgroups instead of team16
 bool cluster_fault_pending();  // als_cg_cluster.hip: a cluster exchange timed out since the last check (clears the flag)
 
@@ -115,6 +118,9 @@ struct Context {
   // of the device is held by another stream's kernels (RCCL send / recv) the workgroups that have to wait for a slot no
   // longer carry a full share, and the hardware dispatcher balances the rest.
   int oversub = 1;
+  // imp_set_deferred_sync: the queue-only entry points return without a host wait (the multi-GPU driver queues a whole
+  // iteration -- K solve chunks, their exchanges, two all-reduces -- and waits once)
+  bool deferred = false;
   hipStream_t occupy_stream = nullptr;  // imp_debug_occupy
   std::recursive_mutex mutex;
   DeviceArray<float> gram_ws;     // split-K partial gramians (gramian.hip)

@@ -49,6 +49,9 @@ std::unique_lock<std::recursive_mutex> lock_device() {
 }
 
 void sync() { IMP_CHECK_HIP(hipStreamSynchronize(stream())); }
+void sync_call() {
+  if (!ctx().deferred) sync();
+}
 
 // ---- profiler -----------------------------------------------------------------------------------
 struct ProfEntry {
@@ -252,6 +255,15 @@ int imp_set_oversubscribe(int factor) {
     ctx().oversub = factor;
   });
 }
+int imp_get_oversubscribe(int *factor) {
+  return guarded([&] { *factor = ctx().oversub; });
+}
+int imp_set_deferred_sync(int on) {
+  return guarded([&] {
+    if (!on) sync();  // leaving the mode: everything queued so far is complete on return
+    ctx().deferred = on != 0;
+  });
+}
 int imp_debug_occupy(int workgroups, int microseconds) {
   return guarded([&] {
     if (workgroups <= 0 || microseconds <= 0) return;
@@ -271,6 +283,9 @@ int imp_device_synchronize(void) {
   return guarded([&] {
     sync();
     IMP_CHECK_HIP(hipDeviceSynchronize());
+    // deferred mode: the solver calls could not report a timed-out cluster exchange themselves
+    if (cluster_fault_pending())
+      throw std::runtime_error("a cluster exchange timed out (als_cg_cluster.hip) since the last synchronisation; results are invalid");
   });
 }
 int imp_mem_get_info(size_t *free_bytes, size_t *total_bytes) {

@@ -11,8 +11,8 @@ HAS_RMM = False
 
 try:
     from ._cuda import (COOMatrix, Comm, CSRMatrix, IntVector, KnnQuery, LeastSquaresSolver, Matrix,  # noqa: F401
-                        Profiler, RandomState, bpr_update, calculate_norms, debug_occupy, get_device_count,
-                        set_device, set_oversubscribe, synchronize)
+                        Profiler, RandomState, bpr_update, calculate_norms, debug_occupy, get_device_count, get_oversubscribe,
+                        set_deferred_sync, set_device, set_oversubscribe, synchronize)
     from ._hip import lib as _lib
 
     _lib()  # ImportError when libimplicit_hip.so has not been built

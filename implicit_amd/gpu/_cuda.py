@@ -379,6 +379,12 @@ class Comm:
     def allgather_rows_end(self):
         check(lib().imp_comm_allgather_rows_end(self._h))
 
+    def alltoall_rows(self, send, send_lo, send_hi, recv, recv_lo, recv_hi):
+        """Rows [send_lo[p], send_hi[p]) of `send` go to rank p and land in rows [recv_lo[q], recv_hi[q]) of its `recv`
+        (q = the sender).  Blocking; bytes travel untouched."""
+        arr = lambda v: (ctypes.c_int64 * self.nranks)(*[int(o) for o in v])  # noqa: E731
+        check(lib().imp_comm_alltoall_rows(self._h, send._h, arr(send_lo), arr(send_hi), recv._h, arr(recv_lo), arr(recv_hi)))
+
     def barrier(self):
         check(lib().imp_comm_barrier(self._h))
 
@@ -396,6 +402,18 @@ def set_oversubscribe(factor):
     """Workgroups launched per resident slot by the persistent row kernels (1 = exactly what the device holds; the
     multi-GPU driver uses 4 so that slots held by RCCL's kernels only delay small shares)."""
     check(lib().imp_set_oversubscribe(int(factor)))
+
+
+def get_oversubscribe():
+    n = ctypes.c_int(0)
+    check(lib().imp_get_oversubscribe(ctypes.byref(n)))
+    return n.value
+
+
+def set_deferred_sync(on):
+    """Deferred mode of the current device: calculate_yty / least_squares / Comm.allreduce_sum only queue their work; one
+    synchronize() orders (and checks) everything queued.  set_deferred_sync(False) waits and restores the default."""
+    check(lib().imp_set_deferred_sync(1 if on else 0))
 
 
 def debug_occupy(workgroups, microseconds):

@@ -20,6 +20,8 @@ _SIGNATURES = {
     "imp_set_device": [ctypes.c_int],
     "imp_get_device": [ctypes.POINTER(ctypes.c_int)],
     "imp_set_oversubscribe": [ctypes.c_int],
+    "imp_get_oversubscribe": [ctypes.POINTER(ctypes.c_int)],
+    "imp_set_deferred_sync": [ctypes.c_int],
     "imp_debug_occupy": [ctypes.c_int, ctypes.c_int],
     "imp_device_synchronize": [],
     "imp_mem_get_info": [ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)],
@@ -76,6 +78,8 @@ _SIGNATURES = {
     "imp_comm_allgather_rows_begin": [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64),
                                       ctypes.POINTER(ctypes.c_int64)],
     "imp_comm_allgather_rows_end": [ctypes.c_void_p],
+    "imp_comm_alltoall_rows": [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
+                               ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)],
     "imp_comm_barrier": [ctypes.c_void_p],
     "imp_prof_enable": [ctypes.c_int],
     "imp_prof_filter": [ctypes.c_char_p],

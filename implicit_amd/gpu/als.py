@@ -16,8 +16,9 @@ numerics of the reference's *CPU* path, which is the parity oracle (implicit/cpu
   * NaN factors after fit raise ModelFitError (cpu/als.py:202).
 
 Multi-GPU: `AlternatingLeastSquares(..., comm=implicit_amd.gpu.Comm(...))`, one process per GPU, every rank calling
-fit() with the same matrix (implicit_amd/gpu/sharded.py: rows sharded by nnz, RCCL all-reduce of the gramian and
-all-gather of the solved factor rows; all ranks end with identical full factors).  `rendezvous.init_comm(gpu)` builds the
+fit() with ITS contiguous block of user rows (blocks in rank order; implicit_amd/gpu/sharded.py: the item-side shard is
+exchanged at set-up, RCCL all-reduce of the gramian and all-gather of the solved factor rows per half sweep; all ranks
+end with identical full factors).  `rendezvous.init_comm(gpu)` builds the
 communicator from the launcher's RANK / WORLD_SIZE / MASTER_* environment.  No reference counterpart
 (implicit/gpu/als.cu:169 "TODO: multi-gpu support").
 """
@@ -84,18 +85,17 @@ class AlternatingLeastSquares(MatrixFactorizationBase):
             Cui = Cui.astype(np.float32)
         if self.alpha != 1.0:
             Cui = self.alpha * Cui
+        self._item_norms = self._user_norms = None
+        self._item_norms_host = self._user_norms_host = None
+        self._YtY = self._XtX = self._YtY0 = self._XtX0 = None
+        if self.comm is not None and self.comm.nranks > 1:
+            return self._fit_sharded(Cui, callback)  # `user_items` = THIS RANK's block of user rows
+
         t0 = time.time()
         Ciu = Cui.T.tocsr()
         log.debug("Calculated transpose in %.3fs", time.time() - t0)
         items, users = Ciu.shape
-
         self._initial_factors(users, items)
-        self._item_norms = self._user_norms = None
-        self._item_norms_host = self._user_norms_host = None
-        self._YtY = self._XtX = self._YtY0 = self._XtX0 = None
-
-        if self.comm is not None and self.comm.nranks > 1:
-            return self._fit_sharded(Cui, Ciu, callback)
 
         Cui_dev, Ciu_dev = gpu.CSRMatrix(Cui), gpu.CSRMatrix(Ciu)
         X, Y = self.user_factors, self.item_factors
@@ -119,23 +119,35 @@ class AlternatingLeastSquares(MatrixFactorizationBase):
             log.info("Final training loss %s", loss)
         self._check_fit_errors()
 
-    def _fit_sharded(self, Cui, Ciu, callback):
+    def _fit_sharded(self, Cui_rows, callback):
+        """Multi-GPU fit: `Cui_rows` is this rank's contiguous block of user rows (all item columns, blocks in rank
+        order; `sharded.take_rank_rows(full, comm)` cuts one out of a full matrix).  Nothing of full-matrix size is
+        built on any rank: the item-side shard comes from a transpose of the block plus one personalised exchange."""
         from . import sharded
 
         if not self.use_cg:
             raise ValueError("the multi-GPU fit runs the CG solver (use_cg=True)")
         if self.dtype != np.float32:
             raise ValueError("the multi-GPU fit keeps float32 factor replicas")
+        backend = sharded.GpuBackend(gpu, solver=self.solver, nranks=self.comm.nranks)
+        sizes = np.zeros(self.comm.nranks, dtype=np.int64)
+        sizes[self.comm.rank] = Cui_rows.shape[0]
+        users = int(sharded.allreduce_ints(self.comm, backend, sizes).sum())
+        self._initial_factors(users, Cui_rows.shape[1])
         # every rank must start from the same factors whatever its random_state: rank 0's win (the others contribute
         # zeros to a sum all-reduce)
         for m in (self.user_factors, self.item_factors):
             if self.comm.rank != 0:
                 m.copy_from_numpy(np.zeros(m.shape, dtype=np.float32))
             self.comm.allreduce_sum(m)
-        sharded.fit_sharded(self, Cui, Ciu, self.comm, callback or self.fit_callback)
+        u_off, _ = sharded.fit_sharded(self, Cui_rows, self.comm, callback or self.fit_callback, backend=backend,
+                                       csr=gpu.CSRMatrix)
         if self.calculate_training_loss:
-            loss = self.solver.calculate_loss(gpu.CSRMatrix(Cui), self.user_factors, self.item_factors, self.regularization)
-            log.info("Final training loss %s", loss)
+            # the objective restricted to this rank's user rows (each rank logs its own; there is no global reduction)
+            r = self.comm.rank
+            loss = self.solver.calculate_loss(gpu.CSRMatrix(Cui_rows), self.user_factors[int(u_off[r]):int(u_off[r + 1])],
+                                              self.item_factors, self.regularization)
+            log.info("Final training loss over rank %d's user rows %s", r, loss)
         self._check_fit_errors()
 
     def _half_sweep(self, C, X, Y, gram):

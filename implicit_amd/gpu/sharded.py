@@ -24,8 +24,11 @@ oracle as the per-shard solver:
 
   comm    : .nranks .rank .allreduce_sum(M) .allgather_rows(M, row_offsets) .barrier()
             .allgather_rows_begin(M, row_lo, row_hi) .allgather_rows_end()   (pipelined form)
+            .alltoall_rows(send, send_lo, send_hi, recv, recv_lo, recv_hi)   (set-up: pieces of the transposed shard)
   backend : .calculate_yty(F_rows, gram, reg) .least_squares(C, X_rows, gram, Y, cg_steps)
             .rows(M, start, stop) -> view sharing storage
+            .upload(float32 array (n, c)) -> M   .download(M) -> float32 array   (set-up only)
+            .deferred(on) .fence()   queue-only solver calls: one host wait per iteration instead of one per call
 """
 import time
 
@@ -61,8 +64,32 @@ class GpuBackend:
 
         self.gpu = gpu
         self.solver = solver or gpu.LeastSquaresSolver()
+        self._restore_oversub = None
         if nranks > 1:
+            self._restore_oversub = gpu.get_oversubscribe()
             gpu.set_oversubscribe(int(os.environ.get("IMP_SHARD_OVERSUB", "4")))
+
+    def close(self):
+        """Undo what the constructor changed on the device: later single-GPU calls of the process (fold-ins, other
+        models) run with the launch shape they had before."""
+        self.deferred(False)
+        if self._restore_oversub is not None:
+            self.gpu.set_oversubscribe(self._restore_oversub)
+            self._restore_oversub = None
+
+    def deferred(self, on):
+        self.gpu.set_deferred_sync(on)
+
+    def fence(self):
+        """Host wait for everything queued; raises if a cluster exchange timed out since the last one."""
+        self.gpu.synchronize()
+
+    def upload(self, array):
+        return self.gpu.Matrix(np.ascontiguousarray(array, dtype=np.float32))
+
+    @staticmethod
+    def download(M):
+        return M.to_numpy()
 
     def calculate_yty(self, rows, gram, reg):
         self.solver.calculate_yty(rows, gram, reg)
@@ -88,6 +115,91 @@ def split_rows(C_shard, chunks):
     """This rank's CSR rows cut the same way (scipy CSR in, list of scipy CSR out)."""
     cuts = chunk_offsets([0, C_shard.shape[0]], chunks)[0]
     return [C_shard[int(cuts[k]):int(cuts[k + 1])] for k in range(chunks)]
+
+
+def allreduce_ints(comm, backend, values):
+    """Exact element-wise sum over the ranks of an array of non-negative integers (< 2^63), through the fp32 sum
+    all-reduce: four 16-bit limbs per value, each limb's sum stays below 2^24 for up to 256 ranks."""
+    v = np.asarray(values, dtype=np.int64).reshape(-1)
+    limbs = np.stack([(v >> (16 * k)) & 0xFFFF for k in range(4)], axis=1).astype(np.float32)
+    m = backend.upload(limbs)
+    comm.allreduce_sum(m)
+    back = np.rint(backend.download(m)).astype(np.int64).reshape(-1, 4)
+    return sum(back[:, k] << (16 * k) for k in range(4))
+
+
+def shard_transpose(comm, backend, Cui_rows):
+    """From user-sharded input to the two shards a rank solves: every rank passes ITS contiguous block of user rows
+    (scipy CSR, global item ids; blocks in rank order) and gets back
+
+        Ciu_rows  its block of ITEM rows (global user ids, columns sorted),
+        u_off     the user cut points (from the block sizes),
+        i_off     the item cut points (balanced by the global nonzeros per item).
+
+    Only the shard is transposed locally (items x my users); the piece of that transpose inside rank p's item range goes
+    to p in one personalised exchange (counts per row, columns, values), and since user blocks are in rank order the
+    received pieces concatenate row by row into sorted rows.  No rank ever holds the full matrix."""
+    import scipy.sparse as sp
+
+    r, n = comm.rank, comm.nranks
+    n_local, items = Cui_rows.shape
+    sizes = np.zeros(n, dtype=np.int64)
+    sizes[r] = n_local
+    u_off = np.concatenate([[0], np.cumsum(allreduce_ints(comm, backend, sizes))]).astype(np.int64)
+    T = Cui_rows.T.tocsr()  # items x my users
+    T.sort_indices()
+    lens = allreduce_ints(comm, backend, np.diff(T.indptr))
+    i_off = shard_offsets(items, n, weights=lens)
+    # nonzeros of the piece rank q sends to rank p: table[q, p]
+    table = np.zeros((n, n), dtype=np.int64)
+    table[r] = T.indptr[i_off[1:]] - T.indptr[i_off[:-1]]
+    table = allreduce_ints(comm, backend, table).reshape(n, n)
+    my_items = int(i_off[r + 1] - i_off[r])
+    # one segment per peer: [row counts | columns (global user ids) | values], 4-byte words riding in an fp32 column
+    segs, send_lo, send_hi, at = [], [], [], 0
+    for p in range(n):
+        lo, hi = int(T.indptr[i_off[p]]), int(T.indptr[i_off[p + 1]])
+        counts = np.diff(T.indptr[i_off[p]:i_off[p + 1] + 1]).astype(np.int32)
+        cols = (T.indices[lo:hi].astype(np.int64) + u_off[r]).astype(np.int32)
+        segs += [counts.view(np.float32), cols.view(np.float32), T.data[lo:hi].astype(np.float32, copy=False)]
+        send_lo.append(at)
+        at += counts.size + 2 * (hi - lo)
+        send_hi.append(at)
+    send = backend.upload(np.concatenate(segs).reshape(-1, 1) if at else np.zeros((1, 1), np.float32))
+    recv_len = [my_items + 2 * int(table[q, r]) for q in range(n)]
+    recv_lo = np.concatenate([[0], np.cumsum(recv_len)])[:-1]
+    recv_hi = recv_lo + np.asarray(recv_len)
+    recv = backend.upload(np.zeros((max(1, int(recv_hi[-1])), 1), dtype=np.float32))
+    comm.alltoall_rows(send, send_lo, send_hi, recv, recv_lo, recv_hi)
+    words = backend.download(recv).reshape(-1)
+    pieces = []
+    for q in range(n):
+        seg = words[int(recv_lo[q]):int(recv_hi[q])]
+        k = int(table[q, r])
+        pieces.append((seg[:my_items].view(np.int32).astype(np.int64), seg[my_items:my_items + k].view(np.int32),
+                       seg[my_items + k:my_items + 2 * k]))
+    row_len = sum(c for c, _, _ in pieces) if pieces else np.zeros(my_items, np.int64)
+    indptr = np.concatenate([[0], np.cumsum(row_len)]).astype(np.int64)
+    indices = np.empty(int(indptr[-1]), dtype=np.int32)
+    data = np.empty(int(indptr[-1]), dtype=np.float32)
+    start = indptr[:-1].copy()  # where the next piece's entries of each row go
+    for counts, cols, vals in pieces:
+        k = cols.size
+        if k:
+            piece_ptr = np.concatenate([[0], np.cumsum(counts)])[:-1]
+            dest = np.repeat(start - piece_ptr, counts) + np.arange(k, dtype=np.int64)
+            indices[dest] = cols
+            data[dest] = vals
+        start += counts
+    idx_dtype = np.int32 if indptr[-1] < 2**31 else np.int64
+    Ciu_rows = sp.csr_matrix((data, indices, indptr.astype(idx_dtype)), shape=(my_items, int(u_off[-1])))
+    return Ciu_rows, u_off, i_off
+
+
+def take_rank_rows(Cui_full, comm):
+    """Convenience for callers that do hold the whole matrix on every rank: this rank's block of user rows, cut by nnz."""
+    u_off = shard_offsets(Cui_full.shape[0], comm.nranks, weights=np.diff(Cui_full.indptr))
+    return Cui_full[int(u_off[comm.rank]):int(u_off[comm.rank + 1])]
 
 
 def half_sweep(backend, comm, C_shard, X_full, x_offsets, Y_full, y_offsets, gram, reg, cg_steps):
@@ -122,37 +234,47 @@ def iteration(backend, comm, Cui_shard, Ciu_shard, X_full, Y_full, u_offsets, i_
 # ---- model-level entry: AlternatingLeastSquares(..., comm=...).fit ------------------------------------------------------
 
 
-def fit_sharded(model, Cui, Ciu, comm, callback=None, chunks=None):
-    """The iterations of AlternatingLeastSquares.fit on `comm.nranks` GPUs.  Every rank calls it with the SAME full
-    matrices (scipy CSR, users x items and its transpose) and the same initial factors in model.user_factors /
-    item_factors; rows are cut by nnz weight, every rank keeps its own rows of both orientations on the device, and
-    all ranks finish with identical full factor matrices."""
+def fit_sharded(model, Cui_rows, comm, callback=None, chunks=None, backend=None, csr=None):
+    """The iterations of AlternatingLeastSquares.fit on `comm.nranks` GPUs.  Every rank calls it with ITS block of user
+    rows (scipy CSR, all item columns; blocks in rank order -- `take_rank_rows` cuts one out of a full matrix) and with
+    model.user_factors / item_factors holding the same full initial factors on every rank.  The item-side shard is built
+    by `shard_transpose` (no rank holds or transposes the full matrix); all ranks finish with identical full factors.
+    Returns (u_off, i_off)."""
     import time
 
-    import implicit_amd.gpu as gpu
+    if backend is None:
+        import implicit_amd.gpu as gpu
 
-    r, n = comm.rank, comm.nranks
-    u_off = shard_offsets(Cui.shape[0], n, weights=np.diff(Cui.indptr))
-    i_off = shard_offsets(Ciu.shape[0], n, weights=np.diff(Ciu.indptr))
-    mine_u, mine_i = Cui[u_off[r]:u_off[r + 1]], Ciu[i_off[r]:i_off[r + 1]]
-    if chunks is None:
-        chunks = 4 if n > 1 else 1
-    if chunks > 1:
-        Cu = [gpu.CSRMatrix(c) for c in split_rows(mine_u, chunks)]
-        Ci = [gpu.CSRMatrix(c) for c in split_rows(mine_i, chunks)]
+        backend, csr = GpuBackend(gpu, solver=model.solver, nranks=comm.nranks), gpu.CSRMatrix
+        gram = gpu.Matrix.zeros(model.factors, model.factors)
     else:
-        Cu, Ci = gpu.CSRMatrix(mine_u), gpu.CSRMatrix(mine_i)
-    backend = GpuBackend(gpu, solver=model.solver, nranks=n)
-    gram = gpu.Matrix.zeros(model.factors, model.factors)
-    X, Y = model.user_factors, model.item_factors
-    for it in range(model.iterations):
-        t0 = time.time()
-        iteration(backend, comm, Cu, Ci, X, Y, u_off, i_off, gram, model.regularization, model.cg_steps)
-        if callback:
-            gpu.synchronize()
-            callback(it, time.time() - t0, None)
-    gpu.synchronize()
-    comm.barrier()
+        gram = backend.upload(np.zeros((model.factors, model.factors), dtype=np.float32))
+    n = comm.nranks
+    try:
+        mine_i, u_off, i_off = shard_transpose(comm, backend, Cui_rows)
+        X, Y = model.user_factors, model.item_factors
+        if X.shape[0] != u_off[-1] or Y.shape[0] != Cui_rows.shape[1]:
+            raise ValueError("user_factors / item_factors do not match the global matrix the shards add up to")
+        if chunks is None:
+            chunks = 4 if n > 1 else 1
+        if chunks > 1:
+            Cu = [csr(c) for c in split_rows(Cui_rows, chunks)]
+            Ci = [csr(c) for c in split_rows(mine_i, chunks)]
+        else:
+            Cu, Ci = csr(Cui_rows), csr(mine_i)
+        backend.deferred(True)  # one host wait per iteration: nothing below reads device results on the host
+        for it in range(model.iterations):
+            t0 = time.time()
+            iteration(backend, comm, Cu, Ci, X, Y, u_off, i_off, gram, model.regularization, model.cg_steps)
+            backend.fence()
+            if callback:
+                callback(it, time.time() - t0, None)
+        backend.deferred(False)
+        comm.barrier()
+    finally:
+        if hasattr(backend, "close"):
+            backend.close()
+    return u_off, i_off
 
 
 # ---- synthetic workloads + benchmark driver (bench.py --gpus N) -------------------------------------------------------
@@ -209,6 +331,7 @@ def bench(args, gpu, shapes, factors, reg, cg_steps, roofline_fn=None):
     t_gen = time.time() - t0
 
     backend = GpuBackend(gpu, nranks=world)
+    no_iter_fence = bool(os.environ.get("IMP_SHARD_NO_ITER_FENCE"))
     # K row chunks per half sweep: chunk k is exchanged over xGMI while chunk k+1 is solved (one chunk = blocking form)
     pipelined = world > 1 or os.environ.get("IMP_FORCE_SHARDED")
     chunks = max(1, int(os.environ.get("IMP_SHARD_CHUNKS", "4"))) if pipelined else 1
@@ -223,8 +346,12 @@ def bench(args, gpu, shapes, factors, reg, cg_steps, roofline_fn=None):
     gram = gpu.Matrix.zeros(factors, factors)
     total_nnz = rank_sum(comm, gpu, Cui.nnz)
 
+    backend.deferred(True)  # a whole iteration is queued without a host wait (K chunks, their exchanges, two all-reduces)
+
     def step():
         iteration(backend, comm, Cui_d, Ciu_d, X, Y, u_off, i_off, gram, reg, cg_steps)
+        if not no_iter_fence:
+            gpu.synchronize()  # as fit_sharded: one host wait per iteration (reports a timed-out cluster exchange)
 
     def fence():
         gpu.synchronize()
@@ -289,4 +416,5 @@ def bench(args, gpu, shapes, factors, reg, cg_steps, roofline_fn=None):
         "setup_s": {"generate": t_gen},
     }
     fence()
+    backend.close()
     return result

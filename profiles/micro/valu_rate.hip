@@ -3,10 +3,20 @@
 // build: hipcc --offload-arch=gfx950 -O3 valu_rate.hip -o valu_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <algorithm>
 #include <vector>
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
-template <int MODE> __global__ __launch_bounds__(1024) void rate_kernel(float *out, int iters) {
+// MODE 0-5: see main(); 6: v_fmac_f32 (VOP2, two vector sources + accumulator); 7: v_fmac_f32 with a scalar multiplicand;
+// 8: v_mul_f32 (two vector sources); 9: v_mov_b32.  `where` (one word per workgroup) receives HW_ID | XCC_ID << 16 so that the
+// host can count the CUs the grid really ran on (a rate per SIMD means nothing if two workgroups shared a CU and another idled).
+template <int MODE> __global__ __launch_bounds__(1024) void rate_kernel(float *out, int iters, unsigned *where) {
+  if (threadIdx.x == 0) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    where[blockIdx.x] = (hw & 0xff00u) | ((xcc & 0xfu) << 16);  // cu_id 11:8, sh_id 12, se_id 15:13
+  }
   float a[16], b = threadIdx.x * 1e-9f, c = 1.0f;
   typedef float f2 __attribute__((ext_vector_type(2)));
   f2 p[8];
@@ -37,6 +47,30 @@ template <int MODE> __global__ __launch_bounds__(1024) void rate_kernel(float *o
     } else if constexpr (MODE == 4) {  // dependent chain of v_fma
 #pragma unroll
       for (int r = 0; r < 64; ++r) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[0]) : "v"(c), "v"(b));
+    } else if constexpr (MODE == 6) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "v"(c), "v"(b));
+    } else if constexpr (MODE == 7) {
+      float sc = __builtin_amdgcn_readfirstlane(c);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "s"(sc), "v"(b));
+    } else if constexpr (MODE == 8) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+    } else if constexpr (MODE == 9) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+          asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(a[i + 1]));
+          asm volatile("v_mov_b32 %0, %1" : "+v"(a[i + 1]) : "v"(b));
+        }
     } else if constexpr (MODE == 5) {  // alternating pk / plain, independent
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -69,24 +103,32 @@ __global__ __launch_bounds__(64) void lds_latency_kernel(unsigned long long *out
   if (threadIdx.x == 0) out[0] = t1 - t0, out[1] = idx;
 }
 
-template <int MODE> int run(const char *name, int waves_per_cu, int instr_per_iter, double flops_per_instr_lane) {
+template <int MODE> int run(const char *name, int waves_per_cu, int instr_per_iter, double flops_per_instr_lane, int grid_mult = 1) {
   float *out;
-  const int cus = 256, iters = 20000;
+  unsigned *where;
+  const int cus = 256 * grid_mult, iters = 20000 / grid_mult;
   CHECK(hipMalloc(&out, (size_t)cus * 1024 * 4));
+  CHECK(hipMalloc(&where, (size_t)cus * 4));
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-  rate_kernel<MODE><<<cus, waves_per_cu * 64>>>(out, 100);
+  rate_kernel<MODE><<<cus, waves_per_cu * 64>>>(out, 100, where);
   CHECK(hipEventRecord(e0));
-  rate_kernel<MODE><<<cus, waves_per_cu * 64>>>(out, iters);
+  rate_kernel<MODE><<<cus, waves_per_cu * 64>>>(out, iters, where);
   CHECK(hipEventRecord(e1));
   CHECK(hipEventSynchronize(e1));
   float ms;
   CHECK(hipEventElapsedTime(&ms, e0, e1));
+  std::vector<unsigned> h(cus);
+  CHECK(hipMemcpy(h.data(), where, (size_t)cus * 4, hipMemcpyDeviceToHost));
+  std::sort(h.begin(), h.end());
+  const int distinct = (int)(std::unique(h.begin(), h.end()) - h.begin());
   double instr = (double)cus * waves_per_cu * iters * instr_per_iter;
-  double cycles_per_instr_per_simd = ms * 1e-3 * 2.4e9 / (instr / (cus * 4.0));
-  printf("%-28s waves/CU %2d: %.3f ms, %.2f cycles per wave-instruction per SIMD (at 2.4 GHz), %.1f TFLOP/s\n", name, waves_per_cu, ms,
-         cycles_per_instr_per_simd, instr * 64 * flops_per_instr_lane / (ms * 1e-3) / 1e12);
+  // per SIMD of the CUs that were really used (`distinct`), not of the 256 the grid was sized for
+  double cycles_per_instr_per_simd = ms * 1e-3 * 2.4e9 / (instr / (distinct * 4.0));
+  printf("%-28s %4d wgs x %2d waves on %3d distinct CUs: %.3f ms, %.2f cycles per wave-instruction per SIMD (at 2.4 GHz), %.1f TFLOP/s\n", name,
+         cus, waves_per_cu, distinct, ms, cycles_per_instr_per_simd, instr * 64 * flops_per_instr_lane / (ms * 1e-3) / 1e12);
   CHECK(hipFree(out));
+  CHECK(hipFree(where));
   return 0;
 }
 
@@ -97,6 +139,14 @@ int main() {
     run<2>("v_fmac_f32_dpp newbcast", w, 64, 2);
     run<5>("pk + plain alternating", w, 64, 3);
   }
+  // saturating grids: 8 workgroups per CU's worth of 4-wave workgroups (8 waves per SIMD whatever the placement)
+  run<0>("v_fma_f32 (independent)", 4, 64, 2, 8);
+  run<1>("v_pk_fma_f32 (independent)", 4, 64, 4, 8);
+  run<6>("v_fmac_f32 vop2 v,v", 4, 64, 2, 8);
+  run<7>("v_fmac_f32 vop2 s,v", 4, 64, 2, 8);
+  run<8>("v_mul_f32 v,v", 4, 64, 1, 8);
+  run<9>("v_mov_b32", 4, 64, 0, 8);
+  run<2>("v_fmac_f32_dpp newbcast", 4, 64, 2, 8);
   run<3>("v_pk_fma_f32 dependent", 4, 64, 4);
   run<4>("v_fma_f32 dependent", 4, 64, 2);
   unsigned long long *o;
