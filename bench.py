@@ -11,8 +11,11 @@ resident in HBM before the timed region starts.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 N = 1 workload: BASELINE configs[2] -- last.fm-360K-shaped synthetic CSR (358,868 users x 292,385
-items, ~17.5M nnz requested), factors=128, CG cg_steps=3, fp32.  N > 1: weak scaling -- every rank
-owns one such shard of users and of items (global matrix = N x users, N x items, N x nnz).
+items, ~17.5M nnz requested), factors=128, CG cg_steps=3, fp32.  N > 1: STRONG scaling on BASELINE
+configs[3] (10M users x 1M items x 500M nnz, f=128; the matrix is a fixed 8 x 8 grid of blocks, so
+N = 1, 2, 4, 8 factorise the same matrix; users and items row-sharded over the ranks).  The one-GPU
+point of that curve is `--gpus 1 --shape c4` (the same sharded driver with one rank); the default
+N = 1 line also carries it as the extra `c4_full_1gpu`.  `--weak`: one configs[2]-shaped shard per rank.
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed on the library
 stream inside the timed region) and `cpu_baseline` (the reference's own Cython CPU solver from
@@ -225,7 +228,9 @@ def main():
     if args.scale != 1.0:
         users, items, nnz_target = int(users * args.scale), int(items * args.scale), int(nnz_target * args.scale)
 
-    if world > 1 or os.environ.get("IMP_FORCE_SHARDED"):  # the env knob exercises the N>1 code path with one rank
+    # N > 1, or the one-GPU point of the configs[3] strong-scaling curve (`--gpus 1 --shape c4`); the env knob exercises
+    # the N > 1 code path (chunked, pipelined exchange) with one rank
+    if world > 1 or args.shape == "c4" or os.environ.get("IMP_FORCE_SHARDED"):
         from implicit_amd.gpu import sharded
 
         def rank0_roofline(Cui, Ciu, timed, steps):
@@ -395,7 +400,7 @@ def main():
                               "wall times of 3 iterations after 1 warm-up); `value` above is configs[2] only")
         for name, fn in (("fit_c3", lambda: extra_fit(gpu, Cui)), ("fp16_c3", lambda: extra_fp16(gpu, Cui, Ciu, X0, Y0)),
                          ("c2", lambda: extra_c2(gpu, SHAPES)),
-                         ("c5", lambda: extra_c5(gpu, SHAPES)), ("c4_shard", lambda: extra_c4_shard(gpu, SHAPES))):
+                         ("c5", lambda: extra_c5(gpu, SHAPES)), ("c4", lambda: extra_c4(gpu, SHAPES))):
             t0 = time.time()
             try:
                 out.update(fn())
@@ -585,41 +590,70 @@ def extra_c5(gpu, SHAPES):
                                  "note": "ids/scores returned to host memory per batch"}}
 
 
-def extra_c4_shard(gpu, SHAPES):
-    """BASELINE configs[3] (10M x 1M x 500M nnz, f = 128, 8 GPUs): what rank 0 of the 8-GPU run computes per iteration, on
-    this one GPU -- its 1.25M user rows against the item replica and its 125K item rows against the 10M-row user replica
-    (no exchange: the RCCL part needs the other seven)."""
+def extra_c4(gpu, SHAPES):
+    """BASELINE configs[3] (10M x 1M x 500M nnz, f = 128) on this one GPU, two ways:
+      c4_full_1gpu  the WHOLE matrix (14 GB of the 288): the one-GPU point of the strong-scaling curve `bench.py --gpus N`
+                    measures for N > 1 (same matrix: the 8 x 8 block grid does not depend on N);
+      c4_shard      what rank 0 of the 8-GPU run computes per iteration -- its 1.25M user rows against the item replica
+                    and its 125K item rows against the 10M-row user replica (no exchange: that needs the other seven)."""
     from implicit_amd.synthetic import grid_shards
 
     users, items, nnz, gamma = SHAPES["c4"]
     t0 = time.time()
-    Cui, Ciu, u_off, i_off = grid_shards(0, 8, users, items, nnz, 8, gamma=gamma, seed=42)
+    Cui, Ciu, _, _ = grid_shards(0, 1, users, items, nnz, 8, gamma=gamma, seed=42)
     t_gen = time.time() - t0
     f = FACTORS
     X = gpu.RandomState(7).uniform(users, f, 0.0, 0.01)
     Y = gpu.RandomState(8).uniform(items, f, 0.0, 0.01)
-    Cd, Ctd = gpu.CSRMatrix(Cui), gpu.CSRMatrix(Ciu)
-    Xm, Ym = X[int(u_off[0]):int(u_off[1])], Y[int(i_off[0]):int(i_off[1])]
     gram = gpu.Matrix.zeros(f, f)
     solver = gpu.LeastSquaresSolver()
+    out = {}
 
-    def step():
+    t0 = time.time()
+    Cd, Ctd = gpu.CSRMatrix(Cui), gpu.CSRMatrix(Ciu)
+    t_upload = time.time() - t0
+
+    def full_step():
+        solver.calculate_yty(Y, gram, REG)
+        solver.least_squares(Cd, X, gram, Y, CG_STEPS)
+        solver.calculate_yty(X, gram, REG)
+        solver.least_squares(Ctd, Y, gram, X, CG_STEPS)
+
+    t, kernels = _time_iterations(gpu, full_step, iters=2)
+    gb = _iteration_bytes(Cui, Ciu, f) / 1e9
+    out["c4_full_1gpu"] = {"workload": "BASELINE configs[3] whole on ONE GPU: %d x %d, %d nnz, f=128, CG cg_steps=%d (strong-scaling "
+                                       "base of `bench.py --gpus N`)" % (users, items, Cui.nnz, CG_STEPS),
+                           "ms_per_iter": 1e3 * t, "updates_per_s": (users + items) / t,
+                           "roofline": {"bound": "hbm", "achieved": gb / t, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": gb / t / HBM_PEAK_GBS, "algorithmic_GB_per_iter": gb},
+                           "kernels_ms_per_iter": kernels, "generate_s": t_gen, "upload_and_schedule_s": t_upload}
+    del Cd, Ctd
+
+    # rank 0's eighth: rows [0, users/8) of Cui, rows [0, items/8) of Ciu (the grid's first block row / block column)
+    nu, ni = users // 8, items // 8
+    Cui_s, Ciu_s = Cui[:nu], Ciu[:ni]
+    del Cui, Ciu
+    Cd, Ctd = gpu.CSRMatrix(Cui_s), gpu.CSRMatrix(Ciu_s)
+    Xm, Ym = X[0:nu], Y[0:ni]
+
+    def shard_step():
         solver.calculate_yty(Ym, gram, REG)      # the rank's partial gramian (all-reduced over xGMI in the real run)
         solver.least_squares(Cd, Xm, gram, Y, CG_STEPS)
         solver.calculate_yty(Xm, gram, REG)
         solver.least_squares(Ctd, Ym, gram, X, CG_STEPS)
 
-    t, kernels = _time_iterations(gpu, step, iters=2)
-    gb = _iteration_bytes(Cui, Ciu, f) / 1e9
+    t, kernels = _time_iterations(gpu, shard_step, iters=2)
+    gb = _iteration_bytes(Cui_s, Ciu_s, f) / 1e9
     xgmi_gb = 7.0 / 8.0 * (users + items) * f * 4 / 1e9
-    return {"c4_shard": {"workload": "rank 0 of BASELINE configs[3] on 8 GPUs: %d user rows (%d nnz) + %d item rows (%d nnz), f=128, "
-                                     "CG cg_steps=%d" % (Cui.shape[0], Cui.nnz, Ciu.shape[0], Ciu.nnz, CG_STEPS),
-                         "compute_ms_per_iter": 1e3 * t,
-                         "roofline": {"bound": "hbm", "achieved": gb / t, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                      "frac": gb / t / HBM_PEAK_GBS, "algorithmic_GB_per_iter": gb},
-                         "projected_8gpu_updates_per_s_if_exchange_hidden": (users + items) / t,
-                         "exchange_GB_received_per_rank_per_iter": xgmi_gb,
-                         "kernels_ms_per_iter": kernels, "generate_s": t_gen}}
+    out["c4_shard"] = {"workload": "rank 0 of BASELINE configs[3] on 8 GPUs: %d user rows (%d nnz) + %d item rows (%d nnz), f=128, "
+                                   "CG cg_steps=%d" % (Cui_s.shape[0], Cui_s.nnz, Ciu_s.shape[0], Ciu_s.nnz, CG_STEPS),
+                       "compute_ms_per_iter": 1e3 * t,
+                       "roofline": {"bound": "hbm", "achieved": gb / t, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": gb / t / HBM_PEAK_GBS, "algorithmic_GB_per_iter": gb},
+                       "projected_8gpu_updates_per_s_if_exchange_hidden": (users + items) / t,
+                       "exchange_GB_received_per_rank_per_iter": xgmi_gb,
+                       "kernels_ms_per_iter": kernels}
+    return out
 
 
 def cpu_topk_baseline(Cui, X, Y, k=10, seconds=8.0):

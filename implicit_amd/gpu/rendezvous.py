@@ -6,7 +6,8 @@ region -- goes through the RCCL communicator itself (implicit_amd.gpu.Comm).
 The launcher's environment is the one `python -m torch.distributed.run` / torchrun sets (the bench driver uses
 it): RANK, WORLD_SIZE, LOCAL_RANK, MASTER_ADDR, MASTER_PORT.  MASTER_PORT itself belongs to the launcher's own
 store, so the exchange listens on MASTER_PORT + 1 + IMP_RDZV_PORT_OFFSET (override the absolute port with
-IMP_RDZV_PORT) or, if that is taken, on one of the 7 ports after it; peers are recognised by a magic handshake.  No reference counterpart (implicit/gpu/als.cu:169 "TODO: multi-gpu support").
+IMP_RDZV_PORT) or, if that is taken, on one of the 7 ports after it; peers are recognised by a magic + job-token
+handshake (two jobs with overlapping candidate ranges cannot serve each other) and count once they ACK the payload.  No reference counterpart (implicit/gpu/als.cu:169 "TODO: multi-gpu support").
 """
 import os
 import socket
@@ -48,43 +49,81 @@ def _recv_exact(conn, n):
     return buf
 
 
+def job_token(world):
+    """16 bytes that identify THIS job: two jobs on one host whose candidate port ranges overlap (adjacent MASTER_PORTs)
+    must not hand each other their communicator ids.  Derived from what every rank of a job shares and no other job
+    does: the launcher's endpoint, its run id and the world size (IMP_RDZV_TOKEN overrides)."""
+    import hashlib
+
+    seed = os.environ.get("IMP_RDZV_TOKEN") or "|".join([
+        os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "29500"),
+        os.environ.get("TORCHELASTIC_RUN_ID", ""), str(world)])
+    return hashlib.sha256(seed.encode()).digest()[:16]
+
+
+_HELLO_TIMEOUT = 5.0  # a connection that does not say hello at once is not one of ours (port scan, health check)
+_ACK = b"IMPRDZVK"
+
+
+def _serve(srv, payload, world, token, deadline):
+    """Rank 0: hand `payload` to each of the world - 1 peers.  One connection at a time; a stray, silent, foreign-job or
+    vanished connection costs at most _HELLO_TIMEOUT and never counts; a peer counts once it has ACKed the payload."""
+    served = set()
+    while len(served) < world - 1:
+        left = deadline - time.time()
+        if left <= 0:
+            raise TimeoutError(f"rendezvous: only {len(served)} of {world - 1} peers arrived")
+        srv.settimeout(min(left, 30.0))
+        try:
+            conn, _ = srv.accept()
+        except socket.timeout:
+            continue
+        with conn:
+            try:
+                conn.settimeout(_HELLO_TIMEOUT)
+                hello = _recv_exact(conn, len(_MAGIC) + len(token) + 4)
+                if hello[:len(_MAGIC)] != _MAGIC or hello[len(_MAGIC):len(_MAGIC) + len(token)] != token:
+                    continue  # not one of ours / another job's peer: closing without the magic makes it try the next port
+                peer = struct.unpack("<i", hello[len(_MAGIC) + len(token):])[0]
+                if not 0 < peer < world:
+                    continue
+                conn.settimeout(30.0)
+                conn.sendall(_MAGIC + token + struct.pack("<q", len(payload)) + payload)
+                if _recv_exact(conn, len(_ACK)) == _ACK:
+                    served.add(peer)
+            except (ConnectionError, OSError):
+                continue  # that peer retries
+
+
 def broadcast_bytes(payload, rank, world, timeout=300.0):
     """Rank 0 passes `payload` (bytes), the others pass None; every rank returns rank 0's bytes."""
     if world == 1:
         return payload
     addr, ports = _endpoints()
+    token = job_token(world)
     deadline = time.time() + timeout
     if rank == 0:
         srv, last = None, None
         for port in ports:
-            cand = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-            cand.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            try:
-                cand.bind(("", port))
-                cand.listen(world)
-                srv = cand
+            for host in (addr, ""):  # MASTER_ADDR's interface where this host owns it, every interface otherwise
+                cand = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                cand.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                try:
+                    cand.bind((host, port))
+                    cand.listen(world)
+                    srv = cand
+                    break
+                except OSError as e:  # taken (or not a local address): next choice
+                    last = e
+                    cand.close()
+                    if getattr(e, "errno", None) == 98:  # EADDRINUSE: the wildcard bind would fail alike
+                        break
+            if srv is not None:
                 break
-            except OSError as e:  # taken: next candidate
-                last = e
-                cand.close()
         if srv is None:
             raise OSError(f"rendezvous: none of the ports {ports[0]}..{ports[-1]} could be bound: {last}")
-        srv.settimeout(timeout)
-        served = set()
         try:
-            while len(served) < world - 1:
-                conn, _ = srv.accept()
-                with conn:
-                    conn.settimeout(timeout)
-                    try:
-                        hello = _recv_exact(conn, len(_MAGIC) + 4)
-                    except (ConnectionError, OSError):
-                        continue
-                    if hello[:len(_MAGIC)] != _MAGIC:
-                        continue  # not one of ours
-                    peer = struct.unpack("<i", hello[len(_MAGIC):])[0]
-                    conn.sendall(_MAGIC + struct.pack("<q", len(payload)) + payload)
-                    served.add(peer)
+            _serve(srv, payload, world, token, deadline)
         finally:
             srv.close()
         return payload
@@ -94,12 +133,14 @@ def broadcast_bytes(payload, rank, world, timeout=300.0):
             try:
                 with socket.create_connection((addr, port), timeout=5.0) as conn:
                     conn.settimeout(10.0)
-                    conn.sendall(_MAGIC + struct.pack("<i", rank))
-                    if _recv_exact(conn, len(_MAGIC)) != _MAGIC:
-                        continue  # somebody else's service on this port
-                    conn.settimeout(timeout)
+                    conn.sendall(_MAGIC + token + struct.pack("<i", rank))
+                    if _recv_exact(conn, len(_MAGIC) + len(token)) != _MAGIC + token:
+                        continue  # somebody else's service, or another job's rank 0, on this port
+                    conn.settimeout(timeout)  # it is ours: from here on wait as long as the job allows
                     n = struct.unpack("<q", _recv_exact(conn, 8))[0]
-                    return _recv_exact(conn, n)
+                    data = _recv_exact(conn, n)
+                    conn.sendall(_ACK)
+                    return data
             except (ConnectionError, OSError) as e:  # nobody there (yet), or a foreign service that does not answer
                 last = e
         time.sleep(0.2)

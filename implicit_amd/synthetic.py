@@ -103,25 +103,47 @@ def _as_int32_csr(m):
     return m
 
 
-def grid_shards(rank, nranks, users_total, items_total, nnz_total, grid, gamma=2.0, seed=42):
+def grid_shards(rank, nranks, users_total, items_total, nnz_total, grid, gamma=2.0, seed=42, workers=None):
     """Rank `rank`'s pieces of the block-composed matrix: (Cui_shard, Ciu_shard, u_offsets, i_offsets).
 
     Cui_shard: the rank's user rows x ALL items (global item ids); Ciu_shard: the rank's item rows x ALL users (global
-    user ids); *_offsets: the nranks + 1 row offsets of the shards (every rank computes the same ones)."""
+    user ids); *_offsets: the nranks + 1 row offsets of the shards (every rank computes the same ones).  Blocks are
+    independent, so they are generated (and transposed) by a pool of `workers` threads (default: up to 16; numpy's sort
+    and scipy's conversions release the GIL) -- one rank of one holds the whole matrix: 64 blocks at grid = 8."""
+    import concurrent.futures
+    import os
+
     if grid % nranks:
         raise ValueError(f"the block grid ({grid}) must be a multiple of the number of ranks ({nranks})")
     per = grid // nranks
     ub, ib = grid_bounds(users_total, grid), grid_bounds(items_total, grid)
     mine = range(rank * per, (rank + 1) * per)
-    cache = {}
+    row_blocks = [(s, t) for s in mine for t in range(grid)]
+    col_blocks = [(s, t) for t in mine for s in range(grid)]
+    wanted = sorted(set(row_blocks) | set(col_blocks))
+    if workers is None:
+        workers = max(1, min(16, (os.cpu_count() or 2) // (2 * max(1, nranks)), len(wanted)))
 
-    def block(s, t):
-        if (s, t) not in cache:
-            cache[(s, t)] = grid_block(users_total, items_total, nnz_total, grid, s, t, gamma, seed)
-        return cache[(s, t)]
+    def make(st):
+        s, t = st
+        b = grid_block(users_total, items_total, nnz_total, grid, s, t, gamma, seed)
+        return st, b, (b.T.tocsr() if st in col_set else None)
 
-    cui = sp.vstack([sp.hstack([block(s, t) for t in range(grid)], format="csr") for s in mine], format="csr")
-    ciu = sp.vstack([sp.hstack([block(s, t).T.tocsr() for s in range(grid)], format="csr") for t in mine], format="csr")
+    col_set = set(col_blocks)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=workers) as ex:
+        made = {st: (b, bt) for st, b, bt in ex.map(make, wanted)}
+
+        def stack_rows(s):
+            return sp.hstack([made[(s, t)][0] for t in range(grid)], format="csr")
+
+        def stack_cols(t):
+            return sp.hstack([made[(s, t)][1] for s in range(grid)], format="csr")
+
+        cui_rows = list(ex.map(stack_rows, mine))
+        ciu_rows = list(ex.map(stack_cols, mine))
+    del made
+    cui = sp.vstack(cui_rows, format="csr") if len(cui_rows) > 1 else cui_rows[0]
+    ciu = sp.vstack(ciu_rows, format="csr") if len(ciu_rows) > 1 else ciu_rows[0]
     u_off = ub[::per].copy()
     i_off = ib[::per].copy()
     return _as_int32_csr(cui), _as_int32_csr(ciu), u_off, i_off

@@ -57,6 +57,13 @@ int imp_get_device(int *device);
  * workgroups that must wait for a slot would do their whole share late.  factor > 1 launches factor x as many workgroups
  * with proportionally smaller shares; the hardware dispatcher then balances them over the slots that are free. */
 int imp_set_oversubscribe(int factor);
+int imp_get_oversubscribe(int *factor);
+/* NEW.  Every call is synchronous on return by default (convention above).  on = 1 puts the CURRENT device into deferred
+ * mode: imp_solver_calculate_yty, imp_solver_least_squares and imp_comm_allreduce_sum only queue their work on the library
+ * stream and return; the caller orders a whole iteration with one imp_device_synchronize (which also reports a timed-out
+ * cluster exchange).  The multi-GPU driver uses it so that a chunk's exchange is queued without a host round trip per chunk.
+ * on = 0 waits for everything queued and restores the default. */
+int imp_set_deferred_sync(int on);
 /* Measurement aid: occupies `workgroups` x (256 threads, 32 KB LDS) for about `microseconds` on a stream of its own. */
 int imp_debug_occupy(int workgroups, int microseconds);
 int imp_device_synchronize(void);
@@ -169,6 +176,11 @@ int imp_comm_allgather_rows(imp_comm *c, imp_matrix *full, const int64_t *row_of
  * _begin after each chunk and _end once, so chunk k travels over xGMI while chunk k+1 is being solved. */
 int imp_comm_allgather_rows_begin(imp_comm *c, imp_matrix *full, const int64_t *row_lo, const int64_t *row_hi);
 int imp_comm_allgather_rows_end(imp_comm *c);
+/* Personalised exchange of row ranges (set-up of a sharded fit: pieces of the transposed shard).  Rows
+ * [send_lo[p], send_hi[p]) of `send` go to rank p, where they arrive as rows [recv_lo[q], recv_hi[q]) of `recv` (q = the
+ * sender); the two matrices must have rows of the same byte size, bytes travel untouched.  Synchronous. */
+int imp_comm_alltoall_rows(imp_comm *c, const imp_matrix *send, const int64_t *send_lo, const int64_t *send_hi,
+                           imp_matrix *recv, const int64_t *recv_lo, const int64_t *recv_hi);
 int imp_comm_barrier(imp_comm *c);
 
 /* ---- NEW: measurement hooks (bench.py's roofline leg) -------------------------------------------- */

@@ -275,7 +275,8 @@ def test_model_fit_with_a_communicator(gpu, oracle):
     model2 = AlternatingLeastSquares(factors=64, regularization=0.05, random_state=5, use_gpu=True, iterations=2)
     Cui = C.astype(np.float32)
     model2._initial_factors(*C.shape)
-    sharded.fit_sharded(model2, Cui, Cui.T.tocsr(), comm, chunks=3)
+    sharded.fit_sharded(model2, Cui, comm, chunks=3)     # one rank: its block of user rows is the whole matrix
+    assert gpu.get_oversubscribe() == 1                   # the driver restores the launch shape it found
     assert rel(model2.user_factors.to_numpy(), plain.user_factors.to_numpy()) < 1e-5
     assert rel(model2.item_factors.to_numpy(), plain.item_factors.to_numpy()) < 1e-5
     import pickle

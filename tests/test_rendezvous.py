@@ -100,3 +100,70 @@ def test_occupied_first_port_is_skipped():
         stop.set()
         t.join(timeout=5)
         squatter.close()
+
+
+def _worker_job(rank, world, master_port, rdzv_port, payload, q, tag):
+    """Like _worker, with the rendezvous port pinned so that two jobs can be made to collide on purpose."""
+    sys.path.insert(0, ROOT)
+    os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank), "MASTER_ADDR": "127.0.0.1",
+                       "MASTER_PORT": str(master_port), "IMP_RDZV_PORT": str(rdzv_port)})
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("rendezvous", os.path.join(ROOT, "implicit_amd", "gpu", "rendezvous.py"))
+    rdzv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rdzv)
+    q.put((tag, rank, rdzv.broadcast_bytes(payload if rank == 0 else None, rank, world, timeout=60.0)))
+
+
+def test_two_jobs_with_overlapping_ports_do_not_cross():
+    """Job A's rank 0 listens on the very port job B's peers try first (adjacent MASTER_PORTs make the candidate ranges
+    overlap): the job token in the handshake makes B's peer walk on to B's own rank 0 instead of taking A's id."""
+    ctx = mp.get_context("spawn")
+    base = _free_port()
+    q = ctx.Queue()
+    a0 = ctx.Process(target=_worker_job, args=(0, 2, base, base + 1, b"A" * 128, q, "A"))
+    a0.start()                                    # A's rank 0 owns base + 1 ...
+    import time
+
+    time.sleep(1.0)
+    procs = [ctx.Process(target=_worker_job, args=(1, 2, base + 7, base + 1, None, q, "B")),   # ... B's peer tries it first
+             ctx.Process(target=_worker_job, args=(0, 2, base + 7, base + 1, b"B" * 128, q, "B")),  # B's rank 0: next free port
+             ctx.Process(target=_worker_job, args=(1, 2, base, base + 1, None, q, "A"))]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(4):
+        tag, rank, data = q.get(timeout=120)
+        got[(tag, rank)] = data
+    for p in [a0] + procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == {("A", 0): b"A" * 128, ("A", 1): b"A" * 128, ("B", 0): b"B" * 128, ("B", 1): b"B" * 128}
+
+
+def test_silent_stray_connection_does_not_stall_the_peers():
+    """A connection that never says hello (health check, port scan) is dropped after a few seconds and is not counted."""
+    import time
+
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    q = ctx.Queue()
+    r0 = ctx.Process(target=_worker, args=(0, 2, port, q))
+    r0.start()
+    stray = None
+    for _ in range(100):                          # wait for rank 0's listener, then sit on a connection without a word
+        try:
+            stray = socket.create_connection(("127.0.0.1", port + 1), timeout=1.0)
+            break
+        except OSError:
+            time.sleep(0.1)
+    assert stray is not None
+    r1 = ctx.Process(target=_worker, args=(1, 2, port, q))
+    r1.start()
+    t0 = time.time()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    stray.close()
+    for p in (r0, r1):
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == {0: bytes(range(128)), 1: bytes(range(128))} and time.time() - t0 < 40
