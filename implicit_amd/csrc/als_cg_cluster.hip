@@ -33,7 +33,10 @@ namespace imp {
 
 namespace {
 constexpr int kClusterWaves = 8;       // wavefronts per workgroup
-constexpr int kSpinLimit = 1 << 19;    // polls of one exchange before giving up (~1 s)
+// A poll gives up by the constant-rate wall clock (100 MHz), not by counting polls: a partly resident cluster may have
+// to wait for a whole share of the clusters ahead of it (and, beside a resident collective, for the slots that holds) --
+// milliseconds; 4 s is far beyond any legitimate wait and still turns a lost member into an error instead of a hang.
+constexpr long long kWaitLimitTicks = 400'000'000ll;
 }  // namespace
 
 // STATS (debug, IMP_CG_STATS=1): s_memtime ticks summed over waves -- [0] row start -> tile resident  [1] passes
@@ -115,6 +118,7 @@ __global__ __launch_bounds__(64 * kClusterWaves, 4) void als_cg_cluster_kernel(
     if (wave < CL) {  // wave w collects members w, w + 8, ...: all of them in flight together
       unsigned long long granule[PER][FC];
       int spins = 0;
+      long long wait_since = 0;
       while (true) {
         bool ok = true;
 #pragma unroll
@@ -126,7 +130,13 @@ __global__ __launch_bounds__(64 * kClusterWaves, 4) void als_cg_cluster_kernel(
             ok = ok && ((unsigned)(granule[k][c] >> 32) & 0x0FFFFFFFu) == seq;
           }
         if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-        if (faulted || ++spins > kSpinLimit) {  // never expected: give up instead of hanging the device
+        bool expired = false;
+        if ((++spins & 255) == 0) {  // the clock is read once per 256 polls
+          const long long now = (long long)wall_clock64();
+          if (wait_since == 0) wait_since = now;
+          expired = now - wait_since > kWaitLimitTicks;
+        }
+        if (faulted || expired) {  // never expected: give up instead of hanging the device
           if (!faulted && lane == 0) __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           faulted = true;
           break;

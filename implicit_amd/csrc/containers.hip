@@ -633,6 +633,7 @@ int imp_csr_create(int32_t rows, int32_t cols, int64_t nnz, const int32_t *indpt
       lp.seg_row.upload(seg_row.data(), seg_row.size());
       lp.seg_begin.upload(seg_begin.data(), seg_begin.size());
       lp.seg_end.upload(seg_end.data(), seg_end.size());
+      sync();  // the uploads read pageable host vectors that die with this scope
     };
     build_plan(n_long, m->plan_all, stripe_reuse, segment);
     // rows within reach of the cluster-resident kernels (als_cg_cluster.hip) leave the streamed plan of the f = 64 / 128 path

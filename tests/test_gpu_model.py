@@ -155,6 +155,48 @@ def test_fit_matches_oracle_fit_free_running(gpu, oracle):
     assert ex < 1e-3 and ey < 1e-3
 
 
+def test_lockstep_fit_every_half_sweep_f128(gpu, oracle):
+    """SURVEY 8(c)-2, the primary 1e-4 gate: a 15-iteration oracle fit at f = 128 (default cold start 0.01 U(0,1), draw
+    order of cpu/als.py:144-147); at EVERY half sweep -- user and item side, 30 in all -- the oracle's current (X, Y) is
+    handed to the GPU and that single sweep is compared with the oracle's next state.  From the second iteration on the
+    states are trained ones (near-zero residuals, the rsold / rsnew < 1e-20 exits, near-duplicate rows) and the bar is
+    1e-4 (expected ~1e-5); the ill-conditioned cold first iteration is judged against the same sweep in fp64 with the
+    oracle's own distance from it as the yardstick."""
+    from implicit_amd.synthetic import synthetic_csr
+
+    f, reg, iters = 128, 0.01, 15
+    C = synthetic_csr(6000, 3500, 260_000, seed=17, neg_frac=0.03, empty_frac=0.01)
+    Ct = C.T.tocsr()
+    rng = np.random.default_rng(23)
+    X = rng.random((C.shape[0], f), dtype=np.float32) * 0.01
+    Y = rng.random((C.shape[1], f), dtype=np.float32) * 0.01
+    solver = gpu.LeastSquaresSolver()
+    Cd, Ctd = gpu.CSRMatrix(C), gpu.CSRMatrix(Ct)
+    gram = gpu.Matrix.zeros(f, f)
+    worst = 0.0
+    for it in range(iters):
+        for side, (M, Md) in enumerate(((C, Cd), (Ct, Ctd))):
+            mine, other = (X, Y) if side == 0 else (Y, X)
+            md, od = gpu.Matrix(mine), gpu.Matrix(other)
+            solver.calculate_yty(od, gram, reg)
+            solver.least_squares(Md, md, gram, od, 3)
+            got = md.to_numpy()
+            nxt = mine.copy()
+            oracle.least_squares_cg(M, nxt, other, reg, cg_steps=3)      # the oracle's own next state (its own gramian)
+            err = np.linalg.norm(got - nxt) / np.linalg.norm(nxt)
+            if it == 0:
+                exact = oracle.least_squares_cg_f64(M, mine, other, reg, cg_steps=3)
+                e_gpu = np.linalg.norm(got - exact) / np.linalg.norm(exact)
+                e_oracle = np.linalg.norm(nxt - exact) / np.linalg.norm(exact)
+                print(f"cold iteration, side {side}: gpu-vs-oracle {err:.2e}, gpu-vs-fp64 {e_gpu:.2e}, oracle-vs-fp64 {e_oracle:.2e}")
+                assert e_gpu < max(1e-4, 1.5 * e_oracle)
+            else:
+                worst = max(worst, err)
+                assert err < 1e-4, (it, side, err)
+            mine[...] = nxt                                               # teacher forcing: the fit continues on the oracle's state
+    print(f"lockstep fit f=128: worst half sweep of iterations 2..{iters}: {worst:.2e}")
+
+
 def test_callbacks_loss_and_zero_iterations(gpu):
     user_items = get_checker_board(30)
     seen = []
