@@ -103,6 +103,39 @@ def test_config3_cg_half_sweeps_full_size(gpu, oracle):
     _sampled_rows_check(gpu, oracle, C.T.tocsr(), Y0, X1, reg, solve_gpu, solve_oracle, reference=reference)
 
 
+def test_config3_from_a_trained_state(gpu, oracle):
+    """configs[2] at full size, sweeps taken from a TRAINED state (5 ALS iterations from the default cold start run on
+    the GPU first): residuals near zero, the rsold / rsnew < 1e-20 exits taken by real rows, near-duplicate factor rows
+    of rarely seen items -- against the oracle and the compiled reference on sampled rows, both orientations."""
+    C = named("lastfm360k")
+    Ct = C.T.tocsr()
+    f, reg = 128, 0.01
+    rng = np.random.default_rng(7)
+    Xd = gpu.Matrix(rng.random((C.shape[0], f), dtype=np.float32) * 0.01)
+    Yd = gpu.Matrix(rng.random((C.shape[1], f), dtype=np.float32) * 0.01)
+    solver, gram = gpu.LeastSquaresSolver(), gpu.Matrix.zeros(f, f)
+    Cd, Ctd = gpu.CSRMatrix(C), gpu.CSRMatrix(Ct)
+    for _ in range(5):
+        solver.calculate_yty(Yd, gram, reg)
+        solver.least_squares(Cd, Xd, gram, Yd, 3)
+        solver.calculate_yty(Xd, gram, reg)
+        solver.least_squares(Ctd, Yd, gram, Xd, 3)
+    X0, Y0 = Xd.to_numpy(), Yd.to_numpy()
+    del Cd, Ctd
+
+    def solve_gpu(Cm, Xm, Ym):
+        solver.calculate_yty(Ym, gram, reg)
+        solver.least_squares(Cm, Xm, gram, Ym, 3)
+        solve_gpu.gram = gram.to_numpy()
+
+    def solve_oracle(Csub, Xsub, Y):
+        oracle.least_squares_cg(Csub, Xsub, Y, reg, cg_steps=3, YtY=solve_gpu.gram)
+
+    reference = lambda Csub, Xsub, Y: _reference_cg(Csub, Xsub, Y, reg)  # noqa: E731
+    X1 = _sampled_rows_check(gpu, oracle, C, X0, Y0, reg, solve_gpu, solve_oracle, reference=reference)
+    _sampled_rows_check(gpu, oracle, Ct, Y0, X1, reg, solve_gpu, solve_oracle, reference=reference)
+
+
 def test_config2_cholesky_scaled(gpu, oracle):
     """BASELINE configs[1] shape at 1/5 scale (200K x 20K, 10M nnz), f=64, Cholesky."""
     C = named("c2", scale=0.2)
