@@ -585,87 +585,7 @@ __device__ __forceinline__ void tile_pass(f32x2 (&y)[8][F / 32], float *cw, int 
   reduce_expanded<F>(aes, acc);
 }
 
-// The lock-step pass with BOTH pipes busy: between the two workgroup barriers of a pass a wave used to run its share of the
-// 16-row gramian product (MFMA) and then its own row's tile entries (VALU) -- every wave of a SIMD in the same phase, so
-// the matrix pipe idled during the tile work and the vector pipe during the product.  The tile part needs only the wave's
-// own operand, which is published before the product starts: here the two are ONE instruction stream, each MFMA
-// (32 matrix-pipe cycles) followed by a quarter of a pair of tile steps (its packed FMAs and DPP adds issue while the
-// MFMA executes).  mfma(m) issues MFMA number m of the wave's 4 KB; the caller supplies it so that this function stays
-// independent of the product's layout.
-template <int F, int NM, bool FIRST, bool LAST, typename ST, typename Mfma>
-__device__ __forceinline__ void tile_pass_mfma(f32x2 (&y)[8][F / 32], float *cw, int cnt, const float *vrow, float (&acc)[F / 64], int lane,
-                                               int cnt_nx, int &col_nx, float &c_nx, const ST *__restrict__ Y, Mfma &&mfma) {
-  constexpr int FE = F / 16, H = FE / 2, PER = NM / 4;  // MFMAs per pair of tile steps
-  static_assert(NM % 4 == 0 && (PER == 1 || PER == 4), "MFMAs per pass");
-  if constexpr (LAST) {
-    col_nx = opaque(col_nx);
-    c_nx = __int_as_float(opaque(__float_as_int(c_nx)));
-  }
-  f32x2 ve[H], ae[H];
-  const float *cwg;
-  {
-    const int ln = opaque(lane);
-    const int g = ln >> 4, m = ln & 15;
-#pragma unroll
-    for (int e = 0; e < FE; e += 4) {
-      const float4 t = *reinterpret_cast<const float4 *>(vrow + 16 * e + 4 * m);
-      ve[e / 2] = f32x2{t.x, t.y}, ve[e / 2 + 1] = f32x2{t.z, t.w};
-    }
-    cwg = cw + g;
-  }
-#pragma unroll
-  for (int h = 0; h < H; ++h) ae[h] = f32x2{0.f, 0.f};
-  auto partial = [&](int q) {
-    f32x2 s = y[q][0] * ve[0];
-#pragma unroll
-    for (int h = 1; h < H; ++h) s = __builtin_elementwise_fma(y[q][h], ve[h], s);
-    return s.x + s.y;
-  };
-  auto axpy = [&](int q, float w) {
-    const f32x2 w2 = {w, w};
-#pragma unroll
-    for (int h = 0; h < H; ++h) ae[h] = __builtin_elementwise_fma(w2, y[q][h], ae[h]);
-  };
-  static_for<4>([&](auto Pc) {
-    constexpr int P = decltype(Pc)::value;
-    if (8 * P < cnt) {  // wave-uniform
-      const float cm1_0 = cwg[8 * P], cm1_1 = cwg[8 * P + 4];
-      float cp_0 = 0.f, cp_1 = 0.f;
-      if constexpr (FIRST) cp_0 = cwg[32 + 8 * P], cp_1 = cwg[32 + 8 * P + 4];
-      mfma(idx_t<PER * P>{});
-      __builtin_amdgcn_sched_barrier(0);
-      const float d0 = partial(2 * P);
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (PER == 4) mfma(idx_t<PER * P + 1>{});
-      __builtin_amdgcn_sched_barrier(0);
-      const float d1 = partial(2 * P + 1);
-      const float u = reduce_pair(d0, d1);
-      const float w0 = FIRST ? fmaf(-cm1_0, row_bcast_from<0>(u), cp_0) : cm1_0 * row_bcast_from<0>(u);
-      const float w1 = FIRST ? fmaf(-cm1_1, row_bcast_from<8>(u), cp_1) : cm1_1 * row_bcast_from<8>(u);
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (PER == 4) mfma(idx_t<PER * P + 2>{});
-      __builtin_amdgcn_sched_barrier(0);
-      axpy(2 * P, w0);
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (PER == 4) mfma(idx_t<PER * P + 3>{});
-      __builtin_amdgcn_sched_barrier(0);
-      axpy(2 * P + 1, w1);
-    } else {
-      asm volatile("" ::: "memory");
-      static_for<PER>([&](auto Kc) { mfma(idx_t<PER * P + decltype(Kc)::value>{}); });
-    }
-    if constexpr (LAST) {
-      if (8 * P < cnt_nx) gather_pair<F, P>(y, cw, col_nx, c_nx, cnt_nx, Y, lane);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  });
-  float aes[FE];
-#pragma unroll
-  for (int h = 0; h < H; ++h) aes[2 * h] = ae[h].x, aes[2 * h + 1] = ae[h].y;
-  reduce_expanded<F>(aes, acc);
-}
-
-template <int F, bool OVERLAP, typename ST>
+template <int F, typename ST>
 __global__ __launch_bounds__(1024) void als_cg_qfgroup_kernel(const int32_t *__restrict__ order, int first, int count,
                                                               const int32_t *__restrict__ indptr,
                                                               const int32_t *__restrict__ indices,
@@ -691,27 +611,10 @@ __global__ __launch_bounds__(1024) void als_cg_qfgroup_kernel(const int32_t *__r
   const unsigned cf = (unsigned)QL<F>::cfactor(lane, 0);  // this lane's compact slots inside a natural-order vector
 
   // out (compact) = A0 . vec for this wave's row; every wave of the workgroup takes both barriers (inactive rows publish 0)
-  auto publish = [&](const float (&vec)[FC], bool valid) {
+  auto dense = [&](const float (&vec)[FC], bool valid, float (&out)[FC]) {
     if constexpr (FC == 2) *reinterpret_cast<float2 *>(prow + cf) = valid ? make_float2(vec[0], vec[1]) : make_float2(0.f, 0.f);
     else prow[cf] = valid ? vec[0] : 0.f;
     __syncthreads();
-  };
-  auto collect = [&](float (&out)[FC]) {  // after the barrier that follows the product
-#pragma unroll
-    for (int c = 0; c < FC; ++c) out[c] = 0.f;
-#pragma unroll
-    for (int h = 0; h < Cfg::KH; ++h) {
-      const float *o = Outs + (h * 16 + wave) * LD + cf;
-      if constexpr (FC == 2) {
-        const float2 t = *reinterpret_cast<const float2 *>(o);
-        out[0] += t.x, out[1] += t.y;
-      } else {
-        out[0] += o[0];
-      }
-    }
-  };
-  auto dense = [&](const float (&vec)[FC], bool valid, float (&out)[FC]) {
-    publish(vec, valid);
     const int ti = wave % Cfg::NT, kh = wave / Cfg::NT;
     const int ln = opaque(lane);
     const int i = ln & 15, kq = ln >> 4;
@@ -728,8 +631,20 @@ __global__ __launch_bounds__(1024) void als_cg_qfgroup_kernel(const int32_t *__r
     }
     *reinterpret_cast<float4 *>(Outs + (kh * 16 + i) * LD + 16 * ti + 4 * kq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     __syncthreads();
-    collect(out);
+#pragma unroll
+    for (int c = 0; c < FC; ++c) out[c] = 0.f;
+#pragma unroll
+    for (int h = 0; h < Cfg::KH; ++h) {
+      const float *o = Outs + (h * 16 + wave) * LD + cf;
+      if constexpr (FC == 2) {
+        const float2 t = *reinterpret_cast<const float2 *>(o);
+        out[0] += t.x, out[1] += t.y;
+      } else {
+        out[0] += o[0];
+      }
+    }
   };
+
   const int groups = (count + 15) / 16, g_step = gridDim.x;
   // row of this wave in group g (groups past the end and rows past the count re-read the last row and stay invalid)
   auto row_id = [&](int g) { return order[first + min(g * 16 + wave, count - 1)]; };  // uniform address: scalar load
@@ -748,38 +663,6 @@ __global__ __launch_bounds__(1024) void als_cg_qfgroup_kernel(const int32_t *__r
     for (int cc = 0; cc < FC; ++cc) v[cc] = 0.f;
   };
   kill(x);
-  // One pass, both pipes at once (OVERLAP): publish, barrier, then the wave's MFMAs of the 16-row product interleaved with its
-  // own row's tile entries; product tile to LDS, barrier, K-slices summed.  dn = A0 . vec (compact), sp = tile part.
-  auto pass = [&](auto FirstC, auto LastC, const float (&vec)[FC], bool valid, bool tiles, float (&dn)[FC], float (&sp)[FC], int cnt_nx) {
-    constexpr bool FIRST = decltype(FirstC)::value != 0, LAST = decltype(LastC)::value != 0;
-    publish(vec, valid);
-    const int ti = wave % Cfg::NT, kh = wave / Cfg::NT;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};  // two chains: a dependent MFMA waits 40 cycles, not 32
-    float4 a, b;
-    auto mfma = [&](auto Mc) {
-      constexpr int M = decltype(Mc)::value, kb = M / 4, comp = M % 4;
-      if constexpr (comp == 0) {
-        const int ln = opaque(lane);
-        const int k0 = (kh * Cfg::KB + kb) * 16 + 4 * (ln >> 4);
-        a = *reinterpret_cast<const float4 *>(A0s + (16 * ti + (ln & 15)) * LD + k0);
-        b = *reinterpret_cast<const float4 *>(Ps + (ln & 15) * LD + k0);
-      }
-      const float av = comp == 0 ? a.x : comp == 1 ? a.y : comp == 2 ? a.z : a.w;
-      const float bv = comp == 0 ? b.x : comp == 1 ? b.y : comp == 2 ? b.z : b.w;
-      if constexpr (M % 2 == 0) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc0, 0, 0, 0);
-      else acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc1, 0, 0, 0);
-    };
-    // an inactive row (early exit taken, or a padding row) still contributes its MFMAs: cnt 0 skips its tile work
-    tile_pass_mfma<F, 4 * Cfg::KB, FIRST, LAST, ST>(y, cw, tiles ? cnt : 0, prow, sp, lane, cnt_nx, ent_col, ent_c, Y, mfma);
-    {
-      const int ln = opaque(lane);
-      *reinterpret_cast<float4 *>(Outs + (kh * 16 + (ln & 15)) * LD + 16 * ti + 4 * (ln >> 4)) =
-          make_float4(acc0[0] + acc1[0], acc0[1] + acc1[1], acc0[2] + acc1[2], acc0[3] + acc1[3]);
-    }
-    __syncthreads();
-    collect(dn);
-  };
-
   for (int g = blockIdx.x; g < groups; g += g_step) {
     const bool valid = row_valid(g);
     ST *xrow = X + (size_t)id0 * F;
@@ -800,22 +683,17 @@ __global__ __launch_bounds__(1024) void als_cg_qfgroup_kernel(const int32_t *__r
 #pragma unroll
     for (int cc = 0; cc < FC; ++cc) xc[cc] = x[cc];
     // r = -(A0 x) + sum_k (c+ - (|c|-1) y.x) y        (_als.pyx:187-201)
-    if constexpr (OVERLAP) {
-      pass(idx_t<1>{}, idx_t<0>{}, xc, valid, valid, Ap, sp, 0);
-    } else {
-      dense(xc, valid, Ap);
-      tile_pass<F, true, false, ST>(y, cw, cnt, prow, sp, lane, 0, ent_col, ent_c, Y);
-    }
+    dense(xc, valid, Ap);
+    tile_pass<F, true, false, ST>(y, cw, cnt, prow, sp, lane, 0, ent_col, ent_c, Y);
 #pragma unroll
     for (int cc = 0; cc < FC; ++cc) p[cc] = r[cc] = sp[cc] - Ap[cc];
     float rsold = dot_compact<F>(r, r);
     bool active = valid && rsold >= 1e-20f;  // else: x untouched (_als.pyx:206)
     const bool store = active;
     for (int it = 0; it + 1 < cg_steps; ++it) {  // all steps but the last; every wave takes the barriers of dense()
-      if constexpr (OVERLAP) pass(idx_t<0>{}, idx_t<0>{}, p, active, active, Ap, sp, 0);
-      else dense(p, active, Ap);
+      dense(p, active, Ap);
       if (active) {  // wave-uniform
-        if constexpr (!OVERLAP) tile_pass<F, false, false, ST>(y, cw, cnt, prow, sp, lane, 0, ent_col, ent_c, Y);
+        tile_pass<F, false, false, ST>(y, cw, cnt, prow, sp, lane, 0, ent_col, ent_c, Y);
 #pragma unroll
         for (int cc = 0; cc < FC; ++cc) Ap[cc] += sp[cc];
         const float alpha = rsold * __builtin_amdgcn_rcpf(dot_compact<F>(p, Ap));
@@ -839,22 +717,17 @@ __global__ __launch_bounds__(1024) void als_cg_qfgroup_kernel(const int32_t *__r
     // rolls the next group's entries in
     bool rolled = false;
     if (cg_steps > 0) {
-      if constexpr (OVERLAP) {  // an inactive row rolls nothing in: its next row starts with a plain gather
-        if constexpr (ROLL) pass(idx_t<0>{}, idx_t<1>{}, p, active, active, Ap, sp, active ? ent_cnt : 0);
-        else pass(idx_t<0>{}, idx_t<0>{}, p, active, active, Ap, sp, 0);
-      } else {
-        dense(p, active, Ap);
-      }
+      dense(p, active, Ap);
       if (active) {
         if constexpr (ROLL) {
-          if constexpr (!OVERLAP) tile_pass<F, false, true, ST>(y, cw, cnt, prow, sp, lane, ent_cnt, ent_col, ent_c, Y);
+          tile_pass<F, false, true, ST>(y, cw, cnt, prow, sp, lane, ent_cnt, ent_col, ent_c, Y);
           cnt = ent_cnt;
           ent_cnt = row_valid(g + 2 * g_step) ? e2 - b2 : 0;
           fetch_entries(indices, data, opaque(lane), b2, max(e2, b2 + 1), ent_col, ent_c);
           load_compact<F>(X + (size_t)id1 * F, opaque(lane), x);
           rolled = true;
         } else {
-          if constexpr (!OVERLAP) tile_pass<F, false, false, ST>(y, cw, cnt, prow, sp, lane, 0, ent_col, ent_c, Y);
+          tile_pass<F, false, false, ST>(y, cw, cnt, prow, sp, lane, 0, ent_col, ent_c, Y);
           kill(x);
         }
 #pragma unroll
@@ -879,9 +752,7 @@ template <int F, typename T>
 static void launch_qfgroup(const imp_csr *C, int first, int count, T *X, const T *Y, const float *A0, int cg_steps, const char *name) {
   if (count <= 0) return;
   size_t lds = QFGroupCfg<F>::lds_floats * sizeof(float);
-  // IMP_SHORT_OVERLAP=0: product, then tile entries (first round-3 form) instead of one interleaved MFMA / VALU stream
-  static const bool overlap = !(getenv("IMP_SHORT_OVERLAP") && atoi(getenv("IMP_SHORT_OVERLAP")) == 0);
-  auto kern = overlap ? als_cg_qfgroup_kernel<F, true, T> : als_cg_qfgroup_kernel<F, false, T>;
+  auto kern = als_cg_qfgroup_kernel<F, T>;
   IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   static const int per_cu = getenv("IMP_QGROUP_PER_CU") ? std::max(1, atoi(getenv("IMP_QGROUP_PER_CU"))) : 2;
   int grid = std::min((count + 15) / 16, ctx().num_cus * std::max(per_cu, ctx().oversub));

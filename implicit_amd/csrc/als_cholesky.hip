@@ -24,6 +24,9 @@ __device__ __forceinline__ float bcast_lane(float v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 
+// PACKED: the augmented lower triangle stored row after row without padding (row i at i (i + 1) / 2): 133 KB at f = 256,
+// where the square image (264 KB) does not fit the 160 KB of LDS -- the form the factor counts above 160 run in
+template <bool PACKED>
 __global__ __launch_bounds__(256) void als_cholesky_kernel(const int32_t *__restrict__ order, int first, int count,
                                                            const int32_t *__restrict__ indptr,
                                                            const int32_t *__restrict__ indices,
@@ -32,7 +35,8 @@ __global__ __launch_bounds__(256) void als_cholesky_kernel(const int32_t *__rest
                                                            int f, float reg, int lda, unsigned long long *failed_row) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *A = smem;                              // [(f+1)][lda] lower triangle used, row f = b^T -> z^T
-  float *yt = A + (size_t)(f + 1) * lda;        // [TILE][f]   gathered rows
+  auto at = [&](int i, int j) { return PACKED ? i * (i + 1) / 2 + j : i * lda + j; };  // j <= i
+  float *yt = A + (PACKED ? (size_t)(f + 1) * (f + 2) / 2 : (size_t)(f + 1) * lda);  // [TILE][f]   gathered rows
   float *ut = yt + (size_t)kCholTile * f;       // [TILE][f+1] (|c|-1) * y, last = c+
   const int tid = threadIdx.x;
   const int ti = tid >> 4, tj = tid & 15;
@@ -44,7 +48,7 @@ __global__ __launch_bounds__(256) void als_cholesky_kernel(const int32_t *__rest
     // A = YtY + reg I (lower triangle), b = 0
     for (int i = ti; i <= f; i += 16)
       for (int j = tj; j <= i && j < f; j += 16)
-        A[i * lda + j] = i < f ? YtY[(size_t)i * f + j] + (i == j ? reg : 0.f) : 0.f;
+        A[at(i, j)] = i < f ? YtY[(size_t)i * f + j] + (i == j ? reg : 0.f) : 0.f;
     __syncthreads();
 
     for (int k0 = row_begin; k0 < row_end; k0 += kCholTile) {
@@ -69,10 +73,10 @@ __global__ __launch_bounds__(256) void als_cholesky_kernel(const int32_t *__rest
       __syncthreads();
       for (int i = ti; i <= f; i += 16)
         for (int j = tj; j <= i && j < f; j += 16) {
-          float s = A[i * lda + j];
+          float s = A[at(i, j)];
 #pragma unroll
           for (int t = 0; t < kCholTile; ++t) s = fmaf(ut[t * (f + 1) + i], yt[t * f + j], s);
-          A[i * lda + j] = s;
+          A[at(i, j)] = s;
         }
       __syncthreads();
     }
@@ -80,18 +84,18 @@ __global__ __launch_bounds__(256) void als_cholesky_kernel(const int32_t *__rest
     // right-looking Cholesky of the first f columns of the augmented triangle
     bool ok = true;
     for (int k = 0; k < f; ++k) {
-      float d = A[k * lda + k];
+      float d = A[at(k, k)];
       if (!(d > 0.f)) {  // uniform: every thread reads the same LDS word
         ok = false;
         break;
       }
       float inv = 1.0f / sqrtf(d);
       __syncthreads();  // everyone has read the pivot
-      for (int i = k + tid; i <= f; i += 256) A[i * lda + k] = i == k ? sqrtf(d) : A[i * lda + k] * inv;
+      for (int i = k + tid; i <= f; i += 256) A[at(i, k)] = i == k ? sqrtf(d) : A[at(i, k)] * inv;
       __syncthreads();
       for (int i = k + 1 + ti; i <= f; i += 16) {
-        float lik = A[i * lda + k];
-        for (int j = k + 1 + tj; j <= i && j < f; j += 16) A[i * lda + j] = fmaf(-lik, A[j * lda + k], A[i * lda + j]);
+        float lik = A[at(i, k)];
+        for (int j = k + 1 + tj; j <= i && j < f; j += 16) A[at(i, j)] = fmaf(-lik, A[at(j, k)], A[at(i, j)]);
       }
       __syncthreads();
     }
@@ -107,18 +111,18 @@ __global__ __launch_bounds__(256) void als_cholesky_kernel(const int32_t *__rest
 #pragma unroll
       for (int m = 0; m < MAXV; ++m) {
         int i = tid + 64 * m;
-        z[m] = i < f ? A[f * lda + i] : 0.f;
+        z[m] = i < f ? A[at(f, i)] : 0.f;
       }
       for (int k = f - 1; k >= 0; --k) {
         float zk = 0.f;
 #pragma unroll
         for (int m = 0; m < MAXV; ++m)
           if ((k >> 6) == m) zk = bcast_lane(z[m], k & 63);
-        float xk = zk / A[k * lda + k];
+        float xk = zk / A[at(k, k)];
 #pragma unroll
         for (int m = 0; m < MAXV; ++m) {
           int i = tid + 64 * m;
-          if (i < k) z[m] = fmaf(-A[k * lda + i], xk, z[m]);
+          if (i < k) z[m] = fmaf(-A[at(k, i)], xk, z[m]);
           if (i == k) z[m] = xk;
         }
       }
@@ -520,9 +524,11 @@ void zero_rows(const int32_t *order, int first, int count, float *X, int f);  //
 // returns -1, or the smallest failing row
 int64_t least_squares_cholesky(const imp_csr *C, imp_matrix *X, const imp_matrix *YtY, const imp_matrix *Y, double reg) {
   const int f = (int)X->cols;
-  if (f > 160) throw std::invalid_argument("least_squares_cholesky: factors must be <= 160 in this build");
+  if (f > 256) throw std::invalid_argument("least_squares_cholesky: factors must be <= 256 in this build");
   int lda = (f + 1) | 1;  // odd
-  size_t lds = ((size_t)(f + 1) * lda + (size_t)kCholTile * f + (size_t)kCholTile * (f + 1)) * sizeof(float);
+  const bool packed = f > 160;  // the square image of the augmented triangle no longer fits the LDS: packed rows
+  size_t lds = ((packed ? (size_t)(f + 1) * (f + 2) / 2 : (size_t)(f + 1) * lda) + (size_t)kCholTile * f + (size_t)kCholTile * (f + 1)) *
+               sizeof(float);
   auto &failb = ctx().chol_failed;
   if (failb.size < 1) failb.alloc(1);
   unsigned long long *g_failed = failb.data();
@@ -616,14 +622,13 @@ int64_t least_squares_cholesky(const imp_csr *C, imp_matrix *X, const imp_matrix
     IMP_CHECK_HIP(hipGetLastError());
   }
   if (n_block > 0) {
-    IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(als_cholesky_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    auto kern = packed ? als_cholesky_kernel<true> : als_cholesky_kernel<false>;
+    IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
     int grid = std::min(n_block, ctx().num_cus * per_cu);
     IMP_PROF("als_cholesky_rows");
-    als_cholesky_kernel<<<grid, 256, lds, stream()>>>(C->order.data(), 0, n_block, C->indptr.data(), C->indices.data(),
-                                                      C->data.data(), X->f32(), Y->f32(), YtY->f32(), f, (float)reg, lda,
-                                                      g_failed);
+    kern<<<grid, 256, lds, stream()>>>(C->order.data(), 0, n_block, C->indptr.data(), C->indices.data(), C->data.data(), X->f32(),
+                                       Y->f32(), YtY->f32(), f, (float)reg, lda, g_failed);
     IMP_CHECK_HIP(hipGetLastError());
   }
   zero_rows(C->order.data(), C->first_empty(), C->n_empty(), X->f32(), f);

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <thread>
 
 #include "common.h"
 
@@ -290,6 +291,85 @@ int imp_device_synchronize(void) {
 }
 int imp_mem_get_info(size_t *free_bytes, size_t *total_bytes) {
   return guarded([&] { IMP_CHECK_HIP(hipMemGetInfo(free_bytes, total_bytes)); });
+}
+
+// ---- host-side helper: parallel CSR transpose ------------------------------------------------------
+// fit() needs both orientations of the confidence matrix (the reference transposes on the host with scipy, implicit/gpu/als.py:121:
+// single-threaded, 0.11 s for configs[2]'s 17 M nonzeros -- a third of this path's whole set-up).  Stable counting
+// transpose over T threads: thread t owns a run of rows balanced by nonzeros and counts its entries per column; the
+// column offsets of thread t are the column's start plus the counts of the threads before it; every thread then scatters
+// its rows in order -- rows stay sorted inside every output row, bit-identical to scipy's result on canonical input.
+int imp_host_csr_transpose(int32_t rows, int32_t cols, int64_t nnz, const int32_t *indptr, const int32_t *indices, const float *data,
+                           int32_t *t_indptr, int32_t *t_indices, float *t_data, int threads) {
+  return guarded([&] {
+    if (rows < 0 || cols < 0 || nnz < 0 || nnz > INT32_MAX) throw std::invalid_argument("host_csr_transpose: sizes out of range");
+    if (indptr[0] != 0 || indptr[rows] != nnz) throw std::invalid_argument("host_csr_transpose: indptr does not span the nonzeros");
+    // per-thread histograms cost T x cols counters: keep them under 256 MB
+    int T = std::max(1, std::min(threads > 0 ? threads : (int)std::thread::hardware_concurrency() / 2, 32));
+    while (T > 1 && (size_t)T * (size_t)cols > ((size_t)64 << 20)) --T;
+    if (nnz < (1 << 16)) T = 1;
+    std::vector<int32_t> cut(T + 1, rows);
+    cut[0] = 0;
+    for (int t = 1; t < T; ++t) {
+      const int64_t target = nnz * t / T;
+      cut[t] = (int32_t)(std::lower_bound(indptr, indptr + rows + 1, (int32_t)target) - indptr);
+      cut[t] = std::min(rows, std::max(cut[t], cut[t - 1]));
+    }
+    std::vector<std::vector<int32_t>> hist(T);
+    std::string error;
+    std::mutex error_mutex;
+    auto parallel = [&](auto &&fn) {
+      std::vector<std::thread> pool;
+      for (int t = 1; t < T; ++t) pool.emplace_back([&, t] { fn(t); });
+      fn(0);
+      for (auto &th : pool) th.join();
+    };
+    parallel([&](int t) {
+      auto &h = hist[t];
+      h.assign((size_t)cols, 0);
+      for (int64_t k = indptr[cut[t]]; k < indptr[cut[t + 1]]; ++k) {
+        const int32_t c = indices[k];
+        if (c < 0 || c >= cols) {
+          std::lock_guard<std::mutex> g(error_mutex);
+          error = "host_csr_transpose: column index out of range";
+          return;
+        }
+        ++h[c];
+      }
+    });
+    if (!error.empty()) throw std::invalid_argument(error);
+    // column totals -> t_indptr; then every thread's histogram becomes its first output slot per column
+    parallel([&](int t) {  // columns split evenly over the threads
+      const int32_t c0 = (int32_t)((int64_t)cols * t / T), c1 = (int32_t)((int64_t)cols * (t + 1) / T);
+      for (int32_t c = c0; c < c1; ++c) {
+        int32_t sum = 0;
+        for (int u = 0; u < T; ++u) sum += hist[u][c];
+        t_indptr[c + 1] = sum;
+      }
+    });
+    t_indptr[0] = 0;
+    for (int32_t c = 0; c < cols; ++c) t_indptr[c + 1] += t_indptr[c];
+    parallel([&](int t) {
+      const int32_t c0 = (int32_t)((int64_t)cols * t / T), c1 = (int32_t)((int64_t)cols * (t + 1) / T);
+      for (int32_t c = c0; c < c1; ++c) {
+        int32_t at = t_indptr[c];
+        for (int u = 0; u < T; ++u) {
+          const int32_t n = hist[u][c];
+          hist[u][c] = at;
+          at += n;
+        }
+      }
+    });
+    parallel([&](int t) {
+      auto &pos = hist[t];
+      for (int32_t r = cut[t]; r < cut[t + 1]; ++r)
+        for (int32_t k = indptr[r]; k < indptr[r + 1]; ++k) {
+          const int32_t at = pos[indices[k]]++;
+          t_indices[at] = r;
+          t_data[at] = data[k];
+        }
+    });
+  });
 }
 
 // ---- Matrix -------------------------------------------------------------------------------------

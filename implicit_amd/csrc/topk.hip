@@ -15,7 +15,9 @@
 //          (ordered(score) << 32 | column) over the score bytes with early exit once the boundary bucket
 //          is taken whole, exact tie resolution otherwise, a gather of the k winners and an in-LDS bitonic sort.
 #include <cfloat>
+#include <type_traits>
 
+#include "als_qtile.h"  // load4: fp32 / fp16 factor storage converted in registers
 #include "common.h"
 
 namespace imp {
@@ -278,8 +280,11 @@ struct EmitArgs {
   int cap;
 };
 
-template <int MODE>
-__global__ __launch_bounds__(256) void score_gemm_direct_kernel(const float *__restrict__ Q, int nq, const float *__restrict__ I,
+// TQ / TI: storage type of the query / item factors (float or __half).  fp16 factors are read as they are stored and
+// converted in registers (8-byte loads; the reference hands fp16 operands straight to the GEMM with fp32 accumulation,
+// implicit/gpu/knn.cu:117-128) -- bit-identical to scoring an fp32 copy, without writing and re-reading one per call.
+template <int MODE, typename TQ = float, typename TI = float>
+__global__ __launch_bounds__(256) void score_gemm_direct_kernel(const TQ *__restrict__ Q, int nq, const TI *__restrict__ I,
                                                                 int ni, int f, const float *__restrict__ norms,
                                                                 float *__restrict__ S, float *__restrict__ tile_max,
                                                                 int n_tiles, int block_stride, EmitArgs emit) {
@@ -287,7 +292,8 @@ __global__ __launch_bounds__(256) void score_gemm_direct_kernel(const float *__r
   const int r = lane & 31, kh = lane >> 5;
   const int q_base = blockIdx.y * 128 + 64 * (wave >> 1);
   const int i_base = (MODE == 1 ? blockIdx.x * block_stride : blockIdx.x) * 128 + 64 * (wave & 1);
-  const float *qp[2], *ip[2];
+  const TQ *qp[2];
+  const TI *ip[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     qp[t] = Q + (size_t)min(q_base + 32 * t + r, nq - 1) * f + 4 * kh;  // clamped rows: results are discarded
@@ -307,8 +313,8 @@ __global__ __launch_bounds__(256) void score_gemm_direct_kernel(const float *__r
   auto fetch = [&](float4 (&a)[2], float4 (&b)[2], int k0) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      a[t] = *reinterpret_cast<const float4 *>(qp[t] + k0);
-      b[t] = *reinterpret_cast<const float4 *>(ip[t] + k0);
+      a[t] = load4(qp[t] + k0);
+      b[t] = load4(ip[t] + k0);
     }
   };
   auto multiply = [&](const float4 (&a)[2], const float4 (&b)[2]) {
@@ -590,29 +596,29 @@ __global__ __launch_bounds__(BLOCK) void select_pruned_kernel(const float *__res
 //      an exact tie at the k-th score (the reference heap's arrival-order rule needs the whole row) raise `fallback`:
 //      those queries are redone by the materialising path, 64 at a time.
 // Scores are the same MFMA accumulations in both passes (same kernel body, same k order): bit-identical.
-constexpr int kSubStride = 32;
+constexpr int kSubStride = 32;   // default / largest stride of the pre-pass subset (emit_stride() lowers it for large k)
 constexpr int kEmitCap = 4096;  // candidates per query (32 KiB: the LDS sort buffer of select_candidates_kernel)
 
 __global__ void coo_bitmap_kernel(uint32_t *__restrict__ bits, int words, int start, int end, int ni, const int32_t *__restrict__ row,
-                                  const int32_t *__restrict__ col, size_t nnz, float *__restrict__ S_sub, int sub_cols) {
+                                  const int32_t *__restrict__ col, size_t nnz, float *__restrict__ S_sub, int sub_cols, int sub_stride) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nnz; i += (size_t)gridDim.x * blockDim.x) {
     const int r = row[i], c = col[i];
     if (r < start || r >= end || c < 0 || c >= ni) continue;
     atomicOr(&bits[(size_t)(r - start) * words + (c >> 5)], 1u << (c & 31));
     const int blk = c >> 7;
-    if (S_sub && blk % kSubStride == 0) S_sub[(size_t)(r - start) * sub_cols + (blk / kSubStride) * 128 + (c & 127)] = -FLT_MAX;
+    if (S_sub && blk % sub_stride == 0) S_sub[(size_t)(r - start) * sub_cols + (blk / sub_stride) * 128 + (c & 127)] = -FLT_MAX;
   }
 }
 
 __global__ void item_bitmap_kernel(uint32_t *__restrict__ bits, int ni, const int32_t *__restrict__ items, int n_items,
-                                   float *__restrict__ S_sub, int rows, int sub_cols) {
+                                   float *__restrict__ S_sub, int rows, int sub_cols, int sub_stride) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)n_items; i += (size_t)gridDim.x * blockDim.x) {
     const int c = items[i];
     if (c < 0 || c >= ni) continue;
     atomicOr(&bits[c >> 5], 1u << (c & 31));
     const int blk = c >> 7;
-    if (blk % kSubStride == 0)
-      for (int q = 0; q < rows; ++q) S_sub[(size_t)q * sub_cols + (blk / kSubStride) * 128 + (c & 127)] = -FLT_MAX;
+    if (blk % sub_stride == 0)
+      for (int q = 0; q < rows; ++q) S_sub[(size_t)q * sub_cols + (blk / sub_stride) * 128 + (c & 127)] = -FLT_MAX;
   }
 }
 
@@ -756,10 +762,11 @@ __global__ __launch_bounds__(BLOCK) void select_candidates_kernel(const uint64_t
 }
 
 // fallback rows: query rows gathered into a compact matrix, filters replayed from the bitmaps onto the materialised scores
-__global__ void gather_query_rows_kernel(const float *__restrict__ Q, const int32_t *__restrict__ rows, int n, int f,
+template <typename TQ>
+__global__ void gather_query_rows_kernel(const TQ *__restrict__ Q, const int32_t *__restrict__ rows, int n, int f,
                                          float *__restrict__ out) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)n * f; i += (size_t)gridDim.x * blockDim.x)
-    out[i] = Q[(size_t)rows[i / f] * f + i % f];
+    out[i] = load1(Q + (size_t)rows[i / f] * f + i % f);
 }
 
 __global__ void bitmap_filter_kernel(float *__restrict__ S, float *__restrict__ tile_max, int ni, int n_tiles,
@@ -869,10 +876,16 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
     if (nq == 0 || k == 0) return;
     if (ni > (size_t)INT32_MAX) throw std::invalid_argument("too many items for topk");
 
-    // fp16 factors: score in fp32 (reference: SgemmEx with fp32 accumulate, knn.cu:117-128)
+    const int k_eff = (int)std::min<size_t>((size_t)k, ni);
+    // fast path: direct-operand MFMA GEMM (+ emit path, or tile maxima + single-pass pruned select)
+    static const bool no_fast = getenv("IMP_TOPK_NO_FAST") != nullptr;
+    const bool fast = !no_fast && (f % 8 == 0) && k_eff <= kCandCap;
+    // fp16 factors (reference: SgemmEx on fp16 operands with fp32 accumulation, knn.cu:117-128): the direct-operand kernels
+    // read them as stored and convert in registers; only the general path (any f, LDS-staged GEMM) scores an fp32 copy
+    const bool half_direct = items_in->itemsize == 2 && fast && getenv("IMP_FP16_CONVERT") == nullptr;
     std::unique_ptr<imp_matrix> items_conv, query_conv;
     const imp_matrix *items = items_in, *query = query_in;
-    if (items_in->itemsize == 2) {
+    if (items_in->itemsize == 2 && !half_direct) {
       imp_matrix *t = nullptr;
       if (imp_matrix_astype(items_in, 4, &t) != IMP_OK) throw std::runtime_error(imp_last_error());
       items_conv.reset(t);
@@ -881,8 +894,6 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
       items = items_conv.get();
       query = query_conv.get();
     }
-
-    const int k_eff = (int)std::min<size_t>((size_t)k, ni);
     int kpad = 1;
     while (kpad < k_eff) kpad <<= 1;
     if (kpad < 2) kpad = 2;
@@ -901,27 +912,33 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
     size_t temp = std::min<size_t>(knn->max_temp_memory, (size_t)4 << 30);
     size_t batch = std::max<size_t>(1, std::min<size_t>(nq, temp / (sizeof(float) * ni)));
     static const bool no_emit_alloc = getenv("IMP_TOPK_NO_EMIT") != nullptr;
-    const bool will_emit = !no_emit_alloc && getenv("IMP_TOPK_NO_FAST") == nullptr && (f % 8 == 0) && ni >= 32768 && k_eff == k && k_eff <= 256;
+    // emit path (no score matrix) whenever the pre-pass subset is a usable sample: every `stride`-th 128-item block, the stride
+    // chosen so that the expected candidate list (stride x k) fills at most half of a query's kEmitCap slots, and the subset at
+    // least 4 k items (catalogues of a few thousand items and up; configs[4]'s 26 744 items at k = 100 run with stride 20)
+    const int stride = std::max(2, std::min(kSubStride, kEmitCap / (2 * std::max(1, k_eff))));
+    const bool emit_shape = (f % 8 == 0) && k_eff == k && k_eff <= 256 && ni >= 4096 &&
+                            ((ni + 127) / 128 + stride - 1) / stride * 128 >= (size_t)4 * k_eff;
+    const bool will_emit = !no_emit_alloc && getenv("IMP_TOPK_NO_FAST") == nullptr && emit_shape;
     float *scores = will_emit ? nullptr : imp_knn::ensure(knn->scores, batch * ni);  // the emit path materialises fallback rows only
     const bool use_lds = (size_t)kpad * 8 <= 96 * 1024;
     uint64_t *gcand = use_lds ? nullptr : imp_knn::ensure(knn->gcand, batch * (size_t)kpad);
 
-    // fast path: direct-operand MFMA GEMM with tile maxima + single-pass pruned select
-    static const bool no_fast = getenv("IMP_TOPK_NO_FAST") != nullptr;
-    const bool fast = !no_fast && (f % 8 == 0) && k_eff <= kCandCap;
     const int n_tiles = (int)((ni + kTileItems - 1) / kTileItems);
     float *tile_max = (fast && !will_emit) ? imp_knn::ensure(knn->tile_max, batch * (size_t)n_tiles) : nullptr;
     int *fallback = (fast && !will_emit) ? imp_knn::ensure(knn->fallback, batch) : nullptr;
     int *counts = nullptr;  // tile maxima are refreshed after the filters: no slack for filtered entries is needed
     const int extra = 0;
 
+    auto run = [&](const auto *Qb, const auto *Ib) {
+      using TQ = std::remove_cv_t<std::remove_pointer_t<decltype(Qb)>>;
+      using TI = std::remove_cv_t<std::remove_pointer_t<decltype(Ib)>>;
     // emit path (no score matrix): large item sets, k small against the candidate lists
     static const bool no_emit = getenv("IMP_TOPK_NO_EMIT") != nullptr;
-    const bool emit_path = fast && !no_emit && ni >= 32768 && k_eff == k && k_eff <= 256;
+    const bool emit_path = fast && !no_emit && emit_shape;
     if (emit_path) {
       const float *norms = item_norms ? item_norms->f32() : nullptr;
       const int words = (int)((ni + 31) / 32);
-      const int n_blocks = (int)((ni + 127) / 128), n_sub = (n_blocks + kSubStride - 1) / kSubStride, sub_cols = n_sub * 128;
+      const int n_blocks = (int)((ni + 127) / 128), n_sub = (n_blocks + stride - 1) / stride, sub_cols = n_sub * 128;
       const size_t ebatch = std::min<size_t>(nq, 2048);
       constexpr int FB = 64;  // fallback rows per materialised group
       float *sub = imp_knn::ensure(knn->sub_scores, ebatch * (size_t)sub_cols);
@@ -937,27 +954,27 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
       std::vector<int32_t> fb_list;
       for (size_t start = 0; start < nq; start += ebatch) {
         const size_t end = std::min(nq, start + ebatch), rows = end - start;
-        const float *qptr = query->f32() + start * f;
+        const auto *qptr = Qb + start * f;
         const unsigned qblocks = (unsigned)((rows + 127) / 128);
         if (have_coo) IMP_CHECK_HIP(hipMemsetAsync(row_bits, 0, rows * (size_t)words * 4, stream()));
         {
           IMP_PROF("score_gemm_subset");
-          score_gemm_direct_kernel<1><<<dim3((unsigned)n_sub, qblocks), 256, 0, stream()>>>(qptr, (int)rows, items->f32(), (int)ni, f, norms,
-                                                                                          sub, nullptr, 0, kSubStride, EmitArgs{});
+          score_gemm_direct_kernel<1, TQ, TI><<<dim3((unsigned)n_sub, qblocks), 256, 0, stream()>>>(qptr, (int)rows, Ib, (int)ni, f, norms,
+                                                                                          sub, nullptr, 0, stride, EmitArgs{});
           IMP_CHECK_HIP(hipGetLastError());
         }
         if (have_items) {
           IMP_PROF("item_filter");
           int grid = (int)std::min<size_t>((item_filter->size + 255) / 256, (size_t)ctx().num_cus * 8);
           item_bitmap_kernel<<<grid, 256, 0, stream()>>>(item_bits, (int)ni, item_filter->v.data(), (int)item_filter->size, sub, (int)rows,
-                                                         sub_cols);
+                                                         sub_cols, stride);
           IMP_CHECK_HIP(hipGetLastError());
         }
         if (have_coo) {
           IMP_PROF("coo_filter");
           int grid = (int)std::min<size_t>(((size_t)query_filter->nnz + 255) / 256, (size_t)ctx().num_cus * 8);
           coo_bitmap_kernel<<<grid, 256, 0, stream()>>>(row_bits, words, (int)start, (int)end, (int)ni, query_filter->row.data(),
-                                                        query_filter->col.data(), (size_t)query_filter->nnz, sub, sub_cols);
+                                                        query_filter->col.data(), (size_t)query_filter->nnz, sub, sub_cols, stride);
           IMP_CHECK_HIP(hipGetLastError());
         }
         {
@@ -968,7 +985,7 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
         {
           IMP_PROF("score_gemm");
           EmitArgs ea{tau, row_bits, item_bits, words, cand, cnt, kEmitCap};
-          score_gemm_direct_kernel<2><<<dim3((unsigned)n_blocks, qblocks), 256, 0, stream()>>>(qptr, (int)rows, items->f32(), (int)ni, f,
+          score_gemm_direct_kernel<2, TQ, TI><<<dim3((unsigned)n_blocks, qblocks), 256, 0, stream()>>>(qptr, (int)rows, Ib, (int)ni, f,
                                                                                              norms, nullptr, nullptr, 0, 1, ea);
           IMP_CHECK_HIP(hipGetLastError());
         }
@@ -1010,8 +1027,8 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
                                             (int)std::max<size_t>(lds, 1)));
           for (size_t g0 = 0; g0 < fb_list.size(); g0 += FB) {
             const int n = (int)std::min<size_t>(FB, fb_list.size() - g0);
-            gather_query_rows_kernel<<<std::max(1, (n * f + 255) / 256), 256, 0, stream()>>>(qptr, d_rows + g0, n, f, fbq);
-            score_gemm_direct_kernel<0><<<dim3((unsigned)n_blocks, 1), 256, 0, stream()>>>(fbq, n, items->f32(), (int)ni, f, norms, fscores,
+            gather_query_rows_kernel<TQ><<<std::max(1, (n * f + 255) / 256), 256, 0, stream()>>>(qptr, d_rows + g0, n, f, fbq);
+            score_gemm_direct_kernel<0, float, TI><<<dim3((unsigned)n_blocks, 1), 256, 0, stream()>>>(fbq, n, Ib, (int)ni, f, norms, fscores,
                                                                                          ftile, n_tiles, 1, EmitArgs{});
             if (have_coo || have_items) {
               int grid = (int)std::min<size_t>(((size_t)n * n_tiles + 255) / 256, (size_t)ctx().num_cus * 8);
@@ -1036,16 +1053,18 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
       if (fast) {
         IMP_PROF("score_gemm");
         dim3 grid((unsigned)((ni + 127) / 128), (unsigned)((rows + 127) / 128));
-        score_gemm_direct_kernel<0><<<grid, 256, 0, stream()>>>(query->f32() + start * f, (int)rows, items->f32(), (int)ni, f,
+        score_gemm_direct_kernel<0, TQ, TI><<<grid, 256, 0, stream()>>>(Qb + start * f, (int)rows, Ib, (int)ni, f,
                                                                 item_norms ? item_norms->f32() : nullptr, scores, tile_max,
                                                                 n_tiles, 1, EmitArgs{});
         IMP_CHECK_HIP(hipGetLastError());
       } else {
         IMP_PROF("score_gemm_lds");
         dim3 grid((unsigned)((ni + kBN - 1) / kBN), (unsigned)((rows + kBM - 1) / kBM));
-        score_gemm_kernel<<<grid, 256, 0, stream()>>>(query->f32() + start * f, (int)rows, items->f32(), (int)ni, f,
-                                                      item_norms ? item_norms->f32() : nullptr, scores);
-        IMP_CHECK_HIP(hipGetLastError());
+        if constexpr (std::is_same<TQ, float>::value) {  // the general path always runs on fp32 (copies of fp16 factors)
+          score_gemm_kernel<<<grid, 256, 0, stream()>>>(Qb + start * f, (int)rows, Ib, (int)ni, f,
+                                                        item_norms ? item_norms->f32() : nullptr, scores);
+          IMP_CHECK_HIP(hipGetLastError());
+        }
       }
       if (item_filter && item_filter->size) {
         IMP_PROF("item_filter");
@@ -1100,6 +1119,9 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
     if (host_ids) IMP_CHECK_HIP(hipMemcpyAsync(indices, d_ids, nq * (size_t)k * 4, hipMemcpyDeviceToHost, stream()));
     if (host_dist) IMP_CHECK_HIP(hipMemcpyAsync(distances, d_dist, nq * (size_t)k * 4, hipMemcpyDeviceToHost, stream()));
     sync();
+    };
+    if (half_direct) run(reinterpret_cast<const __half *>(query_in->data), reinterpret_cast<const __half *>(items_in->data));
+    else run(query->f32(), items->f32());
   });
 }
 

@@ -11,7 +11,7 @@ numerics of the reference's *CPU* path, which is the parity oracle (implicit/cpu
     reference-GPU style U(-0.5/f, 0.5/f) drawn on the device (gpu/als.py:129-139);
   * `use_cg=False` selects the Cholesky solver (cpu/als.py:418-423), which the reference GPU path
     does not have; recalculate_user/item use Cholesky as the CPU path does (cpu/als.py:221-241)
-    when factors <= 160, else CG run to `factors` steps as the reference GPU path does
+    when factors <= 256, else CG run to `factors` steps as the reference GPU path does
     (gpu/als.py:188-195);
   * NaN factors after fit raise ModelFitError (cpu/als.py:202).
 
@@ -29,12 +29,12 @@ import numpy as np
 
 import implicit_amd.gpu as gpu
 
-from ..utils import check_csr, check_random_state
+from ..utils import check_csr, check_random_state, random_factors, transpose_csr
 from .matrix_factorization_base import MatrixFactorizationBase
 
 log = logging.getLogger("implicit_amd")
 
-_CHOLESKY_MAX_FACTORS = 160
+_CHOLESKY_MAX_FACTORS = 256
 
 
 class AlternatingLeastSquares(MatrixFactorizationBase):
@@ -73,10 +73,10 @@ class AlternatingLeastSquares(MatrixFactorizationBase):
             return
         rng = check_random_state(self.random_state)
         if self.user_factors is None:
-            x0 = rng.random((users, self.factors), dtype=np.float32) * 0.01
+            x0 = random_factors(rng, users, self.factors)
             self.user_factors = gpu.Matrix(x0.astype(self.dtype, copy=False))
         if self.item_factors is None:
-            y0 = rng.random((items, self.factors), dtype=np.float32) * 0.01
+            y0 = random_factors(rng, items, self.factors)
             self.item_factors = gpu.Matrix(y0.astype(self.dtype, copy=False))
 
     def fit(self, user_items, show_progress=True, callback=None):
@@ -92,7 +92,7 @@ class AlternatingLeastSquares(MatrixFactorizationBase):
             return self._fit_sharded(Cui, callback)  # `user_items` = THIS RANK's block of user rows
 
         t0 = time.time()
-        Ciu = Cui.T.tocsr()
+        Ciu = transpose_csr(Cui)  # threaded counting transpose in the library (scipy for non-canonical input)
         log.debug("Calculated transpose in %.3fs", time.time() - t0)
         items, users = Ciu.shape
         self._initial_factors(users, items)

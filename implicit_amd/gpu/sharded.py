@@ -146,7 +146,9 @@ def shard_transpose(comm, backend, Cui_rows):
     sizes = np.zeros(n, dtype=np.int64)
     sizes[r] = n_local
     u_off = np.concatenate([[0], np.cumsum(allreduce_ints(comm, backend, sizes))]).astype(np.int64)
-    T = Cui_rows.T.tocsr()  # items x my users
+    from ..utils import transpose_csr
+
+    T = transpose_csr(Cui_rows)  # items x my users
     T.sort_indices()
     lens = allreduce_ints(comm, backend, np.diff(T.indptr))
     i_off = shard_offsets(items, n, weights=lens)

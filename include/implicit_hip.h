@@ -70,6 +70,13 @@ int imp_device_synchronize(void);
 int imp_mem_get_info(size_t *free_bytes, size_t *total_bytes);
 const char *imp_version(void);
 
+/* NEW, host-side helper (no device work, usable without a GPU): stable parallel transpose of a CSR matrix with int32 offsets
+ * (the reference's fit transposes on the host with scipy, implicit/gpu/als.py:121).  Outputs are caller-allocated:
+ * t_indptr[cols + 1], t_indices[nonzeros], t_data[nonzeros]; row ids inside every output row come out ascending.
+ * threads <= 0: half the hardware threads, at most 32. */
+int imp_host_csr_transpose(int32_t rows, int32_t cols, int64_t nonzeros, const int32_t *indptr, const int32_t *indices,
+                           const float *data, int32_t *t_indptr, int32_t *t_indices, float *t_data, int threads);
+
 /* ---- Matrix (matrix.h:23-90, matrix.cu:34-220) -------------------------------------------- */
 /* Matrix(rows, cols, data, allocate=true, itemsize): allocates; copies rows*cols*itemsize bytes
  * from host_data when non-NULL, zero-fills otherwise (matrix.cu:80-96). */

@@ -138,7 +138,7 @@ def test_cg_long_rows_striped_plan(gpu, oracle, monkeypatch, stripe, f):
     assert rel(got_u, want) < TOL
 
 
-@pytest.mark.parametrize("f", [6, 32, 64, 100, 128])
+@pytest.mark.parametrize("f", [6, 32, 64, 100, 128, 160, 200, 256])  # > 160: packed-triangle LDS image
 def test_cholesky_sweep(gpu, oracle, f):
     C, X0, Y0 = _problem(2000, 800, 60_000, f)
     want = X0.copy()

@@ -155,3 +155,48 @@ def test_topk_fp16_factors(gpu):
     want = np.flip(np.argsort(scores)[:, -5:], axis=1)
     assert d.dtype == np.float32
     assert_array_equal(ids, want)
+
+
+@pytest.mark.parametrize("ni,k,f", [(6000, 10, 64), (26_744, 100, 256), (40_000, 10, 128)])
+def test_fp16_factors_are_scored_as_stored(gpu, oracle, ni, k, f):
+    """fp16 item / query factors go to the scoring GEMM as they are stored (converted in registers, fp32 accumulation --
+    the reference feeds fp16 operands to cublasSgemmEx, knn.cu:117-128): same ids and scores as scoring fp32 copies of the
+    same values, with norms and a per-query filter; small and large catalogues (emit path and materialising path)."""
+    rng = np.random.default_rng(ni + k)
+    items16 = (rng.standard_normal((ni, f)) * 0.1).astype(np.float16)
+    q16 = (rng.standard_normal((70, f)) * 0.1).astype(np.float16)
+    items32, q32 = items16.astype(np.float32), q16.astype(np.float32)
+    liked = sp.random(70, ni, density=20.0 / ni, format="csr", random_state=3, dtype=np.float32)
+    knn = gpu.KnnQuery()
+    norms32 = gpu.calculate_norms(gpu.Matrix(items32))
+    got_ids, got_d = knn.topk(gpu.Matrix(items16), gpu.Matrix(q16), k, item_norms=norms32, query_filter=gpu.COOMatrix(liked.tocoo()))
+    ref_ids, ref_d = knn.topk(gpu.Matrix(items32), gpu.Matrix(q32), k, item_norms=norms32, query_filter=gpu.COOMatrix(liked.tocoo()))
+    assert_array_equal(got_ids, ref_ids)          # the same MFMA accumulations on the same values: bit for bit
+    assert_array_equal(got_d, ref_d)
+    want_ids, want_d = oracle.topk(items32, q32, k, item_norms=norms32.to_numpy().reshape(-1), filter_query_items=liked)
+    ok = ~_near_tie_rows(want_d, f)
+    assert ok.mean() > 0.8
+    assert_array_equal(got_ids[ok], want_ids[ok])
+    assert_allclose(got_d, want_d, rtol=3e-5)
+
+
+def test_emit_path_covers_small_catalogues(gpu, oracle):
+    """The score-matrix-free path now runs from a few thousand items up (the stride of its threshold subset adapts to k):
+    configs[4]'s similar_items shape (26 744 items, k = 100, norms) and a 5 000-item catalogue against the oracle."""
+    rng = np.random.default_rng(8)
+    for ni, k, f in ((26_744, 100, 256), (5_000, 10, 64), (5_000, 100, 64)):
+        items = (rng.standard_normal((ni, f)) * 0.1).astype(np.float32)
+        items[::11] = items[5]                      # duplicated rows: exact ties, some at the k-th score
+        q = items[rng.choice(ni, 130, replace=False)]
+        norms = gpu.calculate_norms(gpu.Matrix(items))
+        ids, d = gpu.KnnQuery().topk(gpu.Matrix(items), gpu.Matrix(q), k, item_norms=norms)
+        want_ids1, want_d1 = oracle.topk(items, q, k + 1, item_norms=norms.to_numpy().reshape(-1))
+        want_ids, want_d = want_ids1[:, :k], want_d1[:, :k]
+        assert_allclose(d, want_d, rtol=3e-5)
+        # rows whose top-(k+1) holds two DIFFERENT scores closer than the fp32 summation noise may legitimately swap them;
+        # exact ties (the duplicated rows) follow the reference heap's arrival-order rule and must match like everything else
+        gaps = np.abs(np.diff(want_d1.astype(np.float64), axis=1))
+        scale = np.abs(want_d1[:, :-1]).astype(np.float64) + 1e-30
+        ok = ~((gaps > 0) & (gaps < 4 * np.finfo(np.float32).eps * f * scale)).any(axis=1)
+        assert ok.mean() > 0.7
+        assert_array_equal(ids[ok], want_ids[ok])

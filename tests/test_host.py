@@ -98,3 +98,44 @@ def test_bench_keeps_stdout_for_the_json_line():
     assert out.returncode == 0, out.stderr
     assert out.stdout == '{"metric": "x", "value": 1}\n'
     assert "python-level noise" in out.stderr and "late C-level noise" in out.stderr
+
+
+def test_threaded_initial_factors_are_the_sequential_draw():
+    """utils.random_factors: the CPU path's `rng.random((n, f), float32) * 0.01` drawn by several threads -- same bits, and the
+    generator ends in the same state (the item factors are drawn right after the user factors)."""
+    from implicit_amd.utils import random_factors
+
+    a, b = np.random.default_rng(5), np.random.default_rng(5)
+    for rows, cols in ((9000, 128), (8191, 64), (33, 7), (20_001, 64)):   # the last two take the plain path (odd / small counts)
+        want = a.random((rows, cols), dtype=np.float32) * 0.01
+        got = random_factors(b, rows, cols, workers=4)
+        assert got.dtype == np.float32 and got.shape == (rows, cols)
+        np.testing.assert_array_equal(got, want)
+    assert a.random() == b.random()
+    legacy = np.random.Generator(np.random.MT19937(3))                    # not PCG64: plain path
+    np.testing.assert_array_equal(random_factors(legacy, 8192, 128), np.random.Generator(np.random.MT19937(3)).random((8192, 128), dtype=np.float32) * 0.01)
+
+
+@pytest.mark.parametrize("threads", [1, 3, 8])
+def test_threaded_transpose_equals_scipy(threads):
+    """utils.transpose_csr (imp_host_csr_transpose, host code): the same CSR as `m.T.tocsr()`, rows sorted inside every
+    output row, empty rows / columns kept; non-canonical or 64-bit input takes scipy."""
+    from implicit_amd.synthetic import synthetic_csr
+    from implicit_amd.utils import transpose_csr
+
+    for C in (synthetic_csr(3000, 1700, 90_000, seed=2, empty_frac=0.1, neg_frac=0.1), synthetic_csr(40, 5000, 70_000, seed=3),
+              sp.csr_matrix((7, 9), dtype=np.float32)):
+        want = C.T.tocsr()
+        got = transpose_csr(C, threads=threads)
+        assert got.shape == want.shape and got.indptr.dtype == np.int32
+        assert_array_equal(got.indptr, want.indptr)
+        assert_array_equal(got.indices, want.indices)
+        assert_array_equal(got.data, want.data)
+    C64 = synthetic_csr(300, 200, 4000, seed=4)
+    C64.indptr = C64.indptr.astype(np.int64)
+    assert (transpose_csr(C64) != C64.T.tocsr()).nnz == 0          # scipy path
+    bad = synthetic_csr(300, 200, 4000, seed=4)
+    bad.indices[0] = 5000                                           # out of range: refused, not scattered
+    bad.has_canonical_format = True
+    with pytest.raises(ValueError):
+        transpose_csr(bad, threads=threads)
