@@ -579,6 +579,20 @@ def extra_c5(gpu, SHAPES):
         knn.topk(Y, v, 100, item_norms=norms)
     gpu.synchronize()
     t = time.perf_counter() - t0
+    gpu.Profiler.reset()
+    gpu.Profiler.enable(True)
+    for v in views:
+        knn.topk(Y, v, 100, item_norms=norms)
+    gpu.synchronize()
+    gpu.Profiler.enable(False)
+    sim_kernels = {n: gpu.Profiler.get(n)[0] / n_batches for n in gpu.Profiler.names()}
+    gemm_ms = sim_kernels.get("score_gemm", 0.0)
+    sim_flops = 2.0 * batch * Y.shape[0] * f
+    sim_roofline = None
+    if gemm_ms > 0:
+        sim_roofline = {"bound": "mfma", "kernel": "score_gemm_direct_kernel", "achieved": sim_flops / (gemm_ms * 1e-3) / 1e12,
+                        "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": sim_flops / (gemm_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                        "avg_launch_ms": gemm_ms, "flops_per_launch": sim_flops, "traffic": None}
     return {"cg_c5": {"workload": "BASELINE configs[4]: 138,493 x 26,744, %d nnz, f=256 fp32, CG cg_steps=%d" % (C.nnz, CG_STEPS),
                       "ms_per_iter": 1e3 * t_cg, "updates_per_s": rows / t_cg,
                       "roofline": {"bound": "hbm", "achieved": gb / t_cg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -587,6 +601,7 @@ def extra_c5(gpu, SHAPES):
             "similar_items_c5": {"workload": "KnnQuery similar_items k=100 over all 26,744 items with norms, batches of 1000 items, f=256",
                                  "items_per_s": batch * n_batches / t, "ms_per_batch": 1e3 * t / n_batches,
                                  "scoring_TFLOPs": 2.0 * batch * n_batches * Y.shape[0] * f / t / 1e12,
+                                 "roofline": sim_roofline, "kernels_ms_per_batch": sim_kernels,
                                  "note": "ids/scores returned to host memory per batch"}}
 
 
@@ -706,11 +721,40 @@ def bench_topk(gpu, Cui, X, Y, k=10, queries=20_000, batch=1000):
     gpu.Profiler.enable(False)
     kernels = {name: gpu.Profiler.get(name)[0] / len(views) for name in gpu.Profiler.names()}
     flops = 2.0 * queries * Y.shape[0] * Y.shape[1]
+    # the dominant kernel: the full scoring GEMM (emit epilogue), HIP events of the profiled pass
+    gemm_ms = kernels.get("score_gemm", 0.0)
+    per_batch_flops = 2.0 * batch * Y.shape[0] * Y.shape[1]
+    roofline = None
+    if gemm_ms > 0:
+        tf = per_batch_flops / (gemm_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "score_gemm_direct_kernel<2> (emit epilogue)", "achieved": tf, "peak": FP32_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS, "avg_launch_ms": gemm_ms,
+                    "flops_per_launch": per_batch_flops, "traffic": None,
+                    "note": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32); 2 x batch x items x f flops per launch"}
+    # the model-level call a user makes (recommend(): host COO build of the liked items + upload + KnnQuery.topk per batch)
+    rec = None
+    try:
+        from implicit_amd.als import AlternatingLeastSquares
+
+        model = AlternatingLeastSquares(factors=Y.shape[1], use_gpu=True)
+        model.user_factors, model.item_factors = X, Y
+        ids = np.arange(queries)
+        model.recommend(ids[:batch], Cui[:batch], N=k)
+        gpu.synchronize()
+        t0 = time.perf_counter()
+        for s0 in range(0, queries, batch):
+            model.recommend(ids[s0:s0 + batch], Cui[s0:s0 + batch], N=k)
+        gpu.synchronize()
+        rec = queries / (time.perf_counter() - t0)
+    except Exception as e:  # noqa: BLE001
+        rec = f"{type(e).__name__}: {e}"
     return {"metric": "top-k recs/sec", "value": queries / t, "unit": "recs/s", "k": k, "queries": queries,
-            "kernels_ms_per_batch": kernels, "scoring_TFLOPs": flops / t / 1e12,
+            "kernels_ms_per_batch": kernels, "scoring_TFLOPs": flops / t / 1e12, "roofline": roofline,
+            "model_recommend_recs_per_s": rec,
             "batch": batch, "items": Y.shape[0], "filter_already_liked_items": True,
-            "note": "ids/scores returned to host memory per batch (PCIe D2H included); kernel times from a separate "
-                    "profiled pass"}
+            "note": "value: KnnQuery.topk with the liked-items COO filters already on the device, ids/scores returned to host "
+                    "memory per batch (PCIe D2H included); model_recommend_recs_per_s: AlternatingLeastSquares.recommend() for "
+                    "the same users, host COO build + upload per batch included; kernel times from a separate profiled pass"}
 
 
 if __name__ == "__main__":

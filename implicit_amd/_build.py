@@ -52,5 +52,30 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_variant(tag, defines, sources=("als_cg_qf.hip",)):
+    """A/B aid: the library with `sources` recompiled under extra -D flags, written to build/variants/libimplicit_hip_<tag>.so
+    (git-ignored; it travels to the GPU box) and selected at run time with IMP_LIB_PATH.  Every other object is shared with
+    the regular build."""
+    build(verbose=False)
+    out_dir = os.path.join(HERE, "..", "build", "variants")
+    os.makedirs(out_dir, exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        if src in sources:
+            obj = os.path.join(out_dir, f"{tag}_{src.replace('.hip', '.o')}")
+            subprocess.check_call([HIPCC, *FLAGS, *EXTRA_FLAGS.get(src, []), *[f"-D{d}" for d in defines], "-c",
+                                   os.path.join(CSRC, src), "-o", obj])
+        objs.append(obj)
+    lib = os.path.abspath(os.path.join(out_dir, f"libimplicit_hip_{tag}.so"))
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib, "-L/opt/rocm/lib", "-lrccl",
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    return lib
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--variant" in sys.argv:  # python -m implicit_amd._build --variant TAG DEFINE [DEFINE ...]
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
+    else:
+        build(force="--force" in sys.argv)

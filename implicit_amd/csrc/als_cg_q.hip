@@ -411,7 +411,7 @@ template <int F, typename T> static void run_classes_q(const imp_csr *C, T *X, c
   static const int fused = getenv("IMP_TEAM_FUSED") ? atoi(getenv("IMP_TEAM_FUSED")) : 63;
   static const bool want_stats = getenv("IMP_CG_STATS") != nullptr;
   auto team = [&](int bit, int width, int first, int count, const char *name, auto old) {
-    if ((fused & bit) && !want_stats) launch_team_fused<T>(C, F, width, first, count, X, Y, A0, cg_steps, name);
+    if (fused & bit) launch_team_fused<T>(C, F, width, first, count, X, Y, A0, cg_steps, name);  // IMP_CG_STATS: its own instrumented form
     else old(first, count, name);
   };
   if (!team16_as_cluster())

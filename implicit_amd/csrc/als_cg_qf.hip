@@ -242,13 +242,42 @@ __device__ __forceinline__ void fused_pass(f32x2 (&y)[8][F / 32], float *cw, int
 // control word the leader publishes with every operand
 enum : unsigned { kGo = 1u, kLast = 2u };
 
-template <int F, int WPR, int BLOCK, typename ST>
+// tunables of the team protocol (compile-time: s_sleep / s_setprio take immediates; -D overrides for A/B builds,
+// implicit_amd/_build.py build_variant)
+#ifndef IMP_TEAM_NAP_FIRST
+#define IMP_TEAM_NAP_FIRST 6   // a worker's first nap while the leader updates (64-cycle units)
+#endif
+#ifndef IMP_TEAM_NAP_NEXT
+#define IMP_TEAM_NAP_NEXT 2    // its later naps
+#endif
+#ifndef IMP_TEAM_NAP_LEADER
+#define IMP_TEAM_NAP_LEADER 1  // the leader's naps while it waits for the arrivals
+#endif
+#ifndef IMP_TEAM_LEADER_PRIO
+#define IMP_TEAM_LEADER_PRIO 0 // wave priority of a leader from "arrivals complete" to "operand published" (the team idles meanwhile)
+#endif
+
+// STATS (debug, IMP_CG_STATS=1; timings only): shader-clock cycles summed over the waves of the launch --
+//   [0] waiting for the leader's operand  [1] passes (operand read, dense ticks + tile steps, reduce)  [2] partial -> LDS, arrival
+//   [3] leader: waiting for the team's arrivals  [4] leader: sum of the partials, CG update, publish  [5] row start (gathers
+//   of a row that was not rolled in, iterate load)  [6] wave lifetime  [7] wave-rows
+template <int F, int WPR, int BLOCK, typename ST, bool STATS = false>
 __global__ __launch_bounds__(BLOCK, 4) void als_cg_qfteam_kernel(const int32_t *__restrict__ order, int first, int count,
                                                                  const int32_t *__restrict__ indptr,
                                                                  const int32_t *__restrict__ indices,
                                                                  const float *__restrict__ data, ST *__restrict__ X,
                                                                  const ST *__restrict__ Y, const float *__restrict__ A0,
-                                                                 int cg_steps) {
+                                                                 int cg_steps, unsigned long long *__restrict__ stats = nullptr) {
+  unsigned long long tk[6] = {0, 0, 0, 0, 0, 0}, t_last = 0, t_begin = 0, n_rows = 0;
+  auto tick = [&](int slot) {  // charge the time since the previous tick to `slot`
+    if constexpr (STATS) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      if (slot >= 0) tk[slot] += now - t_last;
+      t_last = now;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   constexpr int FC = F / 64, FE = F / 16, T = 32, WAVES = BLOCK / 64, TEAMS = WAVES / WPR, NJ = F / WPR / 4;
   constexpr bool ROLL = std::is_same<ST, float>::value;  // fp16 storage converts at the load: no rolling gather
   static_assert(WPR <= WAVES && (F / WPR) % 4 == 0, "team width");
@@ -265,6 +294,8 @@ __global__ __launch_bounds__(BLOCK, 4) void als_cg_qfteam_kernel(const int32_t *
   for (int e = threadIdx.x; e < F * F; e += BLOCK) A0s[e] = A0[e];
   if (threadIdx.x < 4 * TEAMS) ctl[threadIdx.x] = 0u;
   __syncthreads();  // the only workgroup-wide barrier: from here on the teams run their rows independently
+  tick(-1);
+  if constexpr (STATS) t_begin = t_last;
   const int j_begin = F * sub / WPR;
   float *vt = vts + (size_t)team * F;
   float *cw = cws + (size_t)wave * 64;
@@ -294,6 +325,7 @@ __global__ __launch_bounds__(BLOCK, 4) void als_cg_qfteam_kernel(const int32_t *
     if (lane == 0)
       asm volatile("ds_write_b32 %0, %1\n\tds_add_u32 %2, %3" ::"v"(words_off + 4u * (pub & 1u)), "v"(w), "v"(generation_off), "v"(1u)
                    : "memory");
+    if constexpr (IMP_TEAM_LEADER_PRIO > 0) __builtin_amdgcn_s_setprio(0);
   };
   auto poll = [&](unsigned off) {  // one ds_read_b32 of a counter, made wave-uniform
     typedef __attribute__((address_space(3))) volatile unsigned lds_word;
@@ -304,8 +336,8 @@ __global__ __launch_bounds__(BLOCK, 4) void als_cg_qfteam_kernel(const int32_t *
     if constexpr (WPR > 1) {
       // every poll costs two vector-issue slots (address + readfirstlane): the first nap covers most of the leader's update
       if (poll(generation_off) < gen) {
-        __builtin_amdgcn_s_sleep(6);
-        while (poll(generation_off) < gen) __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(IMP_TEAM_NAP_FIRST);
+        while (poll(generation_off) < gen) __builtin_amdgcn_s_sleep(IMP_TEAM_NAP_NEXT);
       }
     }
     return poll(words_off + 4u * (gen & 1u));
@@ -321,8 +353,10 @@ __global__ __launch_bounds__(BLOCK, 4) void als_cg_qfteam_kernel(const int32_t *
   auto collect = [&](float (&acc)[FC]) {  // leader: wait for the team, sum its partials in wave order
     arr_target += WPR;
     if constexpr (WPR > 1) {
-      while (poll(arrivals_off) < arr_target) __builtin_amdgcn_s_sleep(1);
+      while (poll(arrivals_off) < arr_target) __builtin_amdgcn_s_sleep(IMP_TEAM_NAP_LEADER);
     }
+    if constexpr (IMP_TEAM_LEADER_PRIO > 0) __builtin_amdgcn_s_setprio(IMP_TEAM_LEADER_PRIO);
+    tick(3);
     const float *slot = reinterpret_cast<const float *>(reinterpret_cast<const char *>(parts + (size_t)(team * WPR) * F) + cf4);
 #pragma unroll
     for (int c = 0; c < FC; ++c) acc[c] = 0.f;
@@ -396,6 +430,8 @@ __global__ __launch_bounds__(BLOCK, 4) void als_cg_qfteam_kernel(const int32_t *
       if (leader) load_compact<F>(xrow, opaque(lane), x);  // last: loads complete in order and the row starts with x
       else kill(x);
     }
+    tick(5);
+    if constexpr (STATS) ++n_rows;
     // ent_* now describe row i + i_step
     float xc[FC], r[FC], p[FC], Ap[FC], rsold = 0.f;  // leader state
 #pragma unroll
@@ -406,12 +442,16 @@ __global__ __launch_bounds__(BLOCK, 4) void als_cg_qfteam_kernel(const int32_t *
 #pragma unroll
       for (int cc = 0; cc < FC; ++cc) xc[cc] = x[cc];  // this row's iterate moves on as xc; x is re-loaded for the next row
       publish(kGo);
+      tick(4);
     }
     unsigned w = await_operand();
+    tick(0);
     {
       float acc[FC];
       fused_pass<F, NJ, true, false, ST>(y, cw, cnt, vt, j_begin, A0s, acc, lane, 0, ent_col, ent_c, Y, nullptr, nullptr, 0, 0);
+      tick(1);
       arrive(acc);
+      tick(2);
     }
     if (leader) {
       collect(r);
@@ -425,12 +465,16 @@ __global__ __launch_bounds__(BLOCK, 4) void als_cg_qfteam_kernel(const int32_t *
       } else {
         publish(0u);
       }
+      tick(4);
     }
     w = await_operand();
+    tick(0);
     for (int it = 0; (w & (kGo | kLast)) == kGo; ++it) {  // all steps but the last
       float acc[FC];
       fused_pass<F, NJ, false, false, ST>(y, cw, cnt, vt, j_begin, A0s, acc, lane, 0, ent_col, ent_c, Y, nullptr, nullptr, 0, 0);
+      tick(1);
       arrive(acc);
+      tick(2);
       if (leader) {
         collect(Ap);
         get_operand(p);
@@ -451,8 +495,10 @@ __global__ __launch_bounds__(BLOCK, 4) void als_cg_qfteam_kernel(const int32_t *
           put_operand(p);
           publish(kGo | (it + 2 >= cg_steps ? kLast : 0u));
         }
+        tick(4);
       }
       w = await_operand();
+      tick(0);
     }
     // The last step stands outside the loop (the compiler must see that nothing of the row follows it): its pass rolls
     // the next row's tile in, and only its x update is evaluated -- the oracle's r, rsnew and p of the last step
@@ -474,7 +520,9 @@ __global__ __launch_bounds__(BLOCK, 4) void als_cg_qfteam_kernel(const int32_t *
         kill(x);
         fused_pass<F, NJ, false, false, ST>(y, cw, cnt, vt, j_begin, A0s, acc, lane, 0, ent_col, ent_c, Y, nullptr, nullptr, 0, 0);
       }
+      tick(1);
       arrive(acc);
+      tick(2);
       if (leader) {
         collect(Ap);
         get_operand(p);
@@ -482,8 +530,10 @@ __global__ __launch_bounds__(BLOCK, 4) void als_cg_qfteam_kernel(const int32_t *
 #pragma unroll
         for (int cc = 0; cc < FC; ++cc) xc[cc] = fmaf(alpha, p[cc], xc[cc]);
         publish(0u);
+        tick(4);
       }
       (void)await_operand();  // the stop generation: keeps every wave's count in step with the leader's
+      tick(0);
     } else {
       kill(x);
     }
@@ -491,6 +541,14 @@ __global__ __launch_bounds__(BLOCK, 4) void als_cg_qfteam_kernel(const int32_t *
     tile_ready = rolled;
     id0 = id1, id1 = id2, id2 = id3, id3 = row_id(i + 4 * i_step);
     b0 = b1, e0 = e1, b1 = b2, e1 = e2, b2 = indptr[id2], e2 = indptr[id2 + 1];
+  }
+  if constexpr (STATS) {
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) atomicAdd(&stats[k], tk[k]);
+      atomicAdd(&stats[6], (unsigned long long)__builtin_amdgcn_s_memtime() - t_begin);
+      atomicAdd(&stats[7], n_rows);
+    }
   }
 }
 
@@ -505,9 +563,29 @@ static void launch_qfteam(const imp_csr *C, int first, int count, T *X, const T 
   int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / BLOCK, (160 * 1024) / lds));
   constexpr int kBaseOversub = WPR <= 4 ? 4 : (WPR == 8 ? 2 : 1);  // als_cg_q.hip launch_qteam
   int grid = std::min((count + TEAMS - 1) / TEAMS, ctx().num_cus * per_cu * std::max(kBaseOversub, ctx().oversub));
+  static const bool want_stats = getenv("IMP_CG_STATS") != nullptr;
+  if (want_stats) {  // debug: per-phase cycle sums of this launch on stderr (instrumented instantiation: timings only)
+    static unsigned long long *stats = nullptr;
+    if (!stats) IMP_CHECK_HIP(hipMalloc(&stats, 8 * sizeof(unsigned long long)));
+    IMP_CHECK_HIP(hipMemsetAsync(stats, 0, 8 * sizeof(unsigned long long), stream()));
+    auto skern = als_cg_qfteam_kernel<F, WPR, BLOCK, T, true>;
+    IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(skern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    skern<<<grid, BLOCK, lds, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(), C->data.data(), X, Y, A0,
+                                          cg_steps, stats);
+    unsigned long long h[8];
+    IMP_CHECK_HIP(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, stream()));
+    IMP_CHECK_HIP(hipStreamSynchronize(stream()));
+    const double n = (double)std::max<unsigned long long>(1, h[7]);
+    const double leaders = n / WPR;
+    fprintf(stderr,
+            "[cg-stats] %s rows=%d wave-rows=%.0f  cycles/wave-row: wait-operand %.0f  passes %.0f  arrive %.0f  row-start %.0f  "
+            "lifetime %.0f | per leader-row: wait-arrivals %.0f  update %.0f\n",
+            name, count, n, h[0] / n, h[1] / n, h[2] / n, h[5] / n, h[6] / n, h[3] / leaders, h[4] / leaders);
+    return;
+  }
   IMP_PROF(name);
   kern<<<grid, BLOCK, lds, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(), C->data.data(), X, Y,
-                                      A0, cg_steps);
+                                      A0, cg_steps, nullptr);
   IMP_CHECK_HIP(hipGetLastError());
 }
 

@@ -7,6 +7,7 @@
 #include <hip/hip_fp16.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -559,6 +560,15 @@ int imp_intvector_destroy(imp_intvector *v) {
 int imp_csr_create(int32_t rows, int32_t cols, int64_t nnz, const int32_t *indptr, const int32_t *indices,
                    const float *data, imp_csr **out) {
   return guarded([&] {
+    static const bool timing = getenv("IMP_CSR_TIMING") != nullptr;  // debug: where the construction time goes, on stderr
+    auto t_mark = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+      if (!timing) return;
+      sync();
+      auto now = std::chrono::steady_clock::now();
+      fprintf(stderr, "[csr-timing] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_mark).count());
+      t_mark = now;
+    };
     if (rows < 0 || cols < 0 || nnz < 0) throw std::invalid_argument("negative dimension for CSRMatrix");
     if (nnz > INT32_MAX) throw std::invalid_argument("CSRMatrix with more than 2^31-1 nonzeros is not supported");
     if (rows && indptr[rows] != nnz) throw std::invalid_argument("indptr[rows] != nonzeros for CSRMatrix");
@@ -577,6 +587,7 @@ int imp_csr_create(int32_t rows, int32_t cols, int64_t nnz, const int32_t *indpt
         throw std::invalid_argument("column index out of range for CSRMatrix (" + std::to_string(lo < 0 ? lo : hi) + " not in [0, " +
                                     std::to_string(cols) + "))");
     }
+    lap("validation");
     auto m = std::make_unique<imp_csr>();
     m->rows = rows;
     m->cols = cols;
@@ -584,6 +595,7 @@ int imp_csr_create(int32_t rows, int32_t cols, int64_t nnz, const int32_t *indpt
     m->indptr.upload(indptr, (size_t)rows + 1);
     m->indices.upload(indices, (size_t)nnz);
     m->data.upload(data, (size_t)nnz);
+    lap("upload indptr/indices/data");
 
     // Row schedule: counting sort of row ids by descending length, cut into length classes.
     int32_t segment = imp_csr::kSegment;
@@ -606,6 +618,7 @@ int imp_csr_create(int32_t rows, int32_t cols, int64_t nnz, const int32_t *indpt
     std::vector<int32_t> order((size_t)rows);
     for (int32_t r = 0; r < rows; ++r) order[start[indptr[r + 1] - indptr[r]]++] = r;
     m->order.upload(order.data(), order.size());
+    lap("row schedule (counting sort)");
     m->bin_start[0] = 0;
     for (int b = 0; b < imp_csr::kBins; ++b) m->bin_start[b + 1] = m->bin_start[b] + class_count[b];
     const int32_t n_long = class_count[0];
@@ -636,7 +649,12 @@ int imp_csr_create(int32_t rows, int32_t cols, int64_t nnz, const int32_t *indpt
         long_nnz += indptr[r + 1] - indptr[r];
         if (stripe > 0 && sorted) sorted = std::is_sorted(indices + indptr[r], indices + indptr[r + 1]);
       }
-      const bool striped = stripe > 0 && sorted && n_plan > 0 && (double)long_nnz >= stripe_reuse * (double)cols;
+      // ... and only when a row still leaves >= 32 nonzeros per stripe on average: with many more stripes than that (configs[3]'s
+      // item side: 10 M columns = 814 stripes under rows of ~800 nonzeros) the cut would produce one- and two-entry segments,
+      // hundreds of millions of them (23 s of plan building before this rule)
+      const int64_t n_stripes_all = stripe > 0 ? ((int64_t)cols + stripe - 1) / stripe : 1;
+      const bool striped = stripe > 0 && sorted && n_plan > 0 && (double)long_nnz >= stripe_reuse * (double)cols &&
+                           (double)long_nnz >= 32.0 * (double)n_stripes_all * (double)n_plan;
       std::vector<int32_t> row_seg((size_t)n_plan + 1, 0), seg_row, seg_begin, seg_end, seg_stripe;
       for (int32_t li = 0; li < n_plan; ++li) {
         const int32_t r = order[li];
@@ -716,6 +734,7 @@ int imp_csr_create(int32_t rows, int32_t cols, int64_t nnz, const int32_t *indpt
       sync();  // the uploads read pageable host vectors that die with this scope
     };
     build_plan(n_long, m->plan_all, stripe_reuse, segment);
+    lap("long-row plan (all)");
     // rows within reach of the cluster-resident kernels (als_cg_cluster.hip) leave the streamed plan of the f = 64 / 128 path
     for (int i = 0; i < 3; ++i) {
       int32_t longer = 0;  // rows strictly longer than kClusterRow >> i (order is sorted by descending length)
@@ -729,6 +748,7 @@ int imp_csr_create(int32_t rows, int32_t cols, int64_t nnz, const int32_t *indpt
     static_assert(imp_csr::kCholLongRow == imp_csr::kClusterRow >> 2, "plan_chol covers order[0 .. cluster_cut[2])");
     build_plan(m->cluster_cut[2], m->plan_chol, 1e30, imp_csr::kCholSegment);  // never striped
     sync();
+    lap("long-row plans (xl, chol)");
     *out = m.release();
   });
 }

@@ -912,12 +912,14 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
     size_t temp = std::min<size_t>(knn->max_temp_memory, (size_t)4 << 30);
     size_t batch = std::max<size_t>(1, std::min<size_t>(nq, temp / (sizeof(float) * ni)));
     static const bool no_emit_alloc = getenv("IMP_TOPK_NO_EMIT") != nullptr;
-    // emit path (no score matrix) whenever the pre-pass subset is a usable sample: every `stride`-th 128-item block, the stride
-    // chosen so that the expected candidate list (stride x k) fills at most half of a query's kEmitCap slots, and the subset at
-    // least 4 k items (catalogues of a few thousand items and up; configs[4]'s 26 744 items at k = 100 run with stride 20)
-    const int stride = std::max(2, std::min(kSubStride, kEmitCap / (2 * std::max(1, k_eff))));
-    const bool emit_shape = (f % 8 == 0) && k_eff == k && k_eff <= 256 && ni >= 4096 &&
-                            ((ni + 127) / 128 + stride - 1) / stride * 128 >= (size_t)4 * k_eff;
+    // emit path (no score matrix) when the candidate lists stay SPARSE: every `stride`-th 128-item block is scored first and
+    // about stride x k entries per query survive its threshold.  The stride is chosen so that they fill at most half of a
+    // query's kEmitCap slots AND are at most one in 64 of the items -- every 64-item tile with a survivor costs an atomic on
+    // the query's counter and a scattered store (measured at configs[4]'s similar_items shape, 26 744 items, k = 100,
+    // stride 20: 7.5 % of all scores survive and the emit GEMM runs at 10 TFLOP/s against 33 for the materialising path) --
+    // and a stride below 8 (a pre-pass of more than an eighth of the GEMM) is not worth it either.
+    const int stride = (int)std::min<size_t>(std::min(kSubStride, kEmitCap / (2 * std::max(1, k_eff))), ni / ((size_t)64 * std::max(1, k_eff)));
+    const bool emit_shape = (f % 8 == 0) && k_eff == k && k_eff <= 256 && stride >= 8;
     const bool will_emit = !no_emit_alloc && getenv("IMP_TOPK_NO_FAST") == nullptr && emit_shape;
     float *scores = will_emit ? nullptr : imp_knn::ensure(knn->scores, batch * ni);  // the emit path materialises fallback rows only
     const bool use_lds = (size_t)kpad * 8 <= 96 * 1024;

@@ -244,7 +244,7 @@ class CSRMatrix:
 
     def __init__(self, X):
         X = check_csr(X)
-        data = np.ascontiguousarray(X.data.astype(np.float32))
+        data = np.ascontiguousarray(X.data.astype(np.float32, copy=False))
         self._h = ctypes.c_void_p()
         self.shape = X.shape
         self.nnz = len(data)

@@ -6,7 +6,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libimplicit_hip.so")
+# IMP_LIB_PATH: an alternative build of the same library (A/B of compile-time variants, profiles/scripts/*.sh)
+LIB_PATH = os.environ.get("IMP_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "libimplicit_hip.so")
 
 c_void_pp = ctypes.POINTER(ctypes.c_void_p)
 c_i32_p = ctypes.POINTER(ctypes.c_int32)

@@ -133,7 +133,10 @@ class MatrixFactorizationBase(RecommenderBase):
         raise NotImplementedError("recalculate_item is not supported with this model")
 
     def _check_fit_errors(self):
-        self._check_factors(self.user_factors.to_numpy(), self.item_factors.to_numpy())
+        """NaN factors raise ModelFitError (cpu/matrix_factorization_base.py:249-250).  Checked through the row norms,
+        computed on the device: a NaN anywhere in a row makes that row's norm NaN, and rows x 4 bytes come back instead
+        of both factor matrices (0.33 GB at configs[2] -- a fifth of fit()'s set-up time)."""
+        self._check_factors(gpu.calculate_norms(self.user_factors).to_numpy(), gpu.calculate_norms(self.item_factors).to_numpy())
 
     # ---- pickling: device arrays travel as numpy (gpu/matrix_factorization_base.py:220-234) --------
     def __getstate__(self):

@@ -174,29 +174,37 @@ def test_fp16_factors_are_scored_as_stored(gpu, oracle, ni, k, f):
     assert_array_equal(got_ids, ref_ids)          # the same MFMA accumulations on the same values: bit for bit
     assert_array_equal(got_d, ref_d)
     want_ids, want_d = oracle.topk(items32, q32, k, item_norms=norms32.to_numpy().reshape(-1), filter_query_items=liked)
-    ok = ~_near_tie_rows(want_d, f)
-    assert ok.mean() > 0.8
-    assert_array_equal(got_ids[ok], want_ids[ok])
     assert_allclose(got_d, want_d, rtol=3e-5)
+    # ids against the oracle: identical, except where two scores are closer than the fp32 summation-order noise (k = 100 sorted
+    # scores of fp16-valued factors sit close together) -- there the id the GPU chose must HAVE that rank's score in fp64
+    i64, q64, n64 = items32.astype(np.float64), q32.astype(np.float64), norms32.to_numpy().reshape(-1).astype(np.float64)
+    differ = got_ids != want_ids
+    assert differ.mean() < 0.05
+    for r, j in zip(*np.nonzero(differ)):
+        exact = i64[got_ids[r, j]] @ q64[r] / n64[got_ids[r, j]]
+        assert abs(exact - want_d[r, j]) <= 4 * f * np.finfo(np.float32).eps * max(abs(want_d[r, j]), 1e-30), (r, j)
 
 
 def test_emit_path_covers_small_catalogues(gpu, oracle):
-    """The score-matrix-free path now runs from a few thousand items up (the stride of its threshold subset adapts to k):
-    configs[4]'s similar_items shape (26 744 items, k = 100, norms) and a 5 000-item catalogue against the oracle."""
+    """The score-matrix-free path runs wherever the candidate lists stay sparse (stride x k survivors <= items / 64, stride
+    adapted to k, >= 8): 6 000 and 26 744 items at k = 10 take it, configs[4]'s similar_items shape (26 744 items, k = 100)
+    and a 5 000-item catalogue stay on the materialising path -- all against the oracle, duplicated rows (exact ties) included."""
     rng = np.random.default_rng(8)
-    for ni, k, f in ((26_744, 100, 256), (5_000, 10, 64), (5_000, 100, 64)):
+    for ni, k, f in ((26_744, 100, 256), (26_744, 10, 256), (6_000, 10, 64), (5_000, 100, 64)):
         items = (rng.standard_normal((ni, f)) * 0.1).astype(np.float32)
         items[::11] = items[5]                      # duplicated rows: exact ties, some at the k-th score
         q = items[rng.choice(ni, 130, replace=False)]
         norms = gpu.calculate_norms(gpu.Matrix(items))
         ids, d = gpu.KnnQuery().topk(gpu.Matrix(items), gpu.Matrix(q), k, item_norms=norms)
-        want_ids1, want_d1 = oracle.topk(items, q, k + 1, item_norms=norms.to_numpy().reshape(-1))
-        want_ids, want_d = want_ids1[:, :k], want_d1[:, :k]
+        nh = norms.to_numpy().reshape(-1)
+        want_ids, want_d = oracle.topk(items, q, k, item_norms=nh)
         assert_allclose(d, want_d, rtol=3e-5)
-        # rows whose top-(k+1) holds two DIFFERENT scores closer than the fp32 summation noise may legitimately swap them;
-        # exact ties (the duplicated rows) follow the reference heap's arrival-order rule and must match like everything else
-        gaps = np.abs(np.diff(want_d1.astype(np.float64), axis=1))
-        scale = np.abs(want_d1[:, :-1]).astype(np.float64) + 1e-30
-        ok = ~((gaps > 0) & (gaps < 4 * np.finfo(np.float32).eps * f * scale)).any(axis=1)
-        assert ok.mean() > 0.7
-        assert_array_equal(ids[ok], want_ids[ok])
+        # ids identical to the oracle's -- exact ties (the duplicated rows) follow the reference heap's arrival-order rule --
+        # except where two DIFFERENT scores are closer than the fp32 summation noise: there the id the GPU put at a rank
+        # must have that rank's score in fp64
+        differ = ids != want_ids
+        assert differ.mean() < 0.05
+        i64, q64 = items.astype(np.float64), q.astype(np.float64)
+        for r, j in zip(*np.nonzero(differ)):
+            exact = i64[ids[r, j]] @ q64[r] / nh[ids[r, j]]
+            assert abs(exact - want_d[r, j]) <= 4 * f * np.finfo(np.float32).eps * max(abs(want_d[r, j]), 1e-30), (ni, k, r, j)
