@@ -92,6 +92,7 @@ def class_bytes_per_iteration(Cui, Ciu, f):
 # substring of the kernel function name -> (schedule class, dispatches per half sweep as a function of cg_steps)
 PMC_KERNELS = {"als_cg_group_kernel": ("short", lambda s: 1), "als_cg_team_kernel": ("mid", lambda s: 1),
                "als_cg_qgroup_kernel": ("short", lambda s: 1), "als_cg_qteam_kernel": ("mid", lambda s: 1),
+               "als_cg_qfgroup_kernel": ("short", lambda s: 1), "als_cg_qfteam_kernel": ("mid", lambda s: 1),
                "cg_long_partial": ("long", lambda s: 1 + s), "cg_long_combine_kernel": ("long", lambda s: 1 + s),
                "als_cg_cluster_kernel": ("long", lambda s: 1)}
 
