@@ -604,7 +604,21 @@ template <int F> struct QFGroupCfg {
   static constexpr int KH = 16 / NT;        // K-slices so that NT * KH == 16 waves
   static constexpr int KB = (F / 16) / KH;  // 16-factor k-blocks per wave
   static constexpr size_t lds_floats = (size_t)F * LD + 16 * LD + (size_t)KH * 16 * LD + 16 * 64;
+  // BF3 form (f = 128): the gramian and the operands as three bf16 terms each (hi + mid + lo = the fp32 value to 2^-24),
+  // rows of LDB bf16; the fp32 gramian image is not kept
+  static constexpr int LDB = F + 8;
+  static constexpr size_t lds_bytes_bf3 = (size_t)3 * F * LDB * 2 + (size_t)3 * 16 * LDB * 2 +
+                                          ((size_t)16 * LD + (size_t)KH * 16 * LD + 16 * 64) * sizeof(float);
 };
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// x = hi + mid + lo + O(2^-24 |x|): every term the nearest bf16 of what is left (the subtractions are exact in fp32)
+__device__ __forceinline__ void split_bf16(float x, __bf16 &hi, __bf16 &mid, __bf16 &lo) {
+  hi = (__bf16)x;
+  const float r1 = x - (float)hi;
+  mid = (__bf16)r1;
+  lo = (__bf16)(r1 - (float)mid);
+}
 
 // tile part of a pass: acc (compact) = sum over the resident entries of w y, operand read expanded from `vrow` (natural order)
 //   FIRST: w = c+ - (|c|-1) y.x   else: w = (|c|-1) y.v
@@ -663,7 +677,7 @@ __device__ __forceinline__ void tile_pass(f32x2 (&y)[8][F / 32], float *cw, int 
   reduce_expanded<F>(aes, acc);
 }
 
-template <int F, typename ST>
+template <int F, bool STAGGER, bool BF3, typename ST>
 __global__ __launch_bounds__(1024) void als_cg_qfgroup_kernel(const int32_t *__restrict__ order, int first, int count,
                                                               const int32_t *__restrict__ indptr,
                                                               const int32_t *__restrict__ indices,
@@ -673,15 +687,25 @@ __global__ __launch_bounds__(1024) void als_cg_qfgroup_kernel(const int32_t *__r
   constexpr int FC = F / 64, FE = F / 16, LD = Cfg::LD;
   constexpr bool ROLL = std::is_same<ST, float>::value;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *A0s = smem;                                   // [F][LD]
-  float *Ps = A0s + (size_t)F * LD;                    // [16][LD]  operands of the 16 rows (natural factor order)
+  constexpr int LDB = Cfg::LDB;
+  // fp32 form: [A0s F x LD][Ps][Outs][cws]      BF3 form: [A0 hi | mid | lo, bf16 F x LDB each][Pb hi | mid | lo, 16 x LDB][Ps][Outs][cws]
+  __bf16 *A0b = reinterpret_cast<__bf16 *>(smem);       // BF3: term t at A0b + t F LDB
+  __bf16 *Pb = A0b + (size_t)3 * F * LDB;               // BF3: term t at Pb + t 16 LDB
+  float *A0s = smem;                                   // fp32 form: [F][LD]
+  float *Ps = BF3 ? reinterpret_cast<float *>(Pb + (size_t)3 * 16 * LDB) : A0s + (size_t)F * LD;  // [16][LD] operands (natural order)
   float *Outs = Ps + 16 * LD;                          // [KH][16][LD]  K-slice partial products
   float *cws = Outs + (size_t)Cfg::KH * 16 * LD;       // [16][64]  per-entry weights (gather_pair)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (int e = threadIdx.x; e < F * F; e += 1024) {
     int r = e / F, c = e - r * F;
-    A0s[r * LD + c] = A0[e];
+    if constexpr (BF3) {
+      __bf16 h, m, l;
+      split_bf16(A0[e], h, m, l);
+      A0b[r * LDB + c] = h, A0b[(size_t)F * LDB + r * LDB + c] = m, A0b[(size_t)2 * F * LDB + r * LDB + c] = l;
+    } else {
+      A0s[r * LD + c] = A0[e];
+    }
   }
   __syncthreads();
   float *prow = Ps + (size_t)wave * LD;
@@ -689,14 +713,51 @@ __global__ __launch_bounds__(1024) void als_cg_qfgroup_kernel(const int32_t *__r
   const unsigned cf = (unsigned)QL<F>::cfactor(lane, 0);  // this lane's compact slots inside a natural-order vector
 
   // out (compact) = A0 . vec for this wave's row; every wave of the workgroup takes both barriers (inactive rows publish 0)
-  auto dense = [&](const float (&vec)[FC], bool valid, float (&out)[FC]) {
+  auto publish = [&](const float (&vec)[FC], bool valid) {
     if constexpr (FC == 2) *reinterpret_cast<float2 *>(prow + cf) = valid ? make_float2(vec[0], vec[1]) : make_float2(0.f, 0.f);
     else prow[cf] = valid ? vec[0] : 0.f;
+    if constexpr (BF3) {  // the same operand as three bf16 terms for the matrix cores (FC == 2: one packed pair per term)
+      bf16x2 t[3];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        __bf16 h, m, l;
+        split_bf16(valid ? vec[c] : 0.f, h, m, l);
+        t[0][c] = h, t[1][c] = m, t[2][c] = l;
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) *reinterpret_cast<bf16x2 *>(Pb + (size_t)k * 16 * LDB + (size_t)wave * LDB + cf) = t[k];
+    }
     __syncthreads();
+  };
+  auto product = [&]() {  // this wave's (output tile, K-slice) of A0 . P^T for the 16 rows -> Outs
     const int ti = wave % Cfg::NT, kh = wave / Cfg::NT;
     const int ln = opaque(lane);
     const int i = ln & 15, kq = ln >> 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (BF3) {
+      // fp32-equivalent product on the bf16 matrix cores: A0 = Ah + Am + Al, p = ph + pm + pl (each to 2^-24), and the six
+      // partial products down to 2^-16 relative weight, smallest first, accumulated in fp32 -- 12 MFMAs of K = 32 per wave
+      // and pass instead of 16 fp32 MFMAs of K = 4, at a quarter of the instruction time each, and on hardware the vector
+      // pipe does not share (v_mfma_f32_16x16x4_f32 runs at the VECTOR rate and, measured, does not overlap with the tile
+      // entries' packed FMAs; these do).  A and B fragments use the same (lane group, element) -> k assignment, which is all
+      // the contraction needs.
+      static_assert(!BF3 || Cfg::KB * 16 == 64, "BF3 product: 64 k per wave");
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int k0 = kh * 64 + 32 * b + 8 * kq;
+        const __bf16 *ar = A0b + (size_t)(16 * ti + i) * LDB + k0, *pr = Pb + (size_t)i * LDB + k0;
+        const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(ar), am = *reinterpret_cast<const bf16x8 *>(ar + (size_t)F * LDB),
+                     al = *reinterpret_cast<const bf16x8 *>(ar + (size_t)2 * F * LDB);
+        const bf16x8 ph = *reinterpret_cast<const bf16x8 *>(pr), pm = *reinterpret_cast<const bf16x8 *>(pr + (size_t)16 * LDB),
+                     pl = *reinterpret_cast<const bf16x8 *>(pr + (size_t)2 * 16 * LDB);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, ph, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, pl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, pm, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, ph, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, pm, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ph, acc, 0, 0, 0);
+      }
+    } else {
 #pragma unroll
     for (int kb = 0; kb < Cfg::KB; ++kb) {
       const int k0 = (kh * Cfg::KB + kb) * 16 + 4 * kq;
@@ -707,8 +768,10 @@ __global__ __launch_bounds__(1024) void als_cg_qfgroup_kernel(const int32_t *__r
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
     }
+    }
     *reinterpret_cast<float4 *>(Outs + (kh * 16 + i) * LD + 16 * ti + 4 * kq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    __syncthreads();
+  };
+  auto collect = [&](float (&out)[FC]) {  // after the barrier that follows the product: the K-slices of this wave's row
 #pragma unroll
     for (int c = 0; c < FC; ++c) out[c] = 0.f;
 #pragma unroll
@@ -722,6 +785,19 @@ __global__ __launch_bounds__(1024) void als_cg_qfgroup_kernel(const int32_t *__r
       }
     }
   };
+  auto dense = [&](const float (&vec)[FC], bool valid, float (&out)[FC]) {
+    publish(vec, valid);
+    product();
+    __syncthreads();
+    collect(out);
+  };
+  // STAGGER: between the two barriers of a pass every wave has a matrix-pipe block (its 4 KB MFMAs of the 16-row product) and a
+  // vector-pipe block (its own row's tile entries, which need only the operand it published itself).  With all waves of a
+  // SIMD in the same block one pipe idled while the other worked (knock-outs: the product, the tile entries and the barriers
+  // each "cost" 40 % of the kernel).  Waves 0-3 and 8-11 now run the product first, waves 4-7 and 12-15 their tile entries
+  // first -- two of each kind per SIMD (wave w sits on SIMD w mod 4) -- so the pipes work side by side, with the same
+  // barriers and the same arithmetic.
+  const bool product_first = ((wave >> 2) & 1) == 0;
 
   const int groups = (count + 15) / 16, g_step = gridDim.x;
   // row of this wave in group g (groups past the end and rows past the count re-read the last row and stay invalid)
@@ -761,17 +837,35 @@ __global__ __launch_bounds__(1024) void als_cg_qfgroup_kernel(const int32_t *__r
 #pragma unroll
     for (int cc = 0; cc < FC; ++cc) xc[cc] = x[cc];
     // r = -(A0 x) + sum_k (c+ - (|c|-1) y.x) y        (_als.pyx:187-201)
-    dense(xc, valid, Ap);
-    tile_pass<F, true, false, ST>(y, cw, cnt, prow, sp, lane, 0, ent_col, ent_c, Y);
+    if constexpr (STAGGER) {
+      publish(xc, valid);
+      if (!product_first) tile_pass<F, true, false, ST>(y, cw, cnt, prow, sp, lane, 0, ent_col, ent_c, Y);
+      product();
+      if (product_first) tile_pass<F, true, false, ST>(y, cw, cnt, prow, sp, lane, 0, ent_col, ent_c, Y);
+      __syncthreads();
+      collect(Ap);
+    } else {
+      dense(xc, valid, Ap);
+      tile_pass<F, true, false, ST>(y, cw, cnt, prow, sp, lane, 0, ent_col, ent_c, Y);
+    }
 #pragma unroll
     for (int cc = 0; cc < FC; ++cc) p[cc] = r[cc] = sp[cc] - Ap[cc];
     float rsold = dot_compact<F>(r, r);
     bool active = valid && rsold >= 1e-20f;  // else: x untouched (_als.pyx:206)
     const bool store = active;
     for (int it = 0; it + 1 < cg_steps; ++it) {  // all steps but the last; every wave takes the barriers of dense()
-      dense(p, active, Ap);
+      if constexpr (STAGGER) {
+        publish(p, active);
+        if (active && !product_first) tile_pass<F, false, false, ST>(y, cw, cnt, prow, sp, lane, 0, ent_col, ent_c, Y);
+        product();
+        if (active && product_first) tile_pass<F, false, false, ST>(y, cw, cnt, prow, sp, lane, 0, ent_col, ent_c, Y);
+        __syncthreads();
+        collect(Ap);
+      } else {
+        dense(p, active, Ap);
+      }
       if (active) {  // wave-uniform
-        tile_pass<F, false, false, ST>(y, cw, cnt, prow, sp, lane, 0, ent_col, ent_c, Y);
+        if constexpr (!STAGGER) tile_pass<F, false, false, ST>(y, cw, cnt, prow, sp, lane, 0, ent_col, ent_c, Y);
 #pragma unroll
         for (int cc = 0; cc < FC; ++cc) Ap[cc] += sp[cc];
         const float alpha = rsold * __builtin_amdgcn_rcpf(dot_compact<F>(p, Ap));
@@ -795,17 +889,30 @@ __global__ __launch_bounds__(1024) void als_cg_qfgroup_kernel(const int32_t *__r
     // rolls the next group's entries in
     bool rolled = false;
     if (cg_steps > 0) {
-      dense(p, active, Ap);
+      if constexpr (STAGGER) {
+        publish(p, active);
+        auto last_tiles = [&]() {
+          if constexpr (ROLL) tile_pass<F, false, true, ST>(y, cw, cnt, prow, sp, lane, ent_cnt, ent_col, ent_c, Y);
+          else tile_pass<F, false, false, ST>(y, cw, cnt, prow, sp, lane, 0, ent_col, ent_c, Y);
+        };
+        if (active && !product_first) last_tiles();
+        product();
+        if (active && product_first) last_tiles();
+        __syncthreads();
+        collect(Ap);
+      } else {
+        dense(p, active, Ap);
+      }
       if (active) {
         if constexpr (ROLL) {
-          tile_pass<F, false, true, ST>(y, cw, cnt, prow, sp, lane, ent_cnt, ent_col, ent_c, Y);
+          if constexpr (!STAGGER) tile_pass<F, false, true, ST>(y, cw, cnt, prow, sp, lane, ent_cnt, ent_col, ent_c, Y);
           cnt = ent_cnt;
           ent_cnt = row_valid(g + 2 * g_step) ? e2 - b2 : 0;
           fetch_entries(indices, data, opaque(lane), b2, max(e2, b2 + 1), ent_col, ent_c);
           load_compact<F>(X + (size_t)id1 * F, opaque(lane), x);
           rolled = true;
         } else {
-          tile_pass<F, false, false, ST>(y, cw, cnt, prow, sp, lane, 0, ent_col, ent_c, Y);
+          if constexpr (!STAGGER) tile_pass<F, false, false, ST>(y, cw, cnt, prow, sp, lane, 0, ent_col, ent_c, Y);
           kill(x);
         }
 #pragma unroll
@@ -829,8 +936,13 @@ __global__ __launch_bounds__(1024) void als_cg_qfgroup_kernel(const int32_t *__r
 template <int F, typename T>
 static void launch_qfgroup(const imp_csr *C, int first, int count, T *X, const T *Y, const float *A0, int cg_steps, const char *name) {
   if (count <= 0) return;
-  size_t lds = QFGroupCfg<F>::lds_floats * sizeof(float);
-  auto kern = als_cg_qfgroup_kernel<F, T>;
+  // IMP_SHORT_STAGGER=0: every wave runs the product first, then its tile entries (the first round-3 form; A/B)
+  static const bool stagger = !(getenv("IMP_SHORT_STAGGER") && atoi(getenv("IMP_SHORT_STAGGER")) == 0);
+  // IMP_SHORT_BF16X3=0: the gramian product on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains) instead of the split-bf16 form
+  static const bool bf3 = F == 128 && !(getenv("IMP_SHORT_BF16X3") && atoi(getenv("IMP_SHORT_BF16X3")) == 0);
+  size_t lds = bf3 ? QFGroupCfg<F>::lds_bytes_bf3 : QFGroupCfg<F>::lds_floats * sizeof(float);
+  auto kern = bf3 ? (stagger ? als_cg_qfgroup_kernel<F, true, F == 128, T> : als_cg_qfgroup_kernel<F, false, F == 128, T>)
+                  : (stagger ? als_cg_qfgroup_kernel<F, true, false, T> : als_cg_qfgroup_kernel<F, false, false, T>);
   IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   static const int per_cu = getenv("IMP_QGROUP_PER_CU") ? std::max(1, atoi(getenv("IMP_QGROUP_PER_CU"))) : 2;
   int grid = std::min((count + 15) / 16, ctx().num_cus * std::max(per_cu, ctx().oversub));
