@@ -412,6 +412,7 @@ def main():
 
 
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
+BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 
 def _time_iterations(gpu, step, iters=3, warmup=1):
@@ -591,9 +592,11 @@ def extra_c5(gpu, SHAPES):
     sim_flops = 2.0 * batch * Y.shape[0] * f
     sim_roofline = None
     if gemm_ms > 0:
+        sim_peak = BF16_PEAK_TFLOPS / 6.0 if os.environ.get("IMP_TOPK_FP32_MFMA") is None else FP32_PEAK_TFLOPS
         sim_roofline = {"bound": "mfma", "kernel": "score_gemm_direct_kernel", "achieved": sim_flops / (gemm_ms * 1e-3) / 1e12,
-                        "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": sim_flops / (gemm_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
-                        "avg_launch_ms": gemm_ms, "flops_per_launch": sim_flops, "traffic": None}
+                        "peak": sim_peak, "unit": "TFLOP/s", "frac": sim_flops / (gemm_ms * 1e-3) / 1e12 / sim_peak,
+                        "avg_launch_ms": gemm_ms, "flops_per_launch": sim_flops, "traffic": None,
+                        "note": "fp32-equivalent flops; peak = dense bf16 MFMA / 6 partial products of the split-bf16 form"}
     return {"cg_c5": {"workload": "BASELINE configs[4]: 138,493 x 26,744, %d nnz, f=256 fp32, CG cg_steps=%d" % (C.nnz, CG_STEPS),
                       "ms_per_iter": 1e3 * t_cg, "updates_per_s": rows / t_cg,
                       "roofline": {"bound": "hbm", "achieved": gb / t_cg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -728,10 +731,15 @@ def bench_topk(gpu, Cui, X, Y, k=10, queries=20_000, batch=1000):
     roofline = None
     if gemm_ms > 0:
         tf = per_batch_flops / (gemm_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "score_gemm_direct_kernel<2> (emit epilogue)", "achieved": tf, "peak": FP32_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS, "avg_launch_ms": gemm_ms,
+        split = os.environ.get("IMP_TOPK_FP32_MFMA") is None and Y.shape[1] % 16 == 0
+        peak = BF16_PEAK_TFLOPS / 6.0 if split else FP32_PEAK_TFLOPS
+        roofline = {"bound": "mfma", "kernel": "score_gemm_direct_kernel<2> (emit epilogue)", "achieved": tf, "peak": peak,
+                    "unit": "TFLOP/s", "frac": tf / peak, "avg_launch_ms": gemm_ms,
                     "flops_per_launch": per_batch_flops, "traffic": None,
-                    "note": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32); 2 x batch x items x f flops per launch"}
+                    "note": ("fp32-equivalent flops (2 x batch x items x f per launch); the product runs as 6 bf16 partial products "
+                             "of three-way split operands on v_mfma_f32_32x32x16_bf16 (fp32 accumulation, error below an fp32 FMA "
+                             "chain's): peak = 2500 TFLOP/s dense bf16 / 6") if split else
+                            "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32); 2 x batch x items x f flops per launch"}
     # the model-level call a user makes (recommend(): host COO build of the liked items + upload + KnnQuery.topk per batch)
     rec = None
     try:

@@ -283,8 +283,31 @@ struct EmitArgs {
 // TQ / TI: storage type of the query / item factors (float or __half).  fp16 factors are read as they are stored and
 // converted in registers (8-byte loads; the reference hands fp16 operands straight to the GEMM with fp32 accumulation,
 // implicit/gpu/knn.cu:117-128) -- bit-identical to scoring an fp32 copy, without writing and re-reading one per call.
-template <int MODE, typename TQ = float, typename TI = float>
-__global__ __launch_bounds__(256) void score_gemm_direct_kernel(const TQ *__restrict__ Q, int nq, const TI *__restrict__ I,
+//
+// BF3 (f % 16 == 0, the default): the product on the bf16 matrix cores with every operand value split into three bf16 terms
+// in registers (hi + mid + lo = the fp32 value to 2^-24) and the six partial products down to 2^-16 relative weight accumulated
+// in fp32, smallest first ("3xBF16"): measured error against fp64 BELOW that of an fp32 FMA chain (2.6e-8 vs 2e-7 relative at
+// f = 128), 24 v_mfma_f32_32x32x16_bf16 per 16 factors of a 64 x 64 wave tile instead of 32 v_mfma_f32_32x32x2_f32 at twice
+// the instruction time each -- the fp32 MFMA runs at the VECTOR rate, 1/16 of the bf16 rate.  The splits (11 vector
+// instructions per pair of values) run on the vector pipe beside the matrix pipe.  A and B fragments share the
+// (lane >> 5, element) -> k assignment, which is all the contraction needs; C/D layout is that of the fp32 form.
+typedef __bf16 tk_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split8_bf16(const float4 &v0, const float4 &v1, tk_bf16x8 &h, tk_bf16x8 &m, tk_bf16x8 &l) {
+  const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 hi = (__bf16)x[e];
+    const float r1 = x[e] - (float)hi;
+    const __bf16 mid = (__bf16)r1;
+    h[e] = hi, m[e] = mid, l[e] = (__bf16)(r1 - (float)mid);
+  }
+}
+
+#ifndef IMP_TOPK_MIN_WAVES
+#define IMP_TOPK_MIN_WAVES 3  // waves per SIMD the register allocation leaves room for (split-bf16 emit GEMM at C3: 2 waves 0.83 ms, 3: 0.73, 4: 0.80)
+#endif
+template <int MODE, typename TQ = float, typename TI = float, bool BF3 = false>
+__global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_kernel(const TQ *__restrict__ Q, int nq, const TI *__restrict__ I,
                                                                 int ni, int f, const float *__restrict__ norms,
                                                                 float *__restrict__ S, float *__restrict__ tile_max,
                                                                 int n_tiles, int block_stride, EmitArgs emit) {
@@ -296,8 +319,8 @@ __global__ __launch_bounds__(256) void score_gemm_direct_kernel(const TQ *__rest
   const TI *ip[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    qp[t] = Q + (size_t)min(q_base + 32 * t + r, nq - 1) * f + 4 * kh;  // clamped rows: results are discarded
-    ip[t] = I + (size_t)min(i_base + 32 * t + r, ni - 1) * f + 4 * kh;
+    qp[t] = Q + (size_t)min(q_base + 32 * t + r, nq - 1) * f + (BF3 ? 8 : 4) * kh;  // clamped rows: results are discarded
+    ip[t] = I + (size_t)min(i_base + 32 * t + r, ni - 1) * f + (BF3 ? 8 : 4) * kh;
   }
   f32x16 acc[2][2];
 #pragma unroll
@@ -307,6 +330,49 @@ __global__ __launch_bounds__(256) void score_gemm_direct_kernel(const TQ *__rest
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
+  if constexpr (BF3) {
+    // 16 factors per step: lane (r, kh) holds factors k0 + 8 kh .. + 8 of its query / item row (two 16-byte loads); the
+    // operands of step s + 1 are requested before the splits and the 24 MFMAs of step s
+    float4 ra0[2][2], rb0[2][2], ra1[2][2], rb1[2][2];
+    auto fetch16 = [&](float4 (&a)[2][2], float4 (&b)[2][2], int k0) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        a[t][0] = load4(qp[t] + k0), a[t][1] = load4(qp[t] + k0 + 4);
+        b[t][0] = load4(ip[t] + k0), b[t][1] = load4(ip[t] + k0 + 4);
+      }
+    };
+    auto multiply16 = [&](const float4 (&a)[2][2], const float4 (&b)[2][2]) {
+      tk_bf16x8 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        split8_bf16(a[t][0], a[t][1], ah[t], am[t], al[t]);
+        split8_bf16(b[t][0], b[t][1], bh[t], bm[t], bl[t]);
+      }
+#pragma unroll
+      for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+          f32x16 c = acc[tq][ti];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tq], bh[ti], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tq], bl[ti], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[tq], bm[ti], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[tq], bh[ti], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tq], bm[ti], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tq], bh[ti], c, 0, 0, 0);
+          acc[tq][ti] = c;
+        }
+    };
+    const int steps16 = f / 16;
+    fetch16(ra0, rb0, 0);
+    int s16 = 0;
+    for (; s16 + 2 <= steps16; s16 += 2) {
+      fetch16(ra1, rb1, 16 * (s16 + 1));
+      multiply16(ra0, rb0);
+      fetch16(ra0, rb0, 16 * min(s16 + 2, steps16 - 1));  // past the end: re-reads the last step, unused
+      multiply16(ra1, rb1);
+    }
+    if (s16 < steps16) multiply16(ra0, rb0);
+  } else {
   // 8 factors per step; the operands of step s + 1 are requested before the 16 MFMAs of step s (two register sets), so
   // the L2 round trip of a step hides under the matrix work of the previous one
   float4 a0[2], b0[2], a1[2], b1[2];
@@ -338,6 +404,7 @@ __global__ __launch_bounds__(256) void score_gemm_direct_kernel(const TQ *__rest
     multiply(a1, b1);
   }
   if (s < steps) multiply(a0, b0);
+  }
   // C/D layout: column (item) = lane & 31, row (query) = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
   float nrm[2];
 #pragma unroll
@@ -931,9 +998,10 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
     int *counts = nullptr;  // tile maxima are refreshed after the filters: no slack for filtered entries is needed
     const int extra = 0;
 
-    auto run = [&](const auto *Qb, const auto *Ib) {
+    auto run = [&](const auto *Qb, const auto *Ib, auto Bf3c) {
       using TQ = std::remove_cv_t<std::remove_pointer_t<decltype(Qb)>>;
       using TI = std::remove_cv_t<std::remove_pointer_t<decltype(Ib)>>;
+      constexpr bool BF3 = decltype(Bf3c)::value;
     // emit path (no score matrix): large item sets, k small against the candidate lists
     static const bool no_emit = getenv("IMP_TOPK_NO_EMIT") != nullptr;
     const bool emit_path = fast && !no_emit && emit_shape;
@@ -961,7 +1029,7 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
         if (have_coo) IMP_CHECK_HIP(hipMemsetAsync(row_bits, 0, rows * (size_t)words * 4, stream()));
         {
           IMP_PROF("score_gemm_subset");
-          score_gemm_direct_kernel<1, TQ, TI><<<dim3((unsigned)n_sub, qblocks), 256, 0, stream()>>>(qptr, (int)rows, Ib, (int)ni, f, norms,
+          score_gemm_direct_kernel<1, TQ, TI, BF3><<<dim3((unsigned)n_sub, qblocks), 256, 0, stream()>>>(qptr, (int)rows, Ib, (int)ni, f, norms,
                                                                                           sub, nullptr, 0, stride, EmitArgs{});
           IMP_CHECK_HIP(hipGetLastError());
         }
@@ -987,7 +1055,7 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
         {
           IMP_PROF("score_gemm");
           EmitArgs ea{tau, row_bits, item_bits, words, cand, cnt, kEmitCap};
-          score_gemm_direct_kernel<2, TQ, TI><<<dim3((unsigned)n_blocks, qblocks), 256, 0, stream()>>>(qptr, (int)rows, Ib, (int)ni, f,
+          score_gemm_direct_kernel<2, TQ, TI, BF3><<<dim3((unsigned)n_blocks, qblocks), 256, 0, stream()>>>(qptr, (int)rows, Ib, (int)ni, f,
                                                                                              norms, nullptr, nullptr, 0, 1, ea);
           IMP_CHECK_HIP(hipGetLastError());
         }
@@ -1030,7 +1098,7 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
           for (size_t g0 = 0; g0 < fb_list.size(); g0 += FB) {
             const int n = (int)std::min<size_t>(FB, fb_list.size() - g0);
             gather_query_rows_kernel<TQ><<<std::max(1, (n * f + 255) / 256), 256, 0, stream()>>>(qptr, d_rows + g0, n, f, fbq);
-            score_gemm_direct_kernel<0, float, TI><<<dim3((unsigned)n_blocks, 1), 256, 0, stream()>>>(fbq, n, Ib, (int)ni, f, norms, fscores,
+            score_gemm_direct_kernel<0, float, TI, BF3><<<dim3((unsigned)n_blocks, 1), 256, 0, stream()>>>(fbq, n, Ib, (int)ni, f, norms, fscores,
                                                                                          ftile, n_tiles, 1, EmitArgs{});
             if (have_coo || have_items) {
               int grid = (int)std::min<size_t>(((size_t)n * n_tiles + 255) / 256, (size_t)ctx().num_cus * 8);
@@ -1055,7 +1123,7 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
       if (fast) {
         IMP_PROF("score_gemm");
         dim3 grid((unsigned)((ni + 127) / 128), (unsigned)((rows + 127) / 128));
-        score_gemm_direct_kernel<0, TQ, TI><<<grid, 256, 0, stream()>>>(Qb + start * f, (int)rows, Ib, (int)ni, f,
+        score_gemm_direct_kernel<0, TQ, TI, BF3><<<grid, 256, 0, stream()>>>(Qb + start * f, (int)rows, Ib, (int)ni, f,
                                                                 item_norms ? item_norms->f32() : nullptr, scores, tile_max,
                                                                 n_tiles, 1, EmitArgs{});
         IMP_CHECK_HIP(hipGetLastError());
@@ -1122,8 +1190,18 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
     if (host_dist) IMP_CHECK_HIP(hipMemcpyAsync(distances, d_dist, nq * (size_t)k * 4, hipMemcpyDeviceToHost, stream()));
     sync();
     };
-    if (half_direct) run(reinterpret_cast<const __half *>(query_in->data), reinterpret_cast<const __half *>(items_in->data));
-    else run(query->f32(), items->f32());
+    // IMP_TOPK_FP32_MFMA=1: the exact-fp32 MFMA form (v_mfma_f32_32x32x2_f32) instead of the split-bf16 one (A/B, parity)
+    static const bool exact_mfma = getenv("IMP_TOPK_FP32_MFMA") != nullptr;
+    const bool bf3 = fast && !exact_mfma && f % 16 == 0;
+    if (half_direct) {
+      const __half *qh = reinterpret_cast<const __half *>(query_in->data), *ih = reinterpret_cast<const __half *>(items_in->data);
+      if (bf3) run(qh, ih, std::true_type{});
+      else run(qh, ih, std::false_type{});
+    } else if (bf3) {
+      run(query->f32(), items->f32(), std::true_type{});
+    } else {
+      run(query->f32(), items->f32(), std::false_type{});
+    }
   });
 }
 
