@@ -32,9 +32,9 @@ for rep in range(2):
     print(f"fit(2 iterations) {tot:.3f} s, iterations {sum(times):.3f} s, set-up {tot - sum(times):.3f} s")
 PY
 tail -3 $O/tests.log; tail -2 $O/bench.err; cat $O/fit_setup.txt
-python - <<'PY'
+python - $O <<'PY'
 import json
-j = json.load(open("gpurun_out/r3g/bench.json"))
+j = json.load(open(__import__("sys").argv[1] + "/bench.json"))
 print("ms/step", j["ms_per_step"], "value", j["value"], "frac", j["roofline"]["frac"])
 for k in ("fit_c3", "fp16_c3", "cholesky_c2", "cg_c2", "cg_c5", "similar_items_c5", "c4_full_1gpu", "c4_shard", "topk"):
     v = j.get(k)
