@@ -433,27 +433,37 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
     return;
   }
   if constexpr (MODE == 2) {
-    // emission is rare (a few hundred scores per query row out of all items): the divergent branch costs nothing next to the
-    // 64 stores per lane it replaces
+    // emission is rare (a few hundred scores per query row out of all items).  The thresholds of four consecutive query rows
+    // come in one 16-byte load (the tau buffer is padded to whole 128-row blocks); a score is first compared with the
+    // threshold as a float -- one instruction, true for every score the exact test accepts (and for a NaN) -- and only the
+    // few that pass take the exact test on the ordered keys, the filter look-ups and the append.
 #pragma unroll
     for (int tq = 0; tq < 2; ++tq)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int q = q_base + 32 * tq + (e & 3) + 8 * (e >> 2) + 4 * kh;
-        if (q >= nq) continue;
-        const uint32_t t = emit.tau[q];
+      for (int eg = 0; eg < 4; ++eg) {
+        const int q0 = q_base + 32 * tq + 8 * eg + 4 * kh;
+        const uint4 t4 = *reinterpret_cast<const uint4 *>(emit.tau + q0);
+        const uint32_t tk[4] = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti) {
-          const int item = i_base + 32 * ti + r;
-          float sc = acc[tq][ti][e];
-          if (norms) sc = sc / nrm[ti];
-          if (item < ni && ordered(sc) >= t) {
-            const uint32_t bit = 1u << (item & 31);
-            bool filtered = emit.item_bits && (emit.item_bits[item >> 5] & bit);
-            if (!filtered && emit.row_bits) filtered = emit.row_bits[(size_t)q * emit.words + (item >> 5)] & bit;
-            if (!filtered) {
-              const unsigned int slot = atomicAdd(&emit.count[q], 1u);
-              if (slot < (unsigned)emit.cap) emit.cand[(size_t)q * emit.cap + slot] = make_key(sc, item);
+        for (int el = 0; el < 4; ++el) {
+          const int e = 4 * eg + el, q = q0 + el;
+          const uint32_t t = tk[el];
+          const float tf = unordered(t);
+#pragma unroll
+          for (int ti = 0; ti < 2; ++ti) {
+            float sc = acc[tq][ti][e];
+            if (norms) sc = sc / nrm[ti];
+            if (!(sc < tf)) {
+              const int item = i_base + 32 * ti + r;
+              if (q < nq && item < ni && ordered(sc) >= t) {
+                const uint32_t bit = 1u << (item & 31);
+                bool filtered = emit.item_bits && (emit.item_bits[item >> 5] & bit);
+                if (!filtered && emit.row_bits) filtered = emit.row_bits[(size_t)q * emit.words + (item >> 5)] & bit;
+                if (!filtered) {
+                  const unsigned int slot = atomicAdd(&emit.count[q], 1u);
+                  if (slot < (unsigned)emit.cap) emit.cand[(size_t)q * emit.cap + slot] = make_key(sc, item);
+                }
+              }
             }
           }
         }
@@ -1012,7 +1022,7 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
       const size_t ebatch = std::min<size_t>(nq, 2048);
       constexpr int FB = 64;  // fallback rows per materialised group
       float *sub = imp_knn::ensure(knn->sub_scores, ebatch * (size_t)sub_cols);
-      uint32_t *tau = imp_knn::ensure(knn->tau, ebatch);
+      uint32_t *tau = imp_knn::ensure(knn->tau, (ebatch + 127) / 128 * 128);  // the emit epilogue loads thresholds four rows at a time
       unsigned int *cnt = imp_knn::ensure(knn->cand_count, ebatch);
       uint64_t *cand = imp_knn::ensure(knn->cand, ebatch * (size_t)kEmitCap);
       int *fallback_e = imp_knn::ensure(knn->fallback, ebatch);
