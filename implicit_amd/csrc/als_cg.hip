@@ -670,6 +670,59 @@ static void launch_all(const imp_csr *C, T *X, const T *Y, const float *A0, int 
 // fp16 factor storage is handled natively (converted in registers) by the f = 64 / 128 kernels
 bool cg_native_half(int f) { return f == 64 || f == 128; }
 
+// ---- other factor counts below 128: zero-padded onto the f = 64 / 128 kernels ------------------------------------------------
+// The resident-tile kernels exist for f = 64 and 128.  Any other f < 128 (the reference's CPU default is 100) ran the generic
+// lane-strided one-wave-per-row kernel: 23.0 ms per configs[2]-shaped iteration at f = 100 against 4.6 at f = 128, 13-16 ms at
+// f = 16 / 32 / 50 against 2.7 at f = 64 (gpurun_out/r3s).  Padding is exact for CG: with the extra columns of X and Y zero and
+// the gramian extended by a unit diagonal block, residual, search direction and iterate stay zero in the padded components
+// (b = 0, x0 = 0 there), and every dot product only gains exact zeros.  Cost: one padded copy of Y and of the solved rows of X
+// in, the rows of X out -- (R_y + 2 R_x)(f + F) 4 bytes per half sweep, ~0.2 ms at configs[2] -- and the workspaces.
+__global__ void pad_rows_kernel(const float *__restrict__ src, float *__restrict__ dst, size_t rows, int f, int F) {
+  const size_t n = rows * (size_t)F;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / F;
+    const int c = (int)(i - r * F);
+    dst[i] = c < f ? src[r * f + c] : 0.f;
+  }
+}
+__global__ void unpad_rows_kernel(const float *__restrict__ src, float *__restrict__ dst, size_t rows, int f, int F) {
+  const size_t n = rows * (size_t)f;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / f;
+    dst[i] = src[r * F + (i - r * f)];
+  }
+}
+__global__ void pad_gram_kernel(const float *__restrict__ src, float *__restrict__ dst, int f, int F) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < F * F; i += gridDim.x * blockDim.x) {
+    const int r = i / F, c = i - r * F;
+    dst[i] = (r < f && c < f) ? src[r * f + c] : (r == c ? 1.f : 0.f);
+  }
+}
+
+static void least_squares_cg_padded(const imp_csr *C, imp_matrix *X, const imp_matrix *YtY, const imp_matrix *Y, int cg_steps, int F) {
+  const int f = (int)X->cols;
+  auto &c = ctx();
+  const size_t rx = (size_t)C->rows, ry = Y->rows;
+  if (c.pad_x.size < rx * F) c.pad_x.alloc(rx * F);
+  if (c.pad_y.size < ry * F) c.pad_y.alloc(ry * F);
+  if (c.pad_gram.size < (size_t)F * F) c.pad_gram.alloc((size_t)F * F);
+  auto grid = [&](size_t n) { return (int)std::max<size_t>(1, std::min<size_t>((n + 255) / 256, (size_t)c.num_cus * 16)); };
+  {
+    IMP_PROF("pad_factors");
+    if (ry) pad_rows_kernel<<<grid(ry * F), 256, 0, stream()>>>(Y->f32(), c.pad_y.data(), ry, f, F);
+    if (rx) pad_rows_kernel<<<grid(rx * F), 256, 0, stream()>>>(X->f32(), c.pad_x.data(), rx, f, F);
+    pad_gram_kernel<<<grid((size_t)F * F), 256, 0, stream()>>>(YtY->f32(), c.pad_gram.data(), f, F);
+    IMP_CHECK_HIP(hipGetLastError());
+  }
+  if (F == 64) launch_all<1, true, true, float>(C, c.pad_x.data(), c.pad_y.data(), c.pad_gram.data(), F, cg_steps);
+  else launch_all<2, true, true, float>(C, c.pad_x.data(), c.pad_y.data(), c.pad_gram.data(), F, cg_steps);
+  {
+    IMP_PROF("unpad_factors");
+    if (rx) unpad_rows_kernel<<<grid(rx * f), 256, 0, stream()>>>(c.pad_x.data(), X->f32(), rx, f, F);
+    IMP_CHECK_HIP(hipGetLastError());
+  }
+}
+
 void least_squares_cg(const imp_csr *C, imp_matrix *X, const imp_matrix *YtY, const imp_matrix *Y, int cg_steps) {
   const int f = (int)X->cols;
   const float *a0 = YtY->f32();
@@ -683,6 +736,12 @@ void least_squares_cg(const imp_csr *C, imp_matrix *X, const imp_matrix *YtY, co
   }
   float *x = X->f32();
   const float *y = Y->f32();
+  // IMP_NO_PAD=1: factor counts other than 64 / 128 on the generic kernels (A/B, parity)
+  static const bool no_pad = getenv("IMP_NO_PAD") != nullptr;
+  if (!no_pad && f < 128 && f != 64 && f >= 1) {
+    least_squares_cg_padded(C, X, YtY, Y, cg_steps, f < 64 ? 64 : 128);
+    return;
+  }
   if (f == 64) launch_all<1, true, true, float>(C, x, y, a0, f, cg_steps);
   else if (f == 128) launch_all<2, true, true, float>(C, x, y, a0, f, cg_steps);
   else if (f == 256) launch_all<4, true, false, float>(C, x, y, a0, f, cg_steps);

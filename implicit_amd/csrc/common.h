@@ -125,6 +125,7 @@ struct Context {
   std::recursive_mutex mutex;
   DeviceArray<float> gram_ws;     // split-K partial gramians (gramian.hip)
   DeviceArray<float> long_ws;     // partial vectors / CG state of the long rows (als_cg.hip)
+  DeviceArray<float> pad_x, pad_y, pad_gram;  // zero-padded copies for factor counts that ride the f = 64 / 128 kernels (als_cg.hip)
   DeviceArray<double> loss_buf;   // 4 accumulators of the loss kernel (solver.hip)
   DeviceArray<unsigned long long> chol_failed;  // smallest failing row of a Cholesky sweep (als_cholesky.hip)
   DeviceArray<float> barrier_word;              // operand of the RCCL barrier (comm.hip)

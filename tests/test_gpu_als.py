@@ -183,3 +183,29 @@ def test_loss_known_answers(gpu):
 
     assert calculate_loss(ratings, user_factors, item_factors, regularization=0) == pytest.approx(1.0)
     assert calculate_loss(ratings, user_factors, item_factors, regularization=1.0) == pytest.approx(2.0)
+
+
+def test_other_factor_counts_ride_the_resident_kernels(gpu, oracle):
+    """Factor counts below 128 other than 64 are zero-padded onto the f = 64 / 128 kernels (exact for CG: the padded
+    components of residual, direction and iterate stay zero).  A matrix with every row class -- short, team widths, rows
+    beyond 512 and 4096 nonzeros -- at f = 100 and f = 20, a row-range view of X, and the outputs' padded columns never
+    leak: the rows of X past the CSR's rows are untouched."""
+    from implicit_amd.synthetic import synthetic_csr
+
+    C = synthetic_csr(900, 30_000, 700_000, seed=31, neg_frac=0.04, empty_frac=0.02, sigma=2.0)
+    assert np.diff(C.indptr).max() > 4096
+    for f in (100, 20):
+        rng = np.random.default_rng(f)
+        X0 = rng.random((C.shape[0] + 7, f), dtype=np.float32) * 0.2 - 0.1   # 7 extra rows: not solved, must stay as they are
+        Y0 = rng.random((C.shape[1], f), dtype=np.float32) * 0.2 - 0.1
+        Xd, Yd, gram = gpu.Matrix(X0), gpu.Matrix(Y0), gpu.Matrix.zeros(f, f)
+        solver = gpu.LeastSquaresSolver()
+        solver.calculate_yty(Yd, gram, 0.05)
+        solver.least_squares(gpu.CSRMatrix(C), Xd, gram, Yd, 3)
+        got = Xd.to_numpy()
+        want = X0[:C.shape[0]].copy()
+        oracle.least_squares_cg(C, want, Y0, 0.05, cg_steps=3, YtY=gram.to_numpy())
+        err = rel(got[:C.shape[0]], want)
+        print(f"f={f} padded route rel={err:.2e}")
+        assert err < TOL
+        np.testing.assert_array_equal(got[C.shape[0]:], X0[C.shape[0]:])
