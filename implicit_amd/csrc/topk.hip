@@ -838,6 +838,18 @@ __global__ __launch_bounds__(BLOCK) void select_candidates_kernel(const uint64_t
   }
 }
 
+// factor counts that are not a multiple of 16 (the reference's CPU default is 100): rows zero-padded to the next multiple, fp16
+// converted on the way -- extra zero factors change no dot product, and the scores come from the direct-operand kernels
+template <typename T>
+__global__ void pad_factor_rows_kernel(const T *__restrict__ src, float *__restrict__ dst, size_t rows, int f, int F) {
+  const size_t n = rows * (size_t)F;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / F;
+    const int c = (int)(i - r * F);
+    dst[i] = c < f ? load1(src + r * f + c) : 0.f;
+  }
+}
+
 // fallback rows: query rows gathered into a compact matrix, filters replayed from the bitmaps onto the materialised scores
 template <typename TQ>
 __global__ void gather_query_rows_kernel(const TQ *__restrict__ Q, const int32_t *__restrict__ rows, int n, int f,
@@ -910,6 +922,7 @@ struct imp_knn {
   DeviceArray<float> dev_dist;
   // emit path
   DeviceArray<float> sub_scores, fb_query, fb_dist;
+  DeviceArray<float> pad_items, pad_query;  // zero-padded fp32 copies for factor counts that are not a multiple of 16
   DeviceArray<uint32_t> tau, row_bits, item_bits;
   DeviceArray<unsigned int> cand_count;
   DeviceArray<uint64_t> cand;
@@ -949,20 +962,42 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
     if (item_norms && (item_norms->itemsize != 4 || item_norms->rows * item_norms->cols != items_in->rows))
       throw std::invalid_argument("item_norms must be a float32 matrix with one entry per item");
     const size_t nq = query_in->rows, ni = items_in->rows;
-    const int f = (int)items_in->cols;
+    const int f_in = (int)items_in->cols;
     if (nq == 0 || k == 0) return;
     if (ni > (size_t)INT32_MAX) throw std::invalid_argument("too many items for topk");
 
     const int k_eff = (int)std::min<size_t>((size_t)k, ni);
     // fast path: direct-operand MFMA GEMM (+ emit path, or tile maxima + single-pass pruned select)
     static const bool no_fast = getenv("IMP_TOPK_NO_FAST") != nullptr;
+    // factor counts off the 16-grid ride the fast path on zero-padded fp32 copies (272 K -> 1.1 M recs/s at f = 100, configs[2]
+    // items; the copies cost ~0.1 ms per call at that size); IMP_TOPK_NO_PAD=1 keeps the general LDS-staged path
+    static const bool no_pad = getenv("IMP_TOPK_NO_PAD") != nullptr;
+    const bool padded = !no_fast && !no_pad && f_in % 16 != 0 && f_in >= 1 && k_eff <= kCandCap;
+    const int f = padded ? (f_in + 15) / 16 * 16 : f_in;
     const bool fast = !no_fast && (f % 8 == 0) && k_eff <= kCandCap;
     // fp16 factors (reference: SgemmEx on fp16 operands with fp32 accumulation, knn.cu:117-128): the direct-operand kernels
     // read them as stored and convert in registers; only the general path (any f, LDS-staged GEMM) scores an fp32 copy
-    const bool half_direct = items_in->itemsize == 2 && fast && getenv("IMP_FP16_CONVERT") == nullptr;
+    const bool half_direct = items_in->itemsize == 2 && fast && !padded && getenv("IMP_FP16_CONVERT") == nullptr;
     std::unique_ptr<imp_matrix> items_conv, query_conv;
     const imp_matrix *items = items_in, *query = query_in;
-    if (items_in->itemsize == 2 && !half_direct) {
+    imp_matrix items_pad, query_pad;  // views of the padded workspaces (no ownership)
+    if (padded) {
+      float *pi = imp_knn::ensure(knn->pad_items, ni * (size_t)f), *pq = imp_knn::ensure(knn->pad_query, nq * (size_t)f);
+      IMP_PROF("pad_factors");
+      auto grid = [&](size_t n) { return (int)std::max<size_t>(1, std::min<size_t>((n + 255) / 256, (size_t)ctx().num_cus * 16)); };
+      if (items_in->itemsize == 4) {
+        pad_factor_rows_kernel<float><<<grid(ni * f), 256, 0, stream()>>>(items_in->f32(), pi, ni, f_in, f);
+        pad_factor_rows_kernel<float><<<grid(nq * f), 256, 0, stream()>>>(query_in->f32(), pq, nq, f_in, f);
+      } else {
+        pad_factor_rows_kernel<__half><<<grid(ni * f), 256, 0, stream()>>>(reinterpret_cast<const __half *>(items_in->data), pi, ni, f_in, f);
+        pad_factor_rows_kernel<__half><<<grid(nq * f), 256, 0, stream()>>>(reinterpret_cast<const __half *>(query_in->data), pq, nq, f_in, f);
+      }
+      IMP_CHECK_HIP(hipGetLastError());
+      items_pad.rows = ni, items_pad.cols = (size_t)f, items_pad.itemsize = 4, items_pad.data = pi;
+      query_pad.rows = nq, query_pad.cols = (size_t)f, query_pad.itemsize = 4, query_pad.data = pq;
+      items = &items_pad;
+      query = &query_pad;
+    } else if (items_in->itemsize == 2 && !half_direct) {
       imp_matrix *t = nullptr;
       if (imp_matrix_astype(items_in, 4, &t) != IMP_OK) throw std::runtime_error(imp_last_error());
       items_conv.reset(t);

@@ -208,3 +208,29 @@ def test_emit_path_covers_small_catalogues(gpu, oracle):
         for r, j in zip(*np.nonzero(differ)):
             exact = i64[ids[r, j]] @ q64[r] / nh[ids[r, j]]
             assert abs(exact - want_d[r, j]) <= 4 * f * np.finfo(np.float32).eps * max(abs(want_d[r, j]), 1e-30), (ni, k, r, j)
+
+
+@pytest.mark.parametrize("f", [100, 10, 50])
+def test_factor_counts_off_the_16_grid_take_the_fast_path(gpu, oracle, f):
+    """f = 100 (the reference's CPU default) and other counts that are not a multiple of 16: rows are zero-padded to the
+    next multiple (extra zero factors change no dot product) and scored by the direct-operand kernels -- fp32 and fp16
+    storage, norms and a per-query filter, against the oracle on the unpadded factors."""
+    rng = np.random.default_rng(f)
+    ni, k = 40_000, 10
+    items = (rng.standard_normal((ni, f)) * 0.1).astype(np.float32)
+    q = (rng.standard_normal((90, f)) * 0.1).astype(np.float32)
+    liked = sp.random(90, ni, density=15.0 / ni, format="csr", random_state=5, dtype=np.float32)
+    norms = gpu.calculate_norms(gpu.Matrix(items))
+    nh = norms.to_numpy().reshape(-1)
+    ids, d = gpu.KnnQuery().topk(gpu.Matrix(items), gpu.Matrix(q), k, item_norms=norms, query_filter=gpu.COOMatrix(liked.tocoo()))
+    want_ids, want_d = oracle.topk(items, q, k, item_norms=nh, filter_query_items=liked)
+    assert_allclose(d, want_d, rtol=3e-5)
+    ok = ~_near_tie_rows(want_d, f)
+    assert ok.mean() > 0.9
+    assert_array_equal(ids[ok], want_ids[ok])
+    i16, q16 = items.astype(np.float16), q.astype(np.float16)
+    ids16, d16 = gpu.KnnQuery().topk(gpu.Matrix(i16), gpu.Matrix(q16), k)
+    w_ids, w_d = oracle.topk(i16.astype(np.float32), q16.astype(np.float32), k)
+    assert_allclose(d16, w_d, rtol=3e-5)
+    ok = ~_near_tie_rows(w_d, f)
+    assert_array_equal(ids16[ok], w_ids[ok])
