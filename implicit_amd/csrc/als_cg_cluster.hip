@@ -31,6 +31,9 @@
 
 namespace imp {
 
+#ifndef IMP_CLUSTER_POLL_NAP
+#define IMP_CLUSTER_POLL_NAP 2  // 64-cycle units between two polls of an exchange (0 / 1 / 2 / 4 measured alike on the configs[1] shape, gpurun_out/r4a)
+#endif
 namespace {
 constexpr int kClusterWaves = 8;       // wavefronts per workgroup
 // A poll gives up by the constant-rate wall clock (100 MHz), not by counting polls: a partly resident cluster may have
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(64 * kClusterWaves, 4) void als_cg_cluster_kernel(
           faulted = true;
           break;
         }
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(IMP_CLUSTER_POLL_NAP);
       }
 #pragma unroll
       for (int k = 0; k < PER; ++k)
