@@ -278,6 +278,16 @@ def test_model_fit_with_a_communicator(gpu, oracle):
     model2._initial_factors(*C.shape)
     sharded.fit_sharded(model2, Cui, comm, chunks=3)     # one rank: its block of user rows is the whole matrix
     assert gpu.get_oversubscribe() == 1                   # the driver restores the launch shape it found
+    # the model-level entry every rank of an N-GPU job goes through (block sizes all-reduced, initial factors agreed through a
+    # sum all-reduce, set-up exchange, iterations, per-rank loss), here with the one rank there is
+    model3 = AlternatingLeastSquares(factors=64, regularization=0.05, random_state=5, use_gpu=True, iterations=2,
+                                     calculate_training_loss=True)
+    model3.comm = comm
+    seen = []
+    model3._fit_sharded(Cui, lambda it, dt, loss: seen.append(it))
+    assert seen == [0, 1]
+    assert rel(model3.user_factors.to_numpy(), plain.user_factors.to_numpy()) < 1e-5
+    assert rel(model3.item_factors.to_numpy(), plain.item_factors.to_numpy()) < 1e-5
     assert rel(model2.user_factors.to_numpy(), plain.user_factors.to_numpy()) < 1e-5
     assert rel(model2.item_factors.to_numpy(), plain.item_factors.to_numpy()) < 1e-5
     import pickle
