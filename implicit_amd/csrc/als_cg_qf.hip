@@ -561,7 +561,9 @@ static void launch_qfteam(const imp_csr *C, int first, int count, T *X, const T 
   auto kern = als_cg_qfteam_kernel<F, WPR, BLOCK, T>;
   IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / BLOCK, (160 * 1024) / lds));
-  constexpr int kBaseOversub = WPR <= 4 ? 4 : (WPR == 8 ? 2 : 1);  // als_cg_q.hip launch_qteam
+  // als_cg_q.hip launch_qteam; the 16-wave team at f = 64 (16 KB of gramian to stage, two workgroups per CU) takes 2 as well:
+  // configs[1]-shaped CG 1.47 -> 1.42 ms, and a fixed share on a contended CU is what took seconds once
+  constexpr int kBaseOversub = WPR <= 4 ? 4 : (WPR == 8 ? 2 : (F == 64 ? 2 : 1));
   int grid = std::min((count + TEAMS - 1) / TEAMS, ctx().num_cus * per_cu * std::max(kBaseOversub, ctx().oversub));
   static const bool want_stats = getenv("IMP_CG_STATS") != nullptr;
   if (want_stats) {  // debug: per-phase cycle sums of this launch on stderr (instrumented instantiation: timings only)
