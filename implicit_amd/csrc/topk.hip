@@ -303,6 +303,50 @@ __device__ __forceinline__ void split8_bf16(const float4 &v0, const float4 &v1, 
   }
 }
 
+// Query rows split ahead of the GEMM (emit path) and stored in FRAGMENT order: for every tile of 32 query rows, step of 16
+// factors and term (hi, mid, lo -- the same bits split8_bf16 produces) the 64 lanes' 8-element operands lie side by side, so
+// a wavefront's operand load is ONE contiguous KB (8 whole cache lines) instead of 64 pieces of 16 bytes in 32 lines, and the
+// 2 x n_item_blocks workgroups that read a query block no longer repeat the split (1000 x 128 values once against 2285 times
+// at configs[2]).  Rows are padded to whole 128-row query blocks with zeros.  `TQ = split_bf16` selects it in score_gemm_direct_kernel
+// (Q then points at the first tile of the launch).  IMP_TOPK_NO_QSPLIT=1: split in the GEMM as for the items (A/B).
+struct split_bf16 {
+  __bf16 v;
+};
+template <typename T>
+__global__ void split_query_rows_kernel(const T *__restrict__ Q, __bf16 *__restrict__ out, size_t rows, size_t rows_pad, int f) {
+  const size_t n = rows_pad * (size_t)f;
+  const int steps16 = f / 16;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t q = i / f;
+    const int c = (int)(i - q * f);
+    const float x = q < rows ? (float)Q[i] : 0.f;
+    const __bf16 hi = (__bf16)x;
+    const float r1 = x - (float)hi;
+    const __bf16 mid = (__bf16)r1;
+    const int lane = (int)(q & 31) + 32 * ((c >> 3) & 1);
+    __bf16 *o = out + ((((q >> 5) * steps16 + (c >> 4)) * 3) * 64 + lane) * 8 + (c & 7);
+    o[0] = hi, o[64 * 8] = mid, o[2 * 64 * 8] = (__bf16)(r1 - (float)mid);
+  }
+}
+
+// four consecutive factors as they are stored, and their fp32 values
+template <typename T> struct raw4 {
+  using type = float4;
+};
+template <> struct raw4<__half> {
+  using type = uint2;
+};
+template <typename T> using raw4_t = typename raw4<T>::type;
+__device__ __forceinline__ float4 load_raw4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ uint2 load_raw4(const __half *p) { return *reinterpret_cast<const uint2 *>(p); }
+__device__ __forceinline__ float4 load_raw4(const split_bf16 *) { return float4{}; }  // never called: split rows have their own loads
+__device__ __forceinline__ float4 widen4(const float4 &v) { return v; }
+__device__ __forceinline__ float4 widen4(const uint2 &raw) {
+  const float2 a = __half22float2(*reinterpret_cast<const __half2 *>(&raw.x));
+  const float2 b = __half22float2(*reinterpret_cast<const __half2 *>(&raw.y));
+  return make_float4(a.x, a.y, b.x, b.y);
+}
+
 #ifndef IMP_TOPK_MIN_WAVES
 #define IMP_TOPK_MIN_WAVES 3  // waves per SIMD the register allocation leaves room for (split-bf16 emit GEMM at C3: 2 waves 0.83 ms, 3: 0.73, 4: 0.80)
 #endif
@@ -315,11 +359,14 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
   const int r = lane & 31, kh = lane >> 5;
   const int q_base = blockIdx.y * 128 + 64 * (wave >> 1);
   const int i_base = (MODE == 1 ? blockIdx.x * block_stride : blockIdx.x) * 128 + 64 * (wave & 1);
+  constexpr bool QS = std::is_same<TQ, split_bf16>::value;  // query rows already split: [3][f] bf16 per row
+  static_assert(!QS || BF3, "split query rows feed the bf16 form only");
   const TQ *qp[2];
   const TI *ip[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    qp[t] = Q + (size_t)min(q_base + 32 * t + r, nq - 1) * f + (BF3 ? 8 : 4) * kh;  // clamped rows: results are discarded
+    if constexpr (QS) qp[t] = Q + ((size_t)(q_base / 32 + t) * (f / 16) * 3 * 64 + lane) * 8;  // fragment order, padded to whole tiles
+    else qp[t] = Q + (size_t)min(q_base + 32 * t + r, nq - 1) * f + (BF3 ? 8 : 4) * kh;  // clamped rows: results are discarded
     ip[t] = I + (size_t)min(i_base + 32 * t + r, ni - 1) * f + (BF3 ? 8 : 4) * kh;
   }
   f32x16 acc[2][2];
@@ -333,20 +380,36 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
   if constexpr (BF3) {
     // 16 factors per step: lane (r, kh) holds factors k0 + 8 kh .. + 8 of its query / item row (two 16-byte loads); the
     // operands of step s + 1 are requested before the splits and the 24 MFMAs of step s
-    float4 ra0[2][2], rb0[2][2], ra1[2][2], rb1[2][2];
-    auto fetch16 = [&](float4 (&a)[2][2], float4 (&b)[2][2], int k0) {
+    // operands wait for their multiply in STORAGE form (fp16: 8 bytes per 4 factors, converted when they are split)
+    struct RawA {
+      raw4_t<TQ> v[2][2];
+    };
+    struct SplitA {
+      tk_bf16x8 v[2][3];
+    };
+    using AReg = std::conditional_t<QS, SplitA, RawA>;
+    AReg ra0, ra1;
+    raw4_t<TI> rb0[2][2], rb1[2][2];
+    auto fetch16 = [&](AReg &a, raw4_t<TI> (&b)[2][2], int k0) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        a[t][0] = load4(qp[t] + k0), a[t][1] = load4(qp[t] + k0 + 4);
-        b[t][0] = load4(ip[t] + k0), b[t][1] = load4(ip[t] + k0 + 4);
+        if constexpr (QS) {
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+            a.v[t][p] = *reinterpret_cast<const tk_bf16x8 *>(reinterpret_cast<const __bf16 *>(qp[t]) + ((k0 >> 4) * 3 + p) * 64 * 8);
+        } else {
+          a.v[t][0] = load_raw4(qp[t] + k0), a.v[t][1] = load_raw4(qp[t] + k0 + 4);
+        }
+        b[t][0] = load_raw4(ip[t] + k0), b[t][1] = load_raw4(ip[t] + k0 + 4);
       }
     };
-    auto multiply16 = [&](const float4 (&a)[2][2], const float4 (&b)[2][2]) {
+    auto multiply16 = [&](const AReg &a, const raw4_t<TI> (&b)[2][2]) {
       tk_bf16x8 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        split8_bf16(a[t][0], a[t][1], ah[t], am[t], al[t]);
-        split8_bf16(b[t][0], b[t][1], bh[t], bm[t], bl[t]);
+        if constexpr (QS) ah[t] = a.v[t][0], am[t] = a.v[t][1], al[t] = a.v[t][2];
+        else split8_bf16(widen4(a.v[t][0]), widen4(a.v[t][1]), ah[t], am[t], al[t]);
+        split8_bf16(widen4(b[t][0]), widen4(b[t][1]), bh[t], bm[t], bl[t]);
       }
 #pragma unroll
       for (int tq = 0; tq < 2; ++tq)
@@ -375,15 +438,17 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
   } else {
   // 8 factors per step; the operands of step s + 1 are requested before the 16 MFMAs of step s (two register sets), so
   // the L2 round trip of a step hides under the matrix work of the previous one
-  float4 a0[2], b0[2], a1[2], b1[2];
-  auto fetch = [&](float4 (&a)[2], float4 (&b)[2], int k0) {
+  raw4_t<TQ> a0[2], a1[2];
+  raw4_t<TI> b0[2], b1[2];
+  auto fetch = [&](raw4_t<TQ> (&a)[2], raw4_t<TI> (&b)[2], int k0) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      a[t] = load4(qp[t] + k0);
-      b[t] = load4(ip[t] + k0);
+      a[t] = load_raw4(qp[t] + k0);
+      b[t] = load_raw4(ip[t] + k0);
     }
   };
-  auto multiply = [&](const float4 (&a)[2], const float4 (&b)[2]) {
+  auto multiply = [&](const raw4_t<TQ> (&ar)[2], const raw4_t<TI> (&br)[2]) {
+    const float4 a[2] = {widen4(ar[0]), widen4(ar[1])}, b[2] = {widen4(br[0]), widen4(br[1])};
 #pragma unroll
     for (int tq = 0; tq < 2; ++tq)
 #pragma unroll
@@ -981,6 +1046,7 @@ struct imp_knn {
   // emit path
   DeviceArray<float> sub_scores, fb_query, fb_dist;
   DeviceArray<float> pad_items, pad_query;  // zero-padded fp32 copies for factor counts that are not a multiple of 16
+  DeviceArray<split_bf16> query_split;      // [nq][3][f] bf16 terms of the query rows (emit path, split form)
   DeviceArray<uint32_t> tau, row_bits, item_bits;
   DeviceArray<unsigned int> cand_count;
   DeviceArray<uint64_t> cand;
@@ -1125,6 +1191,32 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
       if (have_items) IMP_CHECK_HIP(hipMemsetAsync(item_bits, 0, (size_t)words * 4, stream()));
       std::vector<int> flags(ebatch);
       std::vector<int32_t> fb_list;
+      static const bool no_qsplit = getenv("IMP_TOPK_NO_QSPLIT") != nullptr;
+      constexpr bool kCanSplit = BF3;
+      const bool qsplit = kCanSplit && !no_qsplit;
+      split_bf16 *qs = nullptr;
+      if (qsplit) {
+        IMP_PROF("split_query_rows");
+        const size_t nq_pad = (nq + 127) / 128 * 128;  // whole 128-row query blocks: a workgroup reads all four tiles of its block
+        qs = imp_knn::ensure(knn->query_split, nq_pad * 3 * (size_t)f);
+        const int grid = (int)std::max<size_t>(1, std::min<size_t>((nq_pad * (size_t)f + 255) / 256, (size_t)ctx().num_cus * 16));
+        split_query_rows_kernel<TQ><<<grid, 256, 0, stream()>>>(Qb, reinterpret_cast<__bf16 *>(qs), nq, nq_pad, f);
+        IMP_CHECK_HIP(hipGetLastError());
+      }
+      // the two GEMM launches of a batch: query rows pre-split (default) or in their storage type
+      auto gemm = [&](auto mode_c, size_t start, dim3 grid, int rows, float *S_out, int bstride, const EmitArgs &ea) {
+        constexpr int M = decltype(mode_c)::value;
+        const float *norms_p = item_norms ? item_norms->f32() : nullptr;
+        if constexpr (kCanSplit) {
+          if (qsplit) {
+            score_gemm_direct_kernel<M, split_bf16, TI, true><<<grid, 256, 0, stream()>>>(qs + start * 3 * (size_t)f, rows, Ib, (int)ni, f, norms_p,
+                                                                                    S_out, nullptr, 0, bstride, ea);
+            return;
+          }
+        }
+        score_gemm_direct_kernel<M, TQ, TI, BF3><<<grid, 256, 0, stream()>>>(Qb + start * f, rows, Ib, (int)ni, f, norms_p, S_out, nullptr, 0,
+                                                                            bstride, ea);
+      };
       for (size_t start = 0; start < nq; start += ebatch) {
         const size_t end = std::min(nq, start + ebatch), rows = end - start;
         const auto *qptr = Qb + start * f;
@@ -1132,8 +1224,7 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
         if (have_coo) IMP_CHECK_HIP(hipMemsetAsync(row_bits, 0, rows * (size_t)words * 4, stream()));
         {
           IMP_PROF("score_gemm_subset");
-          score_gemm_direct_kernel<1, TQ, TI, BF3><<<dim3((unsigned)n_sub, qblocks), 256, 0, stream()>>>(qptr, (int)rows, Ib, (int)ni, f, norms,
-                                                                                          sub, nullptr, 0, stride, EmitArgs{});
+          gemm(std::integral_constant<int, 1>{}, start, dim3((unsigned)n_sub, qblocks), (int)rows, sub, stride, EmitArgs{});
           IMP_CHECK_HIP(hipGetLastError());
         }
         if (have_items) {
@@ -1161,8 +1252,7 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
         {
           IMP_PROF("score_gemm");
           EmitArgs ea{tau, row_bits, item_bits, words, cand, cnt, kEmitCap};
-          score_gemm_direct_kernel<2, TQ, TI, BF3><<<dim3((unsigned)n_blocks, qblocks), 256, 0, stream()>>>(qptr, (int)rows, Ib, (int)ni, f,
-                                                                                             norms, nullptr, nullptr, 0, 1, ea);
+          gemm(std::integral_constant<int, 2>{}, start, dim3((unsigned)n_blocks, qblocks), (int)rows, nullptr, 1, ea);
           IMP_CHECK_HIP(hipGetLastError());
         }
         {
