@@ -378,9 +378,14 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
   if constexpr (BF3) {
-    // 16 factors per step: lane (r, kh) holds factors k0 + 8 kh .. + 8 of its query / item row (two 16-byte loads); the
-    // operands of step s + 1 are requested before the splits and the 24 MFMAs of step s
-    // operands wait for their multiply in STORAGE form (fp16: 8 bytes per 4 factors, converted when they are split)
+    // 16 factors per step.  QUERY operands: lane (r, kh) holds factors k0 + 8 kh .. + 8 of its row -- from the fragment-ordered
+    // split copy (one contiguous KB per load) or straight from the rows (two 16-byte loads).  ITEM operands come through LDS:
+    // a wavefront load of lane (r, kh)'s own 16 bytes touches 32 cache lines for 1 KB and the texture addresser, not the matrix
+    // pipe, set the pace (emit GEMM 0.72 ms with both operands read that way, 0.56 with the queries in fragment order); instead
+    // each wave brings its 64 item rows x 16 factors with LDS-DMA loads of WHOLE row pieces (1 KB per instruction = 16 rows x
+    // 64 bytes fp32 / 32 rows x 32 bytes fp16, four / two lanes per row) into a wave-private double buffer -- no barrier, no
+    // staging registers -- and reads its fragments back with ds_read_b128.  The 16-byte chunks of a row are XOR-swizzled (on
+    // the SOURCE side: the DMA destination is lane-linear) so that the 32 rows a fragment read touches spread over all banks.
     struct RawA {
       raw4_t<TQ> v[2][2];
     };
@@ -388,9 +393,29 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
       tk_bf16x8 v[2][3];
     };
     using AReg = std::conditional_t<QS, SplitA, RawA>;
-    AReg ra0, ra1;
-    raw4_t<TI> rb0[2][2], rb1[2][2];
-    auto fetch16 = [&](AReg &a, raw4_t<TI> (&b)[2][2], int k0) {
+    constexpr int CH = (int)sizeof(TI);    // 16-byte chunks per item row and step: 4 (fp32), 2 (fp16)
+    constexpr int RPI = 64 / CH;           // item rows per DMA instruction
+    constexpr int EPC = 16 / (int)sizeof(TI);  // factors per chunk
+    __shared__ __attribute__((aligned(1024))) unsigned char stage[4][2][CH * 1024];
+    const TI *isrc[CH];
+    {
+      const int rho = lane / CH, pos = lane % CH, sw = (rho / (8 / CH)) & (CH - 1);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) isrc[j] = I + (size_t)min(i_base + j * RPI + rho, ni - 1) * f + (pos ^ sw) * EPC;
+    }
+    int rd_off[2];  // byte offset of lane (r, kh)'s first chunk of tile t in a step buffer
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int R = 32 * t + r, j = R / RPI, rh = R % RPI, sw = (rh / (8 / CH)) & (CH - 1), c0 = CH == 4 ? 2 * kh : kh;
+      rd_off[t] = j * 1024 + (rh * CH + (c0 ^ sw)) * 16;
+    }
+    auto dma = [&](int buf, int k0) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(isrc[j] + k0),
+                                         (__attribute__((address_space(3))) void *)&stage[wave][buf][j * 1024], 16, 0, 0);
+    };
+    auto fetchA = [&](AReg &a, int k0) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         if constexpr (QS) {
@@ -400,16 +425,30 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
         } else {
           a.v[t][0] = load_raw4(qp[t] + k0), a.v[t][1] = load_raw4(qp[t] + k0 + 4);
         }
-        b[t][0] = load_raw4(ip[t] + k0), b[t][1] = load_raw4(ip[t] + k0 + 4);
       }
     };
-    auto multiply16 = [&](const AReg &a, const raw4_t<TI> (&b)[2][2]) {
+    float4 rb[2][2];  // item fragments of the current step, fp32
+    auto readB = [&](int buf) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA of this step has landed (and the query loads with it)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const unsigned char *base = &stage[wave][buf][0];
+        if constexpr (CH == 4) {
+          rb[t][0] = *reinterpret_cast<const float4 *>(base + rd_off[t]);
+          rb[t][1] = *reinterpret_cast<const float4 *>(base + (rd_off[t] ^ 16));
+        } else {
+          const uint4 raw = *reinterpret_cast<const uint4 *>(base + rd_off[t]);
+          rb[t][0] = widen4(uint2{raw.x, raw.y}), rb[t][1] = widen4(uint2{raw.z, raw.w});
+        }
+      }
+    };
+    auto multiply16 = [&](const AReg &a) {
       tk_bf16x8 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         if constexpr (QS) ah[t] = a.v[t][0], am[t] = a.v[t][1], al[t] = a.v[t][2];
         else split8_bf16(widen4(a.v[t][0]), widen4(a.v[t][1]), ah[t], am[t], al[t]);
-        split8_bf16(widen4(b[t][0]), widen4(b[t][1]), bh[t], bm[t], bl[t]);
+        split8_bf16(rb[t][0], rb[t][1], bh[t], bm[t], bl[t]);
       }
 #pragma unroll
       for (int tq = 0; tq < 2; ++tq)
@@ -425,16 +464,28 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
           acc[tq][ti] = c;
         }
     };
+    // step s: wait for its operands, pull the item fragments out of LDS, request step s + 1 (other buffer / register set),
+    // then split and multiply -- the requests have a whole multiply phase to land
     const int steps16 = f / 16;
-    fetch16(ra0, rb0, 0);
-    int s16 = 0;
-    for (; s16 + 2 <= steps16; s16 += 2) {
-      fetch16(ra1, rb1, 16 * (s16 + 1));
-      multiply16(ra0, rb0);
-      fetch16(ra0, rb0, 16 * min(s16 + 2, steps16 - 1));  // past the end: re-reads the last step, unused
-      multiply16(ra1, rb1);
+    AReg ra0, ra1;
+    fetchA(ra0, 0);
+    dma(0, 0);
+    for (int s16 = 0; s16 < steps16; s16 += 2) {
+      readB(0);
+      if (s16 + 1 < steps16) {
+        fetchA(ra1, 16 * (s16 + 1));
+        dma(1, 16 * (s16 + 1));
+      }
+      multiply16(ra0);
+      if (s16 + 1 < steps16) {
+        readB(1);
+        if (s16 + 2 < steps16) {
+          fetchA(ra0, 16 * (s16 + 2));
+          dma(0, 16 * (s16 + 2));
+        }
+        multiply16(ra1);
+      }
     }
-    if (s16 < steps16) multiply16(ra0, rb0);
   } else {
   // 8 factors per step; the operands of step s + 1 are requested before the 16 MFMAs of step s (two register sets), so
   // the L2 round trip of a step hides under the matrix work of the previous one
