@@ -378,113 +378,117 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
   if constexpr (BF3) {
-    // 16 factors per step.  QUERY operands: lane (r, kh) holds factors k0 + 8 kh .. + 8 of its row -- from the fragment-ordered
-    // split copy (one contiguous KB per load) or straight from the rows (two 16-byte loads).  ITEM operands come through LDS:
-    // a wavefront load of lane (r, kh)'s own 16 bytes touches 32 cache lines for 1 KB and the texture addresser, not the matrix
-    // pipe, set the pace (emit GEMM 0.72 ms with both operands read that way, 0.56 with the queries in fragment order); instead
-    // each wave brings its 64 item rows x 16 factors with LDS-DMA loads of WHOLE row pieces (1 KB per instruction = 16 rows x
-    // 64 bytes fp32 / 32 rows x 32 bytes fp16, four / two lanes per row) into a wave-private double buffer -- no barrier, no
-    // staging registers -- and reads its fragments back with ds_read_b128.  The 16-byte chunks of a row are XOR-swizzled (on
-    // the SOURCE side: the DMA destination is lane-linear) so that the 32 rows a fragment read touches spread over all banks.
-    struct RawA {
-      raw4_t<TQ> v[2][2];
-    };
-    struct SplitA {
-      tk_bf16x8 v[2][3];
-    };
-    using AReg = std::conditional_t<QS, SplitA, RawA>;
-    constexpr int CH = (int)sizeof(TI);    // 16-byte chunks per item row and step: 4 (fp32), 2 (fp16)
-    constexpr int RPI = 64 / CH;           // item rows per DMA instruction
-    constexpr int EPC = 16 / (int)sizeof(TI);  // factors per chunk
-    __shared__ __attribute__((aligned(1024))) unsigned char stage[4][2][CH * 1024];
-    const TI *isrc[CH];
-    {
-      const int rho = lane / CH, pos = lane % CH, sw = (rho / (8 / CH)) & (CH - 1);
+    // 16 factors per step, both operands through LDS, staged ONCE per workgroup and step by LDS-DMA (no staging registers):
+    // a wavefront load of lane (r, kh)'s own 16 bytes of its row touches 32 cache lines for 1 KB, and with every wave loading
+    // its own operands each tile crossed L2 -> L1 twice; the texture addresser and the L2 port, not the matrix pipe, set the
+    // pace (emit GEMM at configs[2]: 0.72 ms that way; 0.56 with the queries in fragment order; 0.52 with wave-private LDS
+    // staging of the items; knock-outs: MFMAs 0.17 ms, loads 0.17, splits 0.07, epilogue 0.06-0.27).
+    //  * factor ROWS (items; queries when they are not pre-split): 1 KB per DMA instruction = whole 64- / 32-byte row pieces
+    //    (16 rows fp32, 32 rows fp16), the 16-byte chunks of a row XOR-swizzled -- on the SOURCE side, the DMA destination is
+    //    lane-linear -- so that the 32 rows of a fragment read spread over all banks;
+    //  * pre-split queries: 12 fragment pieces of 1 KB (4 tiles x 3 terms), lane-linear as stored.
+    // The 8 (4) + 12 instructions of a step are dealt to the four waves; double buffer, one barrier per step: a wave requests
+    // step s + 1 after the barrier of step s, which every wave reaches only with its fragment reads of step s - 1 consumed.
+    constexpr int CHI = (int)sizeof(TI), CHQ = QS ? 4 : (int)sizeof(TQ);  // 16-byte chunks per row and step: 4 (fp32), 2 (fp16)
+    constexpr int Q_BYTES = QS ? 12 * 1024 : CHQ * 2048, I_BYTES = CHI * 2048;
+    __shared__ __attribute__((aligned(1024))) unsigned char stage[2][Q_BYTES + I_BYTES];
+    const int i_block = i_base - 64 * (wave & 1), q_block = q_base - 64 * (wave >> 1);
+    // DMA sources of this wave (rows are clamped: what the extra rows produce is discarded)
+    constexpr int NI_W = 2 * CHI / 4, NQ_W = QS ? 3 : 2 * CHQ / 4;  // instructions per wave and step
+    const TI *isrc[NI_W];
+    const void *qsrc[NQ_W];
 #pragma unroll
-      for (int j = 0; j < CH; ++j) isrc[j] = I + (size_t)min(i_base + j * RPI + rho, ni - 1) * f + (pos ^ sw) * EPC;
+    for (int i = 0; i < NI_W; ++i) {
+      const int j = wave + 4 * i, rho = lane / CHI, pos = lane % CHI, sw = (rho / (8 / CHI)) & (CHI - 1);
+      isrc[i] = I + (size_t)min(i_block + j * (64 / CHI) + rho, ni - 1) * f + (pos ^ sw) * (16 / (int)sizeof(TI));
     }
-    int rd_off[2];  // byte offset of lane (r, kh)'s first chunk of tile t in a step buffer
+#pragma unroll
+    for (int i = 0; i < NQ_W; ++i) {
+      if constexpr (QS) {
+        const int idx = wave * 3 + i, tile = idx / 3, plane = idx % 3;
+        qsrc[i] = reinterpret_cast<const __bf16 *>(Q) + (((size_t)(q_block / 32 + tile) * (f / 16)) * 3 + plane) * 512 + lane * 8;
+      } else {
+        const int j = wave + 4 * i, rho = lane / CHQ, pos = lane % CHQ, sw = (rho / (8 / CHQ)) & (CHQ - 1);
+        qsrc[i] = Q + (size_t)min(q_block + j * (64 / CHQ) + rho, nq - 1) * f + (pos ^ sw) * (16 / (int)sizeof(TQ));
+      }
+    }
+    auto dma = [&](int buf, int s16) {
+#pragma unroll
+      for (int i = 0; i < NQ_W; ++i) {
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(qsrc[i]) + (QS ? (size_t)s16 * 3 * 1024 : (size_t)s16 * 16 * sizeof(TQ));
+        const int slot = QS ? wave * 3 + i : wave + 4 * i;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)&stage[buf][slot * 1024], 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < NI_W; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(isrc[i] + 16 * s16),
+                                         (__attribute__((address_space(3))) void *)&stage[buf][Q_BYTES + (wave + 4 * i) * 1024], 16, 0, 0);
+    };
+    // fragment offsets of lane (r, kh): row R of a 128-row region -> piece R / rows-per-piece, swizzled chunk
+    auto row_offset = [&](int R, int CH) {
+      const int rpi = 64 / CH, j = R / rpi, rh = R % rpi, sw = (rh / (8 / CH)) & (CH - 1), c0 = CH == 4 ? 2 * kh : kh;
+      return j * 1024 + (rh * CH + (c0 ^ sw)) * 16;
+    };
+    int q_off[2], i_off[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const int R = 32 * t + r, j = R / RPI, rh = R % RPI, sw = (rh / (8 / CH)) & (CH - 1), c0 = CH == 4 ? 2 * kh : kh;
-      rd_off[t] = j * 1024 + (rh * CH + (c0 ^ sw)) * 16;
+      i_off[t] = Q_BYTES + row_offset(64 * (wave & 1) + 32 * t + r, CHI);
+      q_off[t] = QS ? ((2 * (wave >> 1) + t) * 3 * 64 + lane) * 16 : row_offset(64 * (wave >> 1) + 32 * t + r, CHQ);
     }
-    auto dma = [&](int buf, int k0) {
-#pragma unroll
-      for (int j = 0; j < CH; ++j)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(isrc[j] + k0),
-                                         (__attribute__((address_space(3))) void *)&stage[wave][buf][j * 1024], 16, 0, 0);
+    auto read_rows = [&](const unsigned char *base, int off, int CH, float4 &v0, float4 &v1) {
+      if (CH == 4) {
+        v0 = *reinterpret_cast<const float4 *>(base + off);
+        v1 = *reinterpret_cast<const float4 *>(base + (off ^ 16));
+      } else {
+        const uint4 raw = *reinterpret_cast<const uint4 *>(base + off);
+        v0 = widen4(uint2{raw.x, raw.y}), v1 = widen4(uint2{raw.z, raw.w});
+      }
     };
-    auto fetchA = [&](AReg &a, int k0) {
+    auto multiply16 = [&](int buf) {
+      const unsigned char *base = &stage[buf][0];
+      tk_bf16x8 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
+      float4 ra[2][2], rb[2][2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         if constexpr (QS) {
-#pragma unroll
-          for (int p = 0; p < 3; ++p)
-            a.v[t][p] = *reinterpret_cast<const tk_bf16x8 *>(reinterpret_cast<const __bf16 *>(qp[t]) + ((k0 >> 4) * 3 + p) * 64 * 8);
+          ah[t] = *reinterpret_cast<const tk_bf16x8 *>(base + q_off[t]);
+          am[t] = *reinterpret_cast<const tk_bf16x8 *>(base + q_off[t] + 1024);
+          al[t] = *reinterpret_cast<const tk_bf16x8 *>(base + q_off[t] + 2048);
         } else {
-          a.v[t][0] = load_raw4(qp[t] + k0), a.v[t][1] = load_raw4(qp[t] + k0 + 4);
+          read_rows(base, q_off[t], CHQ, ra[t][0], ra[t][1]);
         }
+        read_rows(base, i_off[t], CHI, rb[t][0], rb[t][1]);
       }
-    };
-    float4 rb[2][2];  // item fragments of the current step, fp32
-    auto readB = [&](int buf) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA of this step has landed (and the query loads with it)
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const unsigned char *base = &stage[wave][buf][0];
-        if constexpr (CH == 4) {
-          rb[t][0] = *reinterpret_cast<const float4 *>(base + rd_off[t]);
-          rb[t][1] = *reinterpret_cast<const float4 *>(base + (rd_off[t] ^ 16));
-        } else {
-          const uint4 raw = *reinterpret_cast<const uint4 *>(base + rd_off[t]);
-          rb[t][0] = widen4(uint2{raw.x, raw.y}), rb[t][1] = widen4(uint2{raw.z, raw.w});
-        }
-      }
-    };
-    auto multiply16 = [&](const AReg &a) {
-      tk_bf16x8 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        if constexpr (QS) ah[t] = a.v[t][0], am[t] = a.v[t][1], al[t] = a.v[t][2];
-        else split8_bf16(widen4(a.v[t][0]), widen4(a.v[t][1]), ah[t], am[t], al[t]);
+        if constexpr (!QS) split8_bf16(ra[t][0], ra[t][1], ah[t], am[t], al[t]);
         split8_bf16(rb[t][0], rb[t][1], bh[t], bm[t], bl[t]);
       }
+      return [=](auto &accr) {
 #pragma unroll
-      for (int tq = 0; tq < 2; ++tq)
+        for (int tq = 0; tq < 2; ++tq)
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti) {
-          f32x16 c = acc[tq][ti];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tq], bh[ti], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tq], bl[ti], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[tq], bm[ti], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[tq], bh[ti], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tq], bm[ti], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tq], bh[ti], c, 0, 0, 0);
-          acc[tq][ti] = c;
-        }
+          for (int ti = 0; ti < 2; ++ti) {
+            f32x16 c = accr[tq][ti];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tq], bh[ti], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tq], bl[ti], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[tq], bm[ti], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[tq], bh[ti], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tq], bm[ti], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tq], bh[ti], c, 0, 0, 0);
+            accr[tq][ti] = c;
+          }
+      };
     };
-    // step s: wait for its operands, pull the item fragments out of LDS, request step s + 1 (other buffer / register set),
-    // then split and multiply -- the requests have a whole multiply phase to land
     const int steps16 = f / 16;
-    AReg ra0, ra1;
-    fetchA(ra0, 0);
     dma(0, 0);
-    for (int s16 = 0; s16 < steps16; s16 += 2) {
-      readB(0);
-      if (s16 + 1 < steps16) {
-        fetchA(ra1, 16 * (s16 + 1));
-        dma(1, 16 * (s16 + 1));
-      }
-      multiply16(ra0);
-      if (s16 + 1 < steps16) {
-        readB(1);
-        if (s16 + 2 < steps16) {
-          fetchA(ra0, 16 * (s16 + 2));
-          dma(0, 16 * (s16 + 2));
-        }
-        multiply16(ra1);
-      }
+    for (int s16 = 0; s16 < steps16; ++s16) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of step s16 have landed ...
+      __syncthreads();                                   // ... and so have everybody else's
+      auto products = multiply16(s16 & 1);               // fragments out of LDS, splits
+      if (s16 + 1 < steps16) dma((s16 + 1) & 1, s16 + 1);
+      products(acc);
     }
   } else {
   // 8 factors per step; the operands of step s + 1 are requested before the 16 MFMAs of step s (two register sets), so
@@ -528,6 +532,17 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
     int item = i_base + 32 * ti + r;
     nrm[ti] = (norms && item < ni) ? norms[item] : 1.f;
   }
+  // cosine scores: ONE wave-uniform branch around the 64 divisions.  Written per element ("if (norms) sc = sc / nrm") the
+  // compiler turned the test into a select and every lane ran 64 IEEE division sequences (~700 vector instructions, more
+  // than half of the main loop's count at f = 128) in recommend() calls, which have no norms at all.
+  if (norms) {
+#pragma unroll
+    for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[tq][ti][e] = acc[tq][ti][e] / nrm[ti];
+  }
   if constexpr (MODE == 1) {
     // compact layout: block b of the subset occupies columns [128 b, 128 b + 128); items past the end score -FLT_MAX
     const int sub_cols = gridDim.x * 128;
@@ -541,7 +556,6 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
 #pragma unroll
           for (int ti = 0; ti < 2; ++ti) {
             float sc = acc[tq][ti][e];
-            if (norms) sc = sc / nrm[ti];
             S[(size_t)q * sub_cols + c_base + 32 * ti + r] = (i_base + 32 * ti + r < ni) ? sc : -FLT_MAX;
           }
         }
@@ -560,6 +574,14 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
         const int q0 = q_base + 32 * tq + 8 * eg + 4 * kh;
         const uint4 t4 = *reinterpret_cast<const uint4 *>(emit.tau + q0);
         const uint32_t tk[4] = {t4.x, t4.y, t4.z, t4.w};
+        // eight scores per lane against four thresholds, folded into one wave-wide test: most groups have no survivor
+        bool any = false;
+#pragma unroll
+        for (int el = 0; el < 4; ++el) {
+          const float tf = unordered(tk[el]);
+          any |= !(acc[tq][0][4 * eg + el] < tf) | !(acc[tq][1][4 * eg + el] < tf);
+        }
+        if (__builtin_amdgcn_ballot_w64(any) == 0) continue;
 #pragma unroll
         for (int el = 0; el < 4; ++el) {
           const int e = 4 * eg + el, q = q0 + el;
@@ -568,7 +590,6 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
 #pragma unroll
           for (int ti = 0; ti < 2; ++ti) {
             float sc = acc[tq][ti][e];
-            if (norms) sc = sc / nrm[ti];
             if (!(sc < tf)) {
               const int item = i_base + 32 * ti + r;
               if (q < nq && item < ni && ordered(sc) >= t) {
@@ -595,7 +616,6 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
       for (int e = 0; e < 16; ++e) {
         const int q = q_base + 32 * tq + (e & 3) + 8 * (e >> 2) + 4 * kh;
         float sc0 = acc[tq][0][e], sc1 = acc[tq][1][e];
-        if (norms) sc0 = sc0 / nrm[0], sc1 = sc1 / nrm[1];
         float *row = S + (size_t)q * ni + i_base + r;
         row[0] = sc0;
         row[32] = sc1;
@@ -616,7 +636,6 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
       for (int ti = 0; ti < 2; ++ti) {
         const int item = i_base + 32 * ti + r;
         float sc = acc[tq][ti][e];
-        if (norms) sc = sc / nrm[ti];
         if (item < ni) {
           if (q < nq) S[(size_t)q * ni + item] = sc;
           m = fmaxf(m, sc);
