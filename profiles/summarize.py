@@ -72,6 +72,15 @@ if traces:
     json.dump(rec, open(os.path.join(here, f"{tag}_roofline_check.json"), "w"), indent=1, sort_keys=True)
 
 summary = collections.defaultdict(dict)
+prev = os.path.join(here, f"{tag}_pmc_summary.json")
+if os.path.exists(prev):  # a partial collection (collect.sh <tag> topk) replaces only the kernels it saw
+    for k, d in json.load(open(prev)).items():
+        summary[k] = d
+seen_now = set()
+for sub in ("fetch", "write", "sq", "topk_pmc", "chol_pmc"):  # what a pass collects again it replaces wholesale (kernel names change)
+    if glob.glob(os.path.join(out_dir, sub, "*", "*counter_collection.csv")):
+        for k in [k for k, d in summary.items() if "dispatches_" + sub in d]:
+            del summary[k]
 for sub in ("fetch", "write", "sq", "topk_pmc", "chol_pmc"):
     for f in glob.glob(os.path.join(out_dir, sub, "*", "*counter_collection.csv")):
         agg, cnt = collections.defaultdict(float), collections.Counter()
@@ -80,6 +89,9 @@ for sub in ("fetch", "write", "sq", "topk_pmc", "chol_pmc"):
             agg[key] += float(row["Counter_Value"])
             cnt[key] += 1
         for (k, c), v in agg.items():
+            if k not in seen_now:
+                seen_now.add(k)
+                summary[k] = {}
             summary[k][c] = v / cnt[(k, c)]
             summary[k]["dispatches_" + sub] = cnt[(k, c)]
 for k, d in summary.items():

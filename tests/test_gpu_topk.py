@@ -234,3 +234,21 @@ def test_factor_counts_off_the_16_grid_take_the_fast_path(gpu, oracle, f):
     assert_allclose(d16, w_d, rtol=3e-5)
     ok = ~_near_tie_rows(w_d, f)
     assert_array_equal(ids16[ok], w_ids[ok])
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+def test_emit_path_over_several_query_batches(gpu, oracle, dtype):
+    """More queries than one emit batch (2 048 rows): the fragment-ordered split copy of the query rows is indexed per batch and
+    padded to whole 128-row blocks, the last batch is ragged (77 rows) -- fp32 and fp16 storage, per-query filter, against the
+    oracle on the same (rounded) factors."""
+    rng = np.random.default_rng(21)
+    ni, nq, f, k = 8_000, 2 * 2048 + 77, 64, 10
+    items = (rng.standard_normal((ni, f)) * 0.1).astype(dtype)
+    q = (rng.standard_normal((nq, f)) * 0.1).astype(dtype)
+    liked = sp.random(nq, ni, density=12.0 / ni, format="csr", random_state=3, dtype=np.float32)
+    ids, d = gpu.KnnQuery().topk(gpu.Matrix(items), gpu.Matrix(q), k, query_filter=gpu.COOMatrix(liked.tocoo()))
+    want_ids, want_d = oracle.topk(items.astype(np.float32), q.astype(np.float32), k, filter_query_items=liked)
+    assert_allclose(d, want_d, rtol=3e-5, atol=1e-7)
+    ok = ~_near_tie_rows(want_d, f)
+    assert ok.mean() > 0.9
+    assert_array_equal(ids[ok], want_ids[ok])
