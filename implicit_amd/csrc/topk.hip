@@ -1121,6 +1121,24 @@ struct imp_knn {
   DeviceArray<unsigned int> cand_count;
   DeviceArray<uint64_t> cand;
   DeviceArray<int32_t> fb_rows, fb_ids;
+  // page-locked, device-addressable host memory of the emit path: fallback flags and (host outputs) ids / scores are written
+  // there by the kernels themselves (see imp_knn_topk)
+  struct Pinned {
+    void *p = nullptr;
+    size_t bytes = 0;
+    void *ensure(size_t n) {
+      if (bytes < n) {
+        if (p) (void)hipHostFree(p);
+        p = nullptr, bytes = 0;
+        IMP_CHECK_HIP(hipHostMalloc(&p, n, hipHostMallocDefault));
+        bytes = n;
+      }
+      return p;
+    }
+    ~Pinned() {
+      if (p) (void)hipHostFree(p);
+    }
+  } host_stage;
   template <typename T> static T *ensure(DeviceArray<T> &a, size_t n) {
     if (a.size < n) a.alloc(n);
     return a.data();
@@ -1259,7 +1277,29 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
       uint32_t *row_bits = have_coo ? imp_knn::ensure(knn->row_bits, ebatch * (size_t)words) : nullptr;
       uint32_t *item_bits = have_items ? imp_knn::ensure(knn->item_bits, (size_t)words) : nullptr;
       if (have_items) IMP_CHECK_HIP(hipMemsetAsync(item_bits, 0, (size_t)words * 4, stream()));
-      std::vector<int> flags(ebatch);
+      // Host outputs: the select kernels write ids, scores and the fallback flags STRAIGHT into page-locked host memory the
+      // device can address ([flags of a batch][ids of the call][scores of the call]); after the one host wait of a batch they
+      // are simply there.  Any D2H copy instead costs more than the whole candidate sort: into pageable memory (the caller's
+      // numpy arrays, a std::vector) the runtime stages it with a host wait of its own (three per call: ~0.1 of a 0.59 ms
+      // call), and an ASYNCHRONOUS copy queued behind the kernels, page-locked or not, took ~0.4 ms to start on this stack
+      // (0.59 -> 1.0 ms per call, gpurun_out/r4o, r4q).
+      const size_t out_words = nq * (size_t)k;
+      const bool stage_results = (host_ids || host_dist) && out_words <= ((size_t)16 << 20);
+      int *flags = static_cast<int *>(knn->host_stage.ensure((ebatch + (stage_results ? 2 * out_words : 0)) * 4));
+      int32_t *stage_ids = reinterpret_cast<int32_t *>(flags + ebatch);
+      float *stage_dist = reinterpret_cast<float *>(flags + ebatch + out_words);
+      if (stage_results) {
+        sync();  // (k_eff < k: the copies of the caller's initial values into the device buffers above are not needed any more)
+        if (host_ids) {
+          if (k_eff < k) std::copy(indices, indices + out_words, stage_ids);
+          d_ids = stage_ids;
+        }
+        if (host_dist) {
+          if (k_eff < k) std::copy(distances, distances + out_words, stage_dist);
+          d_dist = stage_dist;
+        }
+      }
+      fallback_e = flags;
       std::vector<int32_t> fb_list;
       static const bool no_qsplit = getenv("IMP_TOPK_NO_QSPLIT") != nullptr;
       constexpr bool kCanSplit = BF3;
@@ -1331,7 +1371,6 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
                                                                              d_dist + start * k, k, fallback_e);
           IMP_CHECK_HIP(hipGetLastError());
         }
-        IMP_CHECK_HIP(hipMemcpyAsync(flags.data(), fallback_e, rows * sizeof(int), hipMemcpyDeviceToHost, stream()));
         sync();
         fb_list.clear();
         for (size_t i = 0; i < rows; ++i)
@@ -1377,9 +1416,15 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
           }
         }
       }
-      if (host_ids) IMP_CHECK_HIP(hipMemcpyAsync(indices, d_ids, nq * (size_t)k * 4, hipMemcpyDeviceToHost, stream()));
-      if (host_dist) IMP_CHECK_HIP(hipMemcpyAsync(distances, d_dist, nq * (size_t)k * 4, hipMemcpyDeviceToHost, stream()));
-      sync();
+      if (stage_results) {
+        sync();  // fallback rows of the last batch
+        if (host_ids) std::copy(stage_ids, stage_ids + out_words, indices);
+        if (host_dist) std::copy(stage_dist, stage_dist + out_words, distances);
+      } else {
+        if (host_ids) IMP_CHECK_HIP(hipMemcpyAsync(indices, d_ids, out_words * 4, hipMemcpyDeviceToHost, stream()));
+        if (host_dist) IMP_CHECK_HIP(hipMemcpyAsync(distances, d_dist, out_words * 4, hipMemcpyDeviceToHost, stream()));
+        sync();
+      }
       return;
     }
 
