@@ -1225,13 +1225,47 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
     const bool host_ids = is_host_pointer(indices), host_dist = is_host_pointer(distances);
     int32_t *d_ids = indices;
     float *d_dist = distances;
-    if (host_ids) d_ids = imp_knn::ensure(knn->dev_ids, nq * (size_t)k);
-    if (host_dist) d_dist = imp_knn::ensure(knn->dev_dist, nq * (size_t)k);
-    if (k_eff < k) {
-      // entries past k_eff keep the caller's initial values (topk.pyx:20-21 zero-fills them)
-      if (host_ids) IMP_CHECK_HIP(hipMemcpyAsync(d_ids, indices, nq * (size_t)k * 4, hipMemcpyHostToDevice, stream()));
-      if (host_dist) IMP_CHECK_HIP(hipMemcpyAsync(d_dist, distances, nq * (size_t)k * 4, hipMemcpyHostToDevice, stream()));
+    // Host outputs: the select kernels write ids and scores (and the emit path its fallback flags) STRAIGHT into page-locked
+    // host memory the device can address -- [2048 flags][ids of the call][scores of the call] -- and after the host wait they
+    // are simply there.  Any D2H copy instead costs more than the whole candidate sort: into pageable memory (the caller's
+    // numpy arrays) the runtime stages it with a host wait of its own (three per emit call: ~0.1 of a 0.59 ms call), and an
+    // ASYNCHRONOUS copy queued behind the kernels, page-locked or not, took ~0.4 ms to start on this stack (0.59 -> 1.0 ms
+    // per call, gpurun_out/r4o, r4q).  Very large results (> 64 MB per array) keep the device buffers and the copies.
+    constexpr size_t kFlagSlots = 2048;  // = the emit path's batch
+    const size_t out_words = nq * (size_t)k;
+    const bool stage_results = (host_ids || host_dist) && out_words <= ((size_t)16 << 20);
+    int *host_flags = static_cast<int *>(knn->host_stage.ensure((kFlagSlots + (stage_results ? 2 * out_words : 0)) * 4));
+    int32_t *stage_ids = reinterpret_cast<int32_t *>(host_flags + kFlagSlots);
+    float *stage_dist = reinterpret_cast<float *>(host_flags + kFlagSlots + out_words);
+    if (host_ids) {
+      if (stage_results) {
+        d_ids = stage_ids;
+        if (k_eff < k) std::copy(indices, indices + out_words, stage_ids);  // entries past k_eff keep the caller's initial values (topk.pyx:20-21 zero-fills them)
+      } else {
+        d_ids = imp_knn::ensure(knn->dev_ids, out_words);
+        if (k_eff < k) IMP_CHECK_HIP(hipMemcpyAsync(d_ids, indices, out_words * 4, hipMemcpyHostToDevice, stream()));
+      }
     }
+    if (host_dist) {
+      if (stage_results) {
+        d_dist = stage_dist;
+        if (k_eff < k) std::copy(distances, distances + out_words, stage_dist);
+      } else {
+        d_dist = imp_knn::ensure(knn->dev_dist, out_words);
+        if (k_eff < k) IMP_CHECK_HIP(hipMemcpyAsync(d_dist, distances, out_words * 4, hipMemcpyHostToDevice, stream()));
+      }
+    }
+    auto deliver = [&] {  // end of a call: wait, then hand the results over
+      if (stage_results) {
+        sync();
+        if (host_ids) std::copy(stage_ids, stage_ids + out_words, indices);
+        if (host_dist) std::copy(stage_dist, stage_dist + out_words, distances);
+      } else {
+        if (host_ids) IMP_CHECK_HIP(hipMemcpyAsync(indices, d_ids, out_words * 4, hipMemcpyDeviceToHost, stream()));
+        if (host_dist) IMP_CHECK_HIP(hipMemcpyAsync(distances, d_dist, out_words * 4, hipMemcpyDeviceToHost, stream()));
+        sync();
+      }
+    };
 
     size_t temp = std::min<size_t>(knn->max_temp_memory, (size_t)4 << 30);
     size_t batch = std::max<size_t>(1, std::min<size_t>(nq, temp / (sizeof(float) * ni)));
@@ -1272,34 +1306,13 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
       uint32_t *tau = imp_knn::ensure(knn->tau, (ebatch + 127) / 128 * 128);  // the emit epilogue loads thresholds four rows at a time
       unsigned int *cnt = imp_knn::ensure(knn->cand_count, ebatch);
       uint64_t *cand = imp_knn::ensure(knn->cand, ebatch * (size_t)kEmitCap);
-      int *fallback_e = imp_knn::ensure(knn->fallback, ebatch);
+      int *fallback_e = host_flags;  // one flag per row of the batch, read by the host after the batch's wait
       const bool have_coo = query_filter && query_filter->nnz, have_items = item_filter && item_filter->size;
       uint32_t *row_bits = have_coo ? imp_knn::ensure(knn->row_bits, ebatch * (size_t)words) : nullptr;
       uint32_t *item_bits = have_items ? imp_knn::ensure(knn->item_bits, (size_t)words) : nullptr;
       if (have_items) IMP_CHECK_HIP(hipMemsetAsync(item_bits, 0, (size_t)words * 4, stream()));
-      // Host outputs: the select kernels write ids, scores and the fallback flags STRAIGHT into page-locked host memory the
-      // device can address ([flags of a batch][ids of the call][scores of the call]); after the one host wait of a batch they
-      // are simply there.  Any D2H copy instead costs more than the whole candidate sort: into pageable memory (the caller's
-      // numpy arrays, a std::vector) the runtime stages it with a host wait of its own (three per call: ~0.1 of a 0.59 ms
-      // call), and an ASYNCHRONOUS copy queued behind the kernels, page-locked or not, took ~0.4 ms to start on this stack
-      // (0.59 -> 1.0 ms per call, gpurun_out/r4o, r4q).
-      const size_t out_words = nq * (size_t)k;
-      const bool stage_results = (host_ids || host_dist) && out_words <= ((size_t)16 << 20);
-      int *flags = static_cast<int *>(knn->host_stage.ensure((ebatch + (stage_results ? 2 * out_words : 0)) * 4));
-      int32_t *stage_ids = reinterpret_cast<int32_t *>(flags + ebatch);
-      float *stage_dist = reinterpret_cast<float *>(flags + ebatch + out_words);
-      if (stage_results) {
-        sync();  // (k_eff < k: the copies of the caller's initial values into the device buffers above are not needed any more)
-        if (host_ids) {
-          if (k_eff < k) std::copy(indices, indices + out_words, stage_ids);
-          d_ids = stage_ids;
-        }
-        if (host_dist) {
-          if (k_eff < k) std::copy(distances, distances + out_words, stage_dist);
-          d_dist = stage_dist;
-        }
-      }
-      fallback_e = flags;
+      static_assert(kFlagSlots >= 2048, "one flag per row of an emit batch");
+      const int *flags = host_flags;
       std::vector<int32_t> fb_list;
       static const bool no_qsplit = getenv("IMP_TOPK_NO_QSPLIT") != nullptr;
       constexpr bool kCanSplit = BF3;
@@ -1416,15 +1429,7 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
           }
         }
       }
-      if (stage_results) {
-        sync();  // fallback rows of the last batch
-        if (host_ids) std::copy(stage_ids, stage_ids + out_words, indices);
-        if (host_dist) std::copy(stage_dist, stage_dist + out_words, distances);
-      } else {
-        if (host_ids) IMP_CHECK_HIP(hipMemcpyAsync(indices, d_ids, out_words * 4, hipMemcpyDeviceToHost, stream()));
-        if (host_dist) IMP_CHECK_HIP(hipMemcpyAsync(distances, d_dist, out_words * 4, hipMemcpyDeviceToHost, stream()));
-        sync();
-      }
+      deliver();
       return;
     }
 
@@ -1497,9 +1502,7 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
         IMP_CHECK_HIP(hipGetLastError());
       }
     }
-    if (host_ids) IMP_CHECK_HIP(hipMemcpyAsync(indices, d_ids, nq * (size_t)k * 4, hipMemcpyDeviceToHost, stream()));
-    if (host_dist) IMP_CHECK_HIP(hipMemcpyAsync(distances, d_dist, nq * (size_t)k * 4, hipMemcpyDeviceToHost, stream()));
-    sync();
+    deliver();
     };
     // IMP_TOPK_FP32_MFMA=1: the exact-fp32 MFMA form (v_mfma_f32_32x32x2_f32) instead of the split-bf16 one (A/B, parity)
     static const bool exact_mfma = getenv("IMP_TOPK_FP32_MFMA") != nullptr;
