@@ -63,6 +63,27 @@ template <typename F> int guarded(F &&body) {
   }
 }
 
+// host-only entry points (no stream, no workspace): same error mapping without the device's call lock, so that they can run
+// beside device calls of another thread (fit() transposes the matrix while the first CSR uploads)
+template <typename F> int guarded_host(F &&body) {
+  try {
+    body();
+    return IMP_OK;
+  } catch (const std::invalid_argument &e) {
+    set_last_error(e.what());
+    return IMP_INVALID_ARGUMENT;
+  } catch (const out_of_range_error &e) {
+    set_last_error(e.what());
+    return IMP_OUT_OF_RANGE;
+  } catch (const std::exception &e) {
+    set_last_error(e.what());
+    return IMP_RUNTIME_ERROR;
+  } catch (...) {
+    set_last_error("unknown error");
+    return IMP_RUNTIME_ERROR;
+  }
+}
+
 inline hipStream_t stream();
 void sync();  // hipStreamSynchronize on the library stream
 // end of a C-ABI call that only queues device work (solver sweeps, gramian, all-reduce): host wait unless the device is in

@@ -302,7 +302,7 @@ int imp_mem_get_info(size_t *free_bytes, size_t *total_bytes) {
 // its rows in order -- rows stay sorted inside every output row, bit-identical to scipy's result on canonical input.
 int imp_host_csr_transpose(int32_t rows, int32_t cols, int64_t nnz, const int32_t *indptr, const int32_t *indices, const float *data,
                            int32_t *t_indptr, int32_t *t_indices, float *t_data, int threads) {
-  return guarded([&] {
+  return guarded_host([&] {
     if (rows < 0 || cols < 0 || nnz < 0 || nnz > INT32_MAX) throw std::invalid_argument("host_csr_transpose: sizes out of range");
     if (indptr[0] != 0 || indptr[rows] != nnz) throw std::invalid_argument("host_csr_transpose: indptr does not span the nonzeros");
     // per-thread histograms cost T x cols counters: keep them under 256 MB

@@ -24,6 +24,7 @@ communicator from the launcher's RANK / WORLD_SIZE / MASTER_* environment.  No r
 """
 import logging
 import time
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -91,13 +92,18 @@ class AlternatingLeastSquares(MatrixFactorizationBase):
         if self.comm is not None and self.comm.nranks > 1:
             return self._fit_sharded(Cui, callback)  # `user_items` = THIS RANK's block of user rows
 
+        # set-up: the transpose (threaded counting transpose in the library, host only, no device lock; scipy for
+        # non-canonical input) runs on a worker thread while this one uploads the user-side matrix with its row schedule
+        # and draws / uploads the initial factors; ctypes and numpy drop the GIL in all of them
         t0 = time.time()
-        Ciu = transpose_csr(Cui)  # threaded counting transpose in the library (scipy for non-canonical input)
-        log.debug("Calculated transpose in %.3fs", time.time() - t0)
-        items, users = Ciu.shape
-        self._initial_factors(users, items)
-
-        Cui_dev, Ciu_dev = gpu.CSRMatrix(Cui), gpu.CSRMatrix(Ciu)
+        users, items = Cui.shape
+        with ThreadPoolExecutor(max_workers=1) as worker:
+            transposed = worker.submit(transpose_csr, Cui)
+            Cui_dev = gpu.CSRMatrix(Cui)
+            self._initial_factors(users, items)
+            Ciu = transposed.result()
+        log.debug("Transpose, user-side upload and initial factors in %.3fs", time.time() - t0)
+        Ciu_dev = gpu.CSRMatrix(Ciu)
         X, Y = self.user_factors, self.item_factors
         gram = gpu.Matrix.zeros(self.factors, self.factors)
         loss = None
