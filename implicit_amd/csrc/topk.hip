@@ -259,12 +259,14 @@ __global__ __launch_bounds__(BLOCK) void select_kernel(const float *__restrict__
 }
 
 
-// ---- fast path (f % 8 == 0): operands straight from global memory, no LDS, no barriers ---------------------------
-// 128 x 128 block tile, 4 waves as 2 x 2, each wave 64 queries x 64 items = 2 x 2 tiles of v_mfma_f32_32x32x2_f32.
-// Lane (r = l & 31, kh = l >> 5) loads ONE float4 = 4 consecutive factors [k0 + 4 kh, +4) of its query / item row per
-// 8-factor block; MFMA step s of the block uses factor k0 + 4 kh + s for BOTH operands (the k index inside an MFMA is
-// a free permutation), so one dwordx4 per operand tile feeds 4 MFMAs.  Epilogue: optional divide by the item norm,
-// coalesced score write, and the per-(query, 64-item) maximum for the pruned select below.
+// ---- fast path (f % 8 == 0): 128 x 128 block tile, 4 waves as 2 x 2, each wave 64 queries x 64 items = 2 x 2 MFMA tiles -----
+// Split-bf16 form (f % 16 == 0, default): v_mfma_f32_32x32x16_bf16 on three-way split operands, both operands staged per
+// workgroup and 16-factor step by LDS-DMA (see the kernel).  Exact-fp32 form (v_mfma_f32_32x32x2_f32; f % 8 == 0 off the
+// 16-grid, IMP_TOPK_FP32_MFMA=1): operands straight from global memory, no LDS, no barriers -- lane (r = l & 31, kh = l >> 5)
+// loads ONE float4 = 4 consecutive factors [k0 + 4 kh, +4) of its query / item row per 8-factor block; MFMA step s of the
+// block uses factor k0 + 4 kh + s for BOTH operands (the k index inside an MFMA is a free permutation), so one dwordx4 per
+// operand tile feeds 4 MFMAs.  Epilogues: optional divide by the item norm, then the coalesced score write with the
+// per-(query, 64-item) maximum for the pruned select below (MODE 0), the compact threshold subset (1) or the emit test (2).
 constexpr int kTileItems = 64;  // granularity of the tile maxima
 
 // MODE 0: scores written to S[q][item] + per-(query, 64-item) maxima          (materialising path)
@@ -339,7 +341,6 @@ template <> struct raw4<__half> {
 template <typename T> using raw4_t = typename raw4<T>::type;
 __device__ __forceinline__ float4 load_raw4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ uint2 load_raw4(const __half *p) { return *reinterpret_cast<const uint2 *>(p); }
-__device__ __forceinline__ float4 load_raw4(const split_bf16 *) { return float4{}; }  // never called: split rows have their own loads
 __device__ __forceinline__ float4 widen4(const float4 &v) { return v; }
 __device__ __forceinline__ float4 widen4(const uint2 &raw) {
   const float2 a = __half22float2(*reinterpret_cast<const __half2 *>(&raw.x));
@@ -361,14 +362,6 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
   const int i_base = (MODE == 1 ? blockIdx.x * block_stride : blockIdx.x) * 128 + 64 * (wave & 1);
   constexpr bool QS = std::is_same<TQ, split_bf16>::value;  // query rows already split: [3][f] bf16 per row
   static_assert(!QS || BF3, "split query rows feed the bf16 form only");
-  const TQ *qp[2];
-  const TI *ip[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    if constexpr (QS) qp[t] = Q + ((size_t)(q_base / 32 + t) * (f / 16) * 3 * 64 + lane) * 8;  // fragment order, padded to whole tiles
-    else qp[t] = Q + (size_t)min(q_base + 32 * t + r, nq - 1) * f + (BF3 ? 8 : 4) * kh;  // clamped rows: results are discarded
-    ip[t] = I + (size_t)min(i_base + 32 * t + r, ni - 1) * f + (BF3 ? 8 : 4) * kh;
-  }
   f32x16 acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -493,6 +486,13 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
   } else {
   // 8 factors per step; the operands of step s + 1 are requested before the 16 MFMAs of step s (two register sets), so
   // the L2 round trip of a step hides under the matrix work of the previous one
+  const TQ *qp[2];
+  const TI *ip[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    qp[t] = Q + (size_t)min(q_base + 32 * t + r, nq - 1) * f + 4 * kh;  // clamped rows: results are discarded
+    ip[t] = I + (size_t)min(i_base + 32 * t + r, ni - 1) * f + 4 * kh;
+  }
   raw4_t<TQ> a0[2], a1[2];
   raw4_t<TI> b0[2], b1[2];
   auto fetch = [&](raw4_t<TQ> (&a)[2], raw4_t<TI> (&b)[2], int k0) {
