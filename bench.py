@@ -235,18 +235,19 @@ def main():
         from implicit_amd.gpu import sharded
 
         def rank0_roofline(Cui, Ciu, timed, steps):
-            """Same definition as the single-GPU line, on rank 0's shard: algorithmic bytes of its mid-row class per
-            half sweep / HIP-event time of the team kernels in the timed region."""
-            live = {k: v for k, v in timed.items() if k in CLASS_KERNELS["mid"] and v[1] > 0}
-            if not live:
+            """Whole-step definition, as in the single-GPU line, on rank 0's shard: algorithmic bytes of every row class of
+            both half sweeps / HIP-event time of its least_squares calls (one event pair per call, K chunk calls per half
+            sweep) in the timed region.  The exchange is not in it (it runs on the other stream, overlapped)."""
+            ms, n = timed.get("als_cg_half_sweep", (0.0, 0))
+            if not n:
                 return None
-            total_ms = sum(v[0] for v in live.values())
-            per_sweep = class_bytes_per_iteration(Cui, Ciu, FACTORS)["mid"] / 2.0
-            achieved = per_sweep * 2 * steps / (total_ms * 1e-3) / 1e9
-            return {"bound": "hbm", "kernel": "+".join(CLASS_KERNELS["mid"]), "row_class": "mid", "achieved": achieved,
+            per_step = sum(class_bytes_per_iteration(Cui, Ciu, FACTORS).values())
+            achieved = per_step * steps / (ms * 1e-3) / 1e9
+            return {"bound": "hbm", "kernel": "CG half sweep: every row-class launch of rank 0's least_squares calls",
+                    "scope": "whole step on rank 0's shard (compute only)", "achieved": achieved,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                    "avg_ms_per_half_sweep": total_ms / (2 * steps), "algorithmic_bytes_per_half_sweep": per_sweep,
-                    "timing_source": "HIP events inside the timed region, rank 0"}
+                    "avg_launch_ms": ms / n, "algorithmic_bytes_per_step": per_step,
+                    "timing_source": "HIP events around each least_squares call inside the timed region, rank 0"}
 
         result = sharded.bench(args, gpu, SHAPES, FACTORS, REG, CG_STEPS, rank0_roofline)
         if rank == 0:
@@ -288,7 +289,7 @@ def main():
     # HIP-event pairs cost stream time (~0.2 ms per iteration for all ~30 launches), so the timed region carries them
     # only for the dominant kernel family -- the mid-row team kernels of the CG sweep -- which is what `roofline`
     # reports; the per-kernel breakdown comes from a separate, untimed pass below.
-    timed_filter = "als_cg_team" if (args.solver == "cg" and FACTORS in (64, 128)) else None
+    timed_filter = "als_cg_half_sweep" if args.solver == "cg" else None
     gpu.Profiler.reset()
     gpu.Profiler.enable(os.environ.get("IMP_BENCH_NO_PROF") is None, only=timed_filter)
     t0 = time.perf_counter()
@@ -310,12 +311,15 @@ def main():
     gpu.synchronize()
     gpu.Profiler.enable(False)
 
-    # ---- roofline of the dominant kernel ----------------------------------------------------------
+    # ---- roofline: the WHOLE step (every row class of both half sweeps), per-class table as an extra ---------------
     cbytes = class_bytes_per_iteration(Cui, Ciu, FACTORS)
     kernels = {}
     for name in gpu.Profiler.names():
         ms, n = gpu.Profiler.get(name)
         kernels[name] = {"total_ms": ms, "launches": n}
+    traffic, traffic_src = (None, None)
+    if (args.shape, args.scale, args.solver, FACTORS) == ("lastfm360k", 1.0, "cg", 128):
+        traffic, traffic_src = pmc_traffic_per_half_sweep(CG_STEPS)
     classes = {}
     for cname, knames in CLASS_KERNELS.items():
         ms = sum(kernels.get(k, {"total_ms": 0})["total_ms"] for k in knames)
@@ -323,37 +327,31 @@ def main():
         if ms > 0:
             classes[cname] = {"ms_per_step": ms / detail_steps, "launches_per_step": launches / detail_steps,
                               "algorithmic_GB_per_step": cbytes[cname] / 1e9,
-                              "achieved_GBps": cbytes[cname] * detail_steps / (ms * 1e-3) / 1e9}
-    roofline = None
-    if classes:
-        # timed-region measurement when the filter covered the class, else the detail pass
-        dom = "mid" if timed_filter and "mid" in classes else max(classes, key=lambda c: classes[c]["ms_per_step"])
-        live = {k: timed[k] for k in CLASS_KERNELS[dom] if k in timed and timed[k][1] > 0}
-        if live:
-            total_ms, n_steps = sum(v[0] for v in live.values()), args.steps
-            first_launches = live.get(CLASS_KERNELS[dom][0], next(iter(live.values())))[1]
-            source = "HIP events inside the timed region"
-        else:
-            total_ms, n_steps = classes[dom]["ms_per_step"] * detail_steps, detail_steps
-            first_launches = kernels[CLASS_KERNELS[dom][0]]["launches"]
-            source = "HIP events, separate pass after the timed region"
-        sweeps = 2 * n_steps  # the class runs once per half sweep (mid: one launch per team width)
-        bytes_per_sweep = cbytes[dom] / 2.0
-        achieved = bytes_per_sweep * sweeps / (total_ms * 1e-3) / 1e9
-        traffic, traffic_src = (None, None)
-        if (args.shape, args.scale, args.solver, FACTORS) == ("lastfm360k", 1.0, "cg", 128):
-            traffic, traffic_src = pmc_traffic_per_half_sweep(CG_STEPS)
-        roofline = {"bound": "hbm", "kernel": "+".join(CLASS_KERNELS[dom]), "row_class": dom,
-                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic.get(dom) if traffic else None, "traffic_source": traffic_src,
-                    "avg_launch_ms": total_ms / max(1, first_launches),
-                    "avg_ms_per_half_sweep": total_ms / sweeps,
-                    "algorithmic_bytes_per_half_sweep": bytes_per_sweep,
-                    "timing_source": source,
-                    "note": "achieved = algorithmic bytes of this row class per half sweep / HIP-event time of its "
-                            "launch(es) in that half sweep; whole-iteration figure in `iteration_roofline`"}
+                              "achieved_GBps": cbytes[cname] * detail_steps / (ms * 1e-3) / 1e9,
+                              "frac": cbytes[cname] * detail_steps / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "pmc_traffic_GB_per_step": (2 * traffic[cname] / 1e9) if traffic and cname in traffic else None}
     total_bytes = sum(cbytes.values())
+    roofline = None
+    sweep_ms, sweep_n = timed.get("als_cg_half_sweep", (0.0, 0))
+    if args.solver == "cg":
+        # `achieved` is quoted on the same clock as `value`: algorithmic bytes of one step / ms_per_step (gramians, launch
+        # gaps and the host loop included); the HIP events around the two half sweeps of a step are the cross-check
+        achieved = total_bytes / (elapsed / args.steps) / 1e9
+        roofline = {"bound": "hbm", "kernel": "CG half sweep: every row-class launch of one least_squares call ("
+                    + ", ".join(k for ks in CLASS_KERNELS.values() for k in ks if k in kernels) + ")",
+                    "scope": "whole step = user half sweep + item half sweep, all row classes",
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": (2 * sum(traffic.values())) if traffic else None, "traffic_source": traffic_src,
+                    "traffic_note": "HBM bytes per STEP (both half sweeps) from the committed rocprofv3 PMC summary",
+                    "algorithmic_bytes_per_step": total_bytes,
+                    "avg_launch_ms": (sweep_ms / sweep_n) if sweep_n else None,
+                    "half_sweeps_timed": sweep_n,
+                    "frac_half_sweep_events": (total_bytes * args.steps / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if sweep_ms else None,
+                    "timing_source": "ms_per_step of the timed region (wall clock, synchronised both sides); "
+                                     "avg_launch_ms / frac_half_sweep_events: one HIP-event pair around each half sweep "
+                                     "inside the same timed region",
+                    "note": "algorithmic bytes = nnz(4f+8) + rows(8f+8) + 4f^2 per half sweep (SURVEY 8d); per-class "
+                            "figures in `row_classes` (separate pass after the timed region, one event pair per launch)"}
     iteration_roofline = {"algorithmic_GB_per_step": total_bytes / 1e9,
                           "achieved_GBps": total_bytes / (elapsed / args.steps) / 1e9,
                           "frac_of_8TBps": total_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS}

@@ -724,6 +724,8 @@ static void least_squares_cg_padded(const imp_csr *C, imp_matrix *X, const imp_m
 }
 
 void least_squares_cg(const imp_csr *C, imp_matrix *X, const imp_matrix *YtY, const imp_matrix *Y, int cg_steps) {
+  // one event pair around ALL launches of the half sweep (every row class): what bench.py's whole-step `roofline` is timed on
+  IMP_PROF("als_cg_half_sweep");
   const int f = (int)X->cols;
   const float *a0 = YtY->f32();
   if (X->itemsize == 2) {

@@ -262,7 +262,7 @@ enum : unsigned { kGo = 1u, kLast = 2u };
 //   [3] leader: waiting for the team's arrivals  [4] leader: sum of the partials, CG update, publish  [5] row start (gathers
 //   of a row that was not rolled in, iterate load)  [6] wave lifetime  [7] wave-rows
 template <int F, int WPR, int BLOCK, typename ST, bool STATS = false>
-__global__ __launch_bounds__(BLOCK, 4) void als_cg_qfteam_kernel(const int32_t *__restrict__ order, int first, int count,
+__global__ __launch_bounds__(BLOCK, F == 64 ? 8 : 4) void als_cg_qfteam_kernel(const int32_t *__restrict__ order, int first, int count,
                                                                  const int32_t *__restrict__ indptr,
                                                                  const int32_t *__restrict__ indices,
                                                                  const float *__restrict__ data, ST *__restrict__ X,
@@ -289,7 +289,17 @@ __global__ __launch_bounds__(BLOCK, 4) void als_cg_qfteam_kernel(const int32_t *
   unsigned *ctl = reinterpret_cast<unsigned *>(cws + (size_t)WAVES * 64);  // [TEAMS][4]  arrivals A, generation B, control words
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // IMP_TEAM_SAME_SIMD: the waves of a team are w, w + TEAMS, ... -- wave w of a workgroup sits on SIMD w mod 4, so a team of
+  // two shares ONE SIMD (and a team of four two SIMDs) instead of spreading over WPR of them
+#ifdef IMP_TEAM_SAME_SIMD
+  const int team = wave % TEAMS, sub = wave / TEAMS;
+  constexpr int kMemberStride = TEAMS;
+  const int first_member = team;
+#else
   const int team = wave / WPR, sub = wave % WPR;
+  constexpr int kMemberStride = 1;
+  const int first_member = team * WPR;
+#endif
   const bool leader = sub == 0;
   for (int e = threadIdx.x; e < F * F; e += BLOCK) A0s[e] = A0[e];
   if (threadIdx.x < 4 * TEAMS) ctl[threadIdx.x] = 0u;
@@ -357,16 +367,16 @@ __global__ __launch_bounds__(BLOCK, 4) void als_cg_qfteam_kernel(const int32_t *
     }
     if constexpr (IMP_TEAM_LEADER_PRIO > 0) __builtin_amdgcn_s_setprio(IMP_TEAM_LEADER_PRIO);
     tick(3);
-    const float *slot = reinterpret_cast<const float *>(reinterpret_cast<const char *>(parts + (size_t)(team * WPR) * F) + cf4);
+    const float *slot = reinterpret_cast<const float *>(reinterpret_cast<const char *>(parts + (size_t)first_member * F) + cf4);
 #pragma unroll
     for (int c = 0; c < FC; ++c) acc[c] = 0.f;
 #pragma unroll
     for (int w = 0; w < WPR; ++w) {
       if constexpr (FC == 2) {
-        const float2 t = *reinterpret_cast<const float2 *>(slot + (size_t)w * F);
+        const float2 t = *reinterpret_cast<const float2 *>(slot + (size_t)w * kMemberStride * F);
         acc[0] += t.x, acc[1] += t.y;
       } else {
-        acc[0] += slot[(size_t)w * F];
+        acc[0] += slot[(size_t)w * kMemberStride * F];
       }
     }
   };
@@ -391,6 +401,23 @@ __global__ __launch_bounds__(BLOCK, 4) void als_cg_qfteam_kernel(const int32_t *
   const int i_step = gridDim.x * TEAMS, i_first = blockIdx.x * TEAMS + team;
   auto slice = [&](int rb, int re, int &k0, int &cnt) {  // even shares rounded up to whole 4-entry tile steps
     const int chunk = min(T, (((re - rb) + WPR - 1) / WPR + 3) & ~3);
+#if defined(IMP_LEADER_LIGHT)
+    // the leader also carries the CG update between the passes: it takes IMP_LEADER_LIGHT entries less (as far as the other
+    // waves' tiles have room), the rest is dealt evenly to the other waves
+    if constexpr (WPR > 1) {
+      const int len = re - rb;
+      const int shift = min(IMP_LEADER_LIGHT, T - chunk);
+      const int cnt_l = max(0, min(chunk - shift, len));
+      if (sub == 0) {
+        k0 = rb, cnt = cnt_l;
+      } else {
+        const int chunk_o = min(T, (((len - cnt_l) + WPR - 2) / (WPR - 1) + 3) & ~3);
+        k0 = min(rb + cnt_l + chunk_o * (sub - 1), re);
+        cnt = min(chunk_o, re - k0);
+      }
+      return;
+    }
+#endif
     k0 = min(rb + chunk * sub, re);
     cnt = min(chunk, re - k0);
   };

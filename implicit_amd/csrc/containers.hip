@@ -526,6 +526,20 @@ int imp_matrix_from_host(imp_matrix *m, const void *host_in) {
   });
 }
 
+int imp_matrix_copy_rows(imp_matrix *dst, size_t dst_row, const imp_matrix *src, size_t src_row, size_t rows) {
+  return guarded([&] {
+    if (dst->cols != src->cols || dst->itemsize != src->itemsize)
+      throw std::invalid_argument("copy_rows: the two matrices must have rows of the same width and itemsize");
+    if (dst_row + rows > dst->rows || src_row + rows > src->rows) throw imp::out_of_range_error("copy_rows: row range out of bounds");
+    const size_t row_bytes = dst->cols * dst->itemsize;
+    if (rows && row_bytes)
+      IMP_CHECK_HIP(hipMemcpyAsync(static_cast<char *>(dst->data) + dst_row * row_bytes,
+                                   static_cast<const char *>(src->data) + src_row * row_bytes, rows * row_bytes,
+                                   hipMemcpyDeviceToDevice, stream()));
+    sync_call();  // queue-only in deferred mode, like the exchange it stands in for
+  });
+}
+
 int imp_matrix_shape(const imp_matrix *m, size_t *rows, size_t *cols, size_t *itemsize) {
   return guarded([&] {
     if (rows) *rows = m->rows;

@@ -202,6 +202,11 @@ class Matrix:
             raise ValueError("shape/dtype mismatch in Matrix.copy_from_numpy")
         check(lib().imp_matrix_from_host(self._h, _vp(X)))
 
+    def copy_rows_from(self, dst_row, other, src_row, rows):
+        """NEW: device-to-device copy of whole rows other[src_row : src_row + rows] -> self[dst_row : ...] on the library
+        stream (the exchange between logical ranks sharing one device, local_comm.py)."""
+        check(lib().imp_matrix_copy_rows(self._h, int(dst_row), other._h, int(src_row), int(rows)))
+
     def __repr__(self):
         return f"Matrix({str(self.to_numpy())})"
 
@@ -396,6 +401,12 @@ class Comm:
 
 def set_device(device):
     check(lib().imp_set_device(int(device)))
+
+
+def get_device():
+    d = ctypes.c_int(0)
+    check(lib().imp_get_device(ctypes.byref(d)))
+    return d.value
 
 
 def set_oversubscribe(factor):

@@ -39,6 +39,7 @@ _SIGNATURES = {
     "imp_matrix_calculate_norms": [ctypes.c_void_p, c_void_pp],
     "imp_matrix_to_host": [ctypes.c_void_p, ctypes.c_void_p],
     "imp_matrix_from_host": [ctypes.c_void_p, ctypes.c_void_p],
+    "imp_matrix_copy_rows": [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t],
     "imp_matrix_shape": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t),
                          ctypes.POINTER(ctypes.c_size_t)],
     "imp_matrix_device_ptr": [ctypes.c_void_p, c_void_pp],

@@ -143,18 +143,21 @@ class AlternatingLeastSquares(MatrixFactorizationBase):
         if self.dtype != np.float32:
             raise ValueError("the multi-GPU fit keeps float32 factor replicas")
         backend = sharded.GpuBackend(gpu, solver=self.solver, nranks=self.comm.nranks)
-        sizes = np.zeros(self.comm.nranks, dtype=np.int64)
-        sizes[self.comm.rank] = Cui_rows.shape[0]
-        users = int(sharded.allreduce_ints(self.comm, backend, sizes).sum())
-        self._initial_factors(users, Cui_rows.shape[1])
-        # every rank must start from the same factors whatever its random_state: rank 0's win (the others contribute
-        # zeros to a sum all-reduce)
-        for m in (self.user_factors, self.item_factors):
-            if self.comm.rank != 0:
-                m.copy_from_numpy(np.zeros(m.shape, dtype=np.float32))
-            self.comm.allreduce_sum(m)
-        u_off, _ = sharded.fit_sharded(self, Cui_rows, self.comm, callback or self.fit_callback, backend=backend,
-                                       csr=gpu.CSRMatrix)
+        try:  # whatever fails below, the device gets its launch shape and synchronous calls back (backend.close)
+            sizes = np.zeros(self.comm.nranks, dtype=np.int64)
+            sizes[self.comm.rank] = Cui_rows.shape[0]
+            users = int(sharded.allreduce_ints(self.comm, backend, sizes).sum())
+            self._initial_factors(users, Cui_rows.shape[1])
+            # every rank must start from the same factors whatever its random_state: rank 0's win (the others contribute
+            # zeros to a sum all-reduce)
+            for m in (self.user_factors, self.item_factors):
+                if self.comm.rank != 0:
+                    m.copy_from_numpy(np.zeros(m.shape, dtype=np.float32))
+                self.comm.allreduce_sum(m)
+            u_off, _ = sharded.fit_sharded(self, Cui_rows, self.comm, callback or self.fit_callback, backend=backend,
+                                           csr=gpu.CSRMatrix, users=users)
+        finally:
+            backend.close()
         if self.calculate_training_loss:
             # the objective restricted to this rank's user rows (each rank logs its own; there is no global reduction)
             r = self.comm.rank

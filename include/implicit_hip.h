@@ -102,6 +102,10 @@ int imp_matrix_calculate_norms(const imp_matrix *m, imp_matrix **out);
 int imp_matrix_to_host(const imp_matrix *m, void *host_out);
 /* NEW: overwrite the matrix from host memory (same shape/itemsize); used to re-seed parity runs. */
 int imp_matrix_from_host(imp_matrix *m, const void *host_in);
+/* NEW: device-to-device copy of `rows` whole rows, src[src_row ..] -> dst[dst_row ..] (same width and itemsize), queued on
+ * the library stream (queue-only in deferred mode).  What an exchange between LOGICAL ranks that share one device is made
+ * of (implicit_amd/gpu/local_comm.py: the N-rank driver exercised on one GPU). */
+int imp_matrix_copy_rows(imp_matrix *dst, size_t dst_row, const imp_matrix *src, size_t src_row, size_t rows);
 int imp_matrix_shape(const imp_matrix *m, size_t *rows, size_t *cols, size_t *itemsize);
 int imp_matrix_device_ptr(const imp_matrix *m, void **ptr);
 int imp_matrix_destroy(imp_matrix *m);
