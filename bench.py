@@ -398,6 +398,7 @@ def main():
         out["extras_note"] = ("secondary measurements on the other BASELINE configs (synthetic, inputs resident, HIP-event / "
                               "wall times of 3 iterations after 1 warm-up); `value` above is configs[2] only")
         for name, fn in (("fit_c3", lambda: extra_fit(gpu, Cui)), ("fp16_c3", lambda: extra_fp16(gpu, Cui, Ciu, X0, Y0)),
+                         ("factor_grid", lambda: extra_factor_grid(gpu, Cui, Ciu)),
                          ("c2", lambda: extra_c2(gpu, SHAPES)),
                          ("c5", lambda: extra_c5(gpu, SHAPES)), ("c4", lambda: extra_c4(gpu, SHAPES))):
             t0 = time.time()
@@ -497,6 +498,36 @@ def _fold_in_latency(gpu, Cui, X0, Y0, batch):
         gpu.synchronize()
         out[f"recalculate_user_{n}_rows_ms"] = 1e3 * (time.perf_counter() - t0) / reps
     out["note"] = "host CSR slice upload + one solver call per batch; Cholesky fold-in for factors <= 160, else CG run to f steps"
+    return out
+
+
+def extra_factor_grid(gpu, Cui, Ciu):
+    """The reference's published factor grid (benchmarks/README.md:29-32,51-58: factors 32 / 64 / 128 / 192 / 256 on last.fm-360K)
+    on the configs[2] matrix, CG cg_steps = 3, fp32: one object per factor count, each with its roofline."""
+    out = {}
+    rows = Cui.shape[0] + Cui.shape[1]
+    Cd, Ctd = gpu.CSRMatrix(Cui), gpu.CSRMatrix(Ciu)
+    solver = gpu.LeastSquaresSolver()
+    rng = np.random.default_rng(7)
+    for f in (32, 64, 192, 256):
+        X = gpu.Matrix(rng.random((Cui.shape[0], f), dtype=np.float32) * 0.01)
+        Y = gpu.Matrix(rng.random((Cui.shape[1], f), dtype=np.float32) * 0.01)
+        gram = gpu.Matrix.zeros(f, f)
+
+        def cg():
+            solver.calculate_yty(Y, gram, REG)
+            solver.least_squares(Cd, X, gram, Y, CG_STEPS)
+            solver.calculate_yty(X, gram, REG)
+            solver.least_squares(Ctd, Y, gram, X, CG_STEPS)
+
+        t, kernels = _time_iterations(gpu, cg)
+        gb = _iteration_bytes(Cui, Ciu, f) / 1e9
+        out[f"cg_c3_f{f}"] = {"workload": f"configs[2] matrix, factors={f}, CG cg_steps={CG_STEPS}", "ms_per_iter": 1e3 * t,
+                              "updates_per_s": rows / t,
+                              "roofline": {"bound": "hbm", "achieved": gb / t, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": gb / t / HBM_PEAK_GBS, "algorithmic_GB_per_iter": gb},
+                              "kernels_ms_per_iter": kernels}
+        del X, Y, gram
     return out
 
 

@@ -715,7 +715,8 @@ static void least_squares_cg_padded(const imp_csr *C, imp_matrix *X, const imp_m
     IMP_CHECK_HIP(hipGetLastError());
   }
   if (F == 64) launch_all<1, true, true, float>(C, c.pad_x.data(), c.pad_y.data(), c.pad_gram.data(), F, cg_steps);
-  else launch_all<2, true, true, float>(C, c.pad_x.data(), c.pad_y.data(), c.pad_gram.data(), F, cg_steps);
+  else if (F == 128) launch_all<2, true, true, float>(C, c.pad_x.data(), c.pad_y.data(), c.pad_gram.data(), F, cg_steps);
+  else launch_all<4, true, false, float>(C, c.pad_x.data(), c.pad_y.data(), c.pad_gram.data(), F, cg_steps);
   {
     IMP_PROF("unpad_factors");
     if (rx) unpad_rows_kernel<<<grid(rx * f), 256, 0, stream()>>>(c.pad_x.data(), X->f32(), rx, f, F);
@@ -740,8 +741,8 @@ void least_squares_cg(const imp_csr *C, imp_matrix *X, const imp_matrix *YtY, co
   const float *y = Y->f32();
   // IMP_NO_PAD=1: factor counts other than 64 / 128 on the generic kernels (A/B, parity)
   static const bool no_pad = getenv("IMP_NO_PAD") != nullptr;
-  if (!no_pad && f < 128 && f != 64 && f >= 1) {
-    least_squares_cg_padded(C, X, YtY, Y, cg_steps, f < 64 ? 64 : 128);
+  if (!no_pad && f < 256 && f != 64 && f != 128 && f >= 1) {  // 129 .. 255 (the reference publishes f = 192) ride the f = 256 kernels
+    least_squares_cg_padded(C, X, YtY, Y, cg_steps, f < 64 ? 64 : (f < 128 ? 128 : 256));
     return;
   }
   if (f == 64) launch_all<1, true, true, float>(C, x, y, a0, f, cg_steps);
@@ -753,7 +754,9 @@ void least_squares_cg(const imp_csr *C, imp_matrix *X, const imp_matrix *YtY, co
   else if (f < 256) launch_all<4, false, false, float>(C, x, y, a0, f, cg_steps);
   else if (f <= 384) launch_all<6, false, false, float>(C, x, y, a0, f, cg_steps);
   else if (f <= 512) launch_all<8, false, false, float>(C, x, y, a0, f, cg_steps);
-  else throw std::invalid_argument("least_squares: factors must be <= 512 in this build");
+  else if (f <= 768) launch_all<12, false, false, float>(C, x, y, a0, f, cg_steps);
+  else if (f <= 1024) launch_all<16, false, false, float>(C, x, y, a0, f, cg_steps);  // the reference's limit: one thread per factor, als.cu:177-179
+  else throw std::invalid_argument("least_squares: factors must be <= 1024 (as the reference, implicit/gpu/als.cu:177-182)");
 }
 
 }  // namespace imp

@@ -106,7 +106,7 @@ template <typename Fn> static void for_each_part(const imp_csr *C, const imp_mat
 
 float calculate_loss(const imp_csr *C, const imp_matrix *X, const imp_matrix *Y, float reg) {
   const int f = (int)X->cols;
-  if (f > 512) throw std::invalid_argument("calculate_loss: factors must be <= 512 in this build");
+  if (f > 1024) throw std::invalid_argument("calculate_loss: factors must be <= 1024 (as the reference, implicit/gpu/als.cu:262-264)");
   auto &lossb = ctx().loss_buf;
   if (lossb.size < 4) lossb.alloc(4);
   double *g_loss_buf = lossb.data();
@@ -123,7 +123,9 @@ float calculate_loss(const imp_csr *C, const imp_matrix *X, const imp_matrix *Y,
         case 2: launch_loss<2>(part, x->f32(), Y->f32(), yty.data(), f, g_loss_buf); break;
         case 3: launch_loss<3>(part, x->f32(), Y->f32(), yty.data(), f, g_loss_buf); break;
         case 4: launch_loss<4>(part, x->f32(), Y->f32(), yty.data(), f, g_loss_buf); break;
-        default: launch_loss<8>(part, x->f32(), Y->f32(), yty.data(), f, g_loss_buf); break;
+        case 5: case 6: case 7: case 8: launch_loss<8>(part, x->f32(), Y->f32(), yty.data(), f, g_loss_buf); break;
+        case 9: case 10: case 11: case 12: launch_loss<12>(part, x->f32(), Y->f32(), yty.data(), f, g_loss_buf); break;
+        default: launch_loss<16>(part, x->f32(), Y->f32(), yty.data(), f, g_loss_buf); break;
       }
       IMP_CHECK_HIP(hipGetLastError());
     });

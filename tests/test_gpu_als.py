@@ -209,3 +209,37 @@ def test_other_factor_counts_ride_the_resident_kernels(gpu, oracle):
         print(f"f={f} padded route rel={err:.2e}")
         assert err < TOL
         np.testing.assert_array_equal(got[C.shape[0]:], X0[C.shape[0]:])
+
+
+@pytest.mark.parametrize("f", [192, 320, 640, 1024])
+def test_reference_factor_grid_beyond_128(gpu, oracle, f):
+    """The reference's kernels take any factor count up to 1024 (one thread per factor, implicit/gpu/als.cu:177-182) and its
+    benchmarks publish f = 192 (benchmarks/README.md:31,35).  129..255 ride the f = 256 kernels zero-padded, larger counts the
+    lane-strided kernels; rows of every class (beyond 512 and 4096 nonzeros too), gramian and loss at the same f."""
+    C = synthetic_csr(400, 9_000, 160_000 if f <= 320 else 60_000, seed=37, neg_frac=0.04, empty_frac=0.02, sigma=2.0)
+    assert np.diff(C.indptr).max() > (4096 if f <= 320 else 512)
+    rng = np.random.default_rng(f)
+    X0 = rng.random((C.shape[0], f), dtype=np.float32) * 0.2 - 0.1
+    Y0 = rng.random((C.shape[1], f), dtype=np.float32) * 0.2 - 0.1
+    Xd, Yd, gram = gpu.Matrix(X0), gpu.Matrix(Y0), gpu.Matrix.zeros(f, f)
+    solver = gpu.LeastSquaresSolver()
+    solver.calculate_yty(Yd, gram, 0.05)
+    want_gram = oracle.gramian(Y0) + np.float32(0.05) * np.eye(f, dtype=np.float32)
+    assert rel(gram.to_numpy(), want_gram) < 1e-6
+    Cd = gpu.CSRMatrix(C)
+    solver.least_squares(Cd, Xd, gram, Yd, 3)
+    want = X0.copy()
+    oracle.least_squares_cg(C, want, Y0, 0.05, cg_steps=3, YtY=gram.to_numpy())
+    err = rel(Xd.to_numpy(), want)
+    print(f"f={f} rel={err:.2e}")
+    assert err < TOL
+    loss = solver.calculate_loss(Cd, Xd, Yd, 0.05)
+    assert loss == pytest.approx(oracle.calculate_loss(C, Xd.to_numpy(), Y0, 0.05), rel=1e-4)
+
+
+def test_more_than_1024_factors_is_an_error_like_the_reference(gpu):
+    C = synthetic_csr(10, 10, 30, seed=1)
+    f = 1025
+    X, Y, gram = gpu.Matrix.zeros(10, f), gpu.Matrix.zeros(10, f), gpu.Matrix.zeros(f, f)
+    with pytest.raises(ValueError):
+        gpu.LeastSquaresSolver().least_squares(gpu.CSRMatrix(C), X, gram, Y, 3)
