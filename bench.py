@@ -121,6 +121,19 @@ def pmc_traffic_per_half_sweep(cg_steps):
     return out, os.path.basename(files[-1])
 
 
+def _pmc_kernel_traffic(kernel_substr):
+    """HBM read bytes per dispatch of one kernel from the newest committed PMC summary (None if it is not there)."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    if not files:
+        return None
+    for kname, d in json.load(open(files[-1])).items():
+        if kernel_substr in kname and "hbm_read_bytes_per_dispatch_corrected" in d:
+            return d["hbm_read_bytes_per_dispatch_corrected"] + d.get("hbm_write_bytes_per_dispatch", 0.0)
+    return None
+
+
 def cpu_baseline(Cui, Ciu, X0, Y0, seconds):
     """Times the reference CPU solver (oracle/_ref, else the plain-C port) on a bounded row sample."""
     from oracle import oracle as port
@@ -764,7 +777,9 @@ def bench_topk(gpu, Cui, X, Y, k=10, queries=20_000, batch=1000):
         peak = BF16_PEAK_TFLOPS / 6.0 if split else FP32_PEAK_TFLOPS
         roofline = {"bound": "mfma", "kernel": "score_gemm_direct_kernel<2> (emit epilogue)", "achieved": tf, "peak": peak,
                     "unit": "TFLOP/s", "frac": tf / peak, "avg_launch_ms": gemm_ms,
-                    "flops_per_launch": per_batch_flops, "traffic": None,
+                    "flops_per_launch": per_batch_flops, "traffic": _pmc_kernel_traffic("score_gemm_direct_kernel<2"),
+                    "traffic_note": "HBM bytes per launch of the emit GEMM from the committed rocprofv3 PMC summary "
+                                    "(FETCH_SIZE corrected for gfx950); algorithmic operand bytes = items x f x 4 once per launch",
                     "note": ("fp32-equivalent flops (2 x batch x items x f per launch); the product runs as 6 bf16 partial products "
                              "of three-way split operands on v_mfma_f32_32x32x16_bf16 (fp32 accumulation, error below an fp32 FMA "
                              "chain's): peak = 2500 TFLOP/s dense bf16 / 6") if split else

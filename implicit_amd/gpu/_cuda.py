@@ -65,6 +65,22 @@ class KnnQuery:
             item_filter._h if item_filter is not None else None))
         return indices, distances
 
+    def topk_device(self, items, m, k, item_norms=None, query_filter=None, item_filter=None):
+        """NEW: the same call with DEVICE output buffers (knn.cu:40-54,147-164 detects where its output pointers live): returns
+        (ids, distances) as two rows x k device Matrix objects; the ids are int32 bit patterns in a 4-byte-per-element
+        matrix (`ids.to_numpy().view(np.int32)`).  For callers that keep post-processing on the device."""
+        if not isinstance(items, Matrix) or not isinstance(m, Matrix):
+            raise TypeError("KnnQuery.topk expects implicit.gpu.Matrix arguments")
+        k = int(k)
+        rows = m.shape[0]
+        ids, dist = Matrix.zeros(rows, k), Matrix.zeros(rows, k)
+        check(lib().imp_knn_topk(
+            self._h, items._h, m._h, k, ctypes.c_void_p(ids.device_ptr), ctypes.c_void_p(dist.device_ptr),
+            item_norms._h if item_norms is not None else None,
+            query_filter._h if query_filter is not None else None,
+            item_filter._h if item_filter is not None else None))
+        return ids, dist
+
     def __del__(self):
         if getattr(self, "_h", None):
             lib().imp_knn_destroy(self._h)
@@ -288,6 +304,19 @@ class COOMatrix:
         self.shape = X.shape
         check(lib().imp_coo_create(X.shape[0], X.shape[1], len(data), _vp(row), _vp(col), _vp(data),
                                    ctypes.byref(self._h)))
+
+    @classmethod
+    def from_csr_pattern(cls, X):
+        """NEW: the (row, col) pattern of a scipy CSR matrix as a device COO without its values -- all the top-k filters read
+        (knn.cu:197-214 reads row / col only).  Skips scipy's tocoo() and the value upload: recommend() builds one per batch."""
+        self = cls.__new__(cls)
+        indptr = np.asarray(X.indptr)
+        col = np.ascontiguousarray(X.indices, dtype=np.int32)
+        row = np.repeat(np.arange(X.shape[0], dtype=np.int32), np.diff(indptr))
+        self._h = ctypes.c_void_p()
+        self.shape = X.shape
+        check(lib().imp_coo_create(X.shape[0], X.shape[1], len(col), _vp(row), _vp(col), None, ctypes.byref(self._h)))
+        return self
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -40,7 +40,16 @@ class MatrixFactorizationBase(RecommenderBase):
             if user_items.shape[0] != (1 if scalar else len(userid)):
                 raise ValueError("user_items must contain 1 row for every user in userids")
 
-        query = self.recalculate_user(userid, user_items) if recalculate_user else self.user_factors[userid]
+        if recalculate_user:
+            query = self.recalculate_user(userid, user_items)
+        elif not scalar and len(userid) > 1 and isinstance(userid, np.ndarray) and userid.dtype.kind in "iu" and \
+                userid[0] >= 0 and userid[-1] - userid[0] == len(userid) - 1 and (np.diff(userid) == 1).all():
+            # a run of consecutive ids (what batched callers pass): a row-range VIEW of the factors, no gather
+            if userid[-1] >= self.user_factors.shape[0]:
+                raise IndexError("row id out of range for selecting items from matrix")
+            query = self.user_factors[int(userid[0]):int(userid[-1]) + 1]
+        else:
+            query = self.user_factors[userid]
 
         candidates = self.item_factors
         if items is not None:
@@ -60,7 +69,7 @@ class MatrixFactorizationBase(RecommenderBase):
         if filter_already_liked_items:
             liked = user_items if items is None else _filter_items_from_sparse_matrix(items, user_items)
             if liked.nnz:
-                query_filter = gpu.COOMatrix(liked.tocoo())
+                query_filter = gpu.COOMatrix.from_csr_pattern(liked)  # the filter reads (row, col) only
 
         ids, scores = self.knn.topk(candidates, query, N, query_filter=query_filter, item_filter=item_filter)
         if scalar:

@@ -281,6 +281,50 @@ def fit_sharded(model, Cui_rows, comm, callback=None, chunks=None, backend=None,
     return u_off, i_off
 
 
+# ---- inference on N GPUs: queries shard trivially (SURVEY section 8e) -----------------------------------------------------
+#
+# After fit_sharded every rank holds the full user and item factors, so recommend / similar_items need no exchange at all:
+# the batch of queries is cut into contiguous slices, one per rank, each rank scores ITS slice against its replica of the
+# item factors with the single-GPU scorer (KnnQuery.topk, knn.cu:131-265 semantics) and returns the slice's bounds with the
+# results; whoever needs the whole batch concatenates the slices in rank order (they are row-independent, so the result is
+# the one-GPU call's bit for bit).  Same arguments as the model's own methods (gpu/matrix_factorization_base.py:34-101).
+
+
+def query_slice(n_queries, comm):
+    """[lo, hi) of this rank's share of a batch of `n_queries` (contiguous, sizes differing by at most one)."""
+    offs = shard_offsets(int(n_queries), comm.nranks)
+    return int(offs[comm.rank]), int(offs[comm.rank + 1])
+
+
+def recommend(model, comm, userids, user_items, N=10, **kwargs):
+    """This rank's slice of model.recommend(userids, user_items, N, ...): returns (lo, hi, ids, scores) with ids / scores of
+    userids[lo:hi].  `user_items` has one row per entry of `userids` (as the model's method wants it) or is None when neither
+    filter_already_liked_items nor recalculate_user needs it."""
+    userids = np.asarray(userids)
+    if userids.ndim != 1:
+        raise ValueError("the sharded recommend takes a batch (1-d array) of user ids")
+    if user_items is not None and user_items.shape[0] != len(userids):
+        raise ValueError("user_items must contain 1 row for every user in userids")
+    lo, hi = query_slice(len(userids), comm)
+    if hi == lo:
+        return lo, hi, np.zeros((0, N), dtype=np.int32), np.zeros((0, N), dtype=np.float32)
+    rows = user_items[lo:hi] if user_items is not None else None
+    ids, scores = model.recommend(userids[lo:hi], rows, N=N, **kwargs)
+    return lo, hi, ids, scores
+
+
+def similar_items(model, comm, itemids, N=10, **kwargs):
+    """This rank's slice of model.similar_items(itemids, N, ...): (lo, hi, ids, scores)."""
+    itemids = np.asarray(itemids)
+    if itemids.ndim != 1:
+        raise ValueError("the sharded similar_items takes a batch (1-d array) of item ids")
+    lo, hi = query_slice(len(itemids), comm)
+    if hi == lo:
+        return lo, hi, np.zeros((0, N), dtype=np.int32), np.zeros((0, N), dtype=np.float32)
+    ids, scores = model.similar_items(itemids[lo:hi], N=N, **kwargs)
+    return lo, hi, ids, scores
+
+
 # ---- synthetic workloads + benchmark driver (bench.py --gpus N) -------------------------------------------------------
 
 

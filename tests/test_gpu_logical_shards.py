@@ -111,3 +111,39 @@ def test_copy_rows_checks_its_arguments(gpu):
         b.copy_rows_from(4, a, 0, 3)
     with pytest.raises(ValueError):
         b.copy_rows_from(0, gpu.Matrix.zeros(3, 5), 0, 1)
+
+
+def test_sharded_recommend_and_similar_items_on_logical_ranks(gpu, unsharded):
+    """Inference on N ranks: queries cut into contiguous slices, replicated factors, no collective
+    (`sharded.recommend` / `sharded.similar_items`); the slices of 8 logical ranks concatenated are the one-GPU call's
+    result bit for bit -- liked-items filter, an item filter and a ragged query count included."""
+    from implicit_amd.als import AlternatingLeastSquares
+    from implicit_amd.gpu import local_comm, sharded
+
+    _, _, X2, Y2 = unsharded
+    C = sp.vstack([grid_shards(r, GRID, USERS, ITEMS, NNZ, GRID, gamma=2.0, seed=11)[0] for r in range(GRID)]).tocsr()
+    users = np.arange(5, USERS, 23)[:1003]  # 1003 queries over 8 ranks: 126 / 125 per rank
+    liked = C[users]
+    banned = [0, 1, 2, 17]
+
+    def build():
+        m = AlternatingLeastSquares(factors=F, use_gpu=True)
+        m.user_factors, m.item_factors = gpu.Matrix(X2), gpu.Matrix(Y2)
+        return m
+
+    one = build()
+    want = one.recommend(users, liked, N=10, filter_items=banned)
+    want_sim = one.similar_items(np.arange(0, ITEMS, 3), N=20)
+
+    def rank_body(comm):
+        model = build()  # every rank its own replica of the factors, as after fit_sharded
+        return (sharded.recommend(model, comm, users, liked, N=10, filter_items=banned),
+                sharded.similar_items(model, comm, np.arange(0, ITEMS, 3), N=20))
+
+    out = local_comm.run(8, rank_body, gpu=gpu, oversubscribe=0)
+    rec, sim = [o[0] for o in out], [o[1] for o in out]
+    assert [r[0] for r in rec[1:]] == [r[1] for r in rec[:-1]] and rec[0][0] == 0 and rec[-1][1] == len(users)
+    np.testing.assert_array_equal(np.vstack([r[2] for r in rec]), want[0])
+    np.testing.assert_array_equal(np.vstack([r[3] for r in rec]), want[1])
+    np.testing.assert_array_equal(np.vstack([s[2] for s in sim]), want_sim[0])
+    np.testing.assert_array_equal(np.vstack([s[3] for s in sim]), want_sim[1])

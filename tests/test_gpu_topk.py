@@ -252,3 +252,25 @@ def test_emit_path_over_several_query_batches(gpu, oracle, dtype):
     ok = ~_near_tie_rows(want_d, f)
     assert ok.mean() > 0.9
     assert_array_equal(ids[ok], want_ids[ok])
+
+
+@pytest.mark.parametrize("shape", [(20_000, 64, 300, 10), (3_000, 40, 70, 100), (40_000, 128, 1500, 10)])
+def test_device_output_pointers(gpu, shape):
+    """imp_knn_topk writes into DEVICE buffers when the caller passes device pointers (the reference detects where its output
+    pointers live, knn.cu:40-54,147-164): every path -- emit (sparse candidate lists), materialising (k = 100 over a small
+    catalogue), several query batches, with the liked-items filter -- must return what the host-pointer call returns."""
+    ni, f, nq, k = shape
+    rng = np.random.default_rng(ni)
+    items = rng.standard_normal((ni, f)).astype(np.float32)
+    queries = rng.standard_normal((nq, f)).astype(np.float32)
+    liked = sp.random(nq, ni, density=20.0 / ni, format="csr", random_state=3, dtype=np.float32)
+    knn = gpu.KnnQuery(max_temp_memory=50_000_000 if nq > 1000 else 0)
+    I, Q = gpu.Matrix(items), gpu.Matrix(queries)
+    for flt in (None, gpu.COOMatrix(liked.tocoo()), gpu.COOMatrix.from_csr_pattern(liked)):
+        want_ids, want_d = knn.topk(I, Q, k, query_filter=flt)
+        ids_d, dist_d = knn.topk_device(I, Q, k, query_filter=flt)
+        assert_array_equal(ids_d.to_numpy().view(np.int32), want_ids)
+        assert_array_equal(dist_d.to_numpy(), want_d)
+        if flt is not None:  # nothing a user already liked comes back
+            hit = [np.intersect1d(want_ids[r], liked.indices[liked.indptr[r]:liked.indptr[r + 1]]).size for r in range(nq)]
+            assert not any(hit)

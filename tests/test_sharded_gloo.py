@@ -294,3 +294,73 @@ def test_shard_offsets_balance_by_weight():
     assert abs(left - right) <= 100
     offs = shard_offsets(3, 8)  # more ranks than rows: empty shards are legal
     assert offs[0] == 0 and offs[-1] == 3 and (np.diff(offs) >= 0).all()
+
+
+# ---- sharded inference: queries split over the ranks, no collective ------------------------------------------------------
+
+
+class _OracleModel:
+    """recommend / similar_items of the reference's model layer on the oracle's top-k (the product's model needs a GPU)."""
+
+    def __init__(self, oracle, X, Y):
+        self.o, self.X, self.Y = oracle, X, Y
+
+    def recommend(self, userid, user_items, N=10, filter_already_liked_items=True):
+        return self.o.topk(self.Y, self.X[userid], N, filter_query_items=user_items if filter_already_liked_items else None)
+
+    def similar_items(self, itemid, N=10):
+        norms = np.linalg.norm(self.Y, axis=1).astype(np.float32)
+        ids, d = self.o.topk(self.Y, self.Y[itemid], N, item_norms=norms)
+        return ids, d / norms[itemid][:, None]
+
+
+def _recommend_problem():
+    from implicit_amd.synthetic import synthetic_csr
+
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((300, 24)).astype(np.float32)
+    Y = rng.standard_normal((500, 24)).astype(np.float32)
+    C = synthetic_csr(300, 500, 6000, seed=4)
+    users = np.arange(3, 300, 7)   # 43 queries: the two ranks get 22 and 21
+    return X, Y, C, users
+
+
+def _worker_recommend(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from implicit_amd.gpu import sharded
+    from oracle import oracle
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    X, Y, C, users = _recommend_problem()
+    comm = GlooComm(dist, torch)
+    model = _OracleModel(oracle, X, Y)
+    lo, hi, ids, scores = sharded.recommend(model, comm, users, C[users], N=7)
+    slo, shi, sids, sscores = sharded.similar_items(model, comm, np.arange(0, 500, 11), N=5)
+    elo, ehi, eids, _ = sharded.recommend(model, comm, users[:1], C[users[:1]], N=7)  # fewer queries than ranks
+    np.savez(os.path.join(out_dir, f"rec_rank{rank}.npz"), lo=lo, hi=hi, ids=ids, scores=scores, slo=slo, shi=shi, sids=sids,
+             sscores=sscores, elo=elo, ehi=ehi, eids=eids)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_recommend_is_the_single_process_result_cut_in_two(tmp_path, oracle):
+    import torch.multiprocessing as mp
+
+    world = 2
+    mp.spawn(_worker_recommend, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"rec_rank{k}.npz") for k in range(world)]
+    X, Y, C, users = _recommend_problem()
+    model = _OracleModel(oracle, X, Y)
+    want_ids, want_scores = model.recommend(users, C[users], N=7)
+    assert (int(r[0]["lo"]), int(r[0]["hi"]), int(r[1]["lo"]), int(r[1]["hi"])) == (0, 22, 22, 43)
+    np.testing.assert_array_equal(np.vstack([r[0]["ids"], r[1]["ids"]]), want_ids)
+    np.testing.assert_array_equal(np.vstack([r[0]["scores"], r[1]["scores"]]), want_scores)
+    want_sids, want_ss = model.similar_items(np.arange(0, 500, 11), N=5)
+    np.testing.assert_array_equal(np.vstack([r[0]["sids"], r[1]["sids"]]), want_sids)
+    np.testing.assert_array_equal(np.vstack([r[0]["sscores"], r[1]["sscores"]]), want_ss)
+    # one query, two ranks: rank 0 answers, rank 1 returns an empty slice of the right shape
+    assert (int(r[0]["elo"]), int(r[0]["ehi"]), int(r[1]["elo"]), int(r[1]["ehi"])) == (0, 1, 1, 1)
+    assert r[0]["eids"].shape == (1, 7) and r[1]["eids"].shape == (0, 7)
