@@ -22,8 +22,16 @@
 // at most the resident capacity (2 workgroups per CU) every cluster is resident from the start; with an oversubscribed grid
 // (Context::oversub, multi-GPU driver) or with part of the device held by another stream's kernels, the slots a finished
 // cluster frees go to the next cluster as a whole, and a partly resident cluster merely waits for slots that complete
-// clusters keep freeing.  Every poll is bounded all the same (a timed-out exchange sets a host-visible fault word and the
-// call raises).
+// clusters keep freeing.  Every poll is bounded all the same, and a timed-out exchange costs time, not correctness (round 4):
+//   * a workgroup whose poll expired is FAULTED for the rest of the launch: it keeps taking part in the exchanges (so that
+//     nobody waits for it) but marks its granules as poisoned, which faults whoever reads them; a reader that finds a slot
+//     already carrying a LATER sequence number (the cluster moved on without it) faults at once;
+//   * a faulted cluster never stores an iterate: the owner of the store appends the row id to a device-side list instead, so
+//     every row is either solved completely or still holds the iterate it had;
+//   * `als_cg_fault_fixup_kernel`, queued right behind the cluster launches, re-solves the listed rows (normally none: it
+//     reads a zero and exits) by streaming them, one wavefront per row -- on the device, in stream order, so it also works in
+//     deferred mode where the host looks at nothing until the end of the iteration.  The host-visible fault word only makes
+//     the next synchronisation print a warning.
 #include <type_traits>
 
 #include "als_qtile.h"
@@ -40,6 +48,8 @@ constexpr int kClusterWaves = 8;       // wavefronts per workgroup
 // to wait for a whole share of the clusters ahead of it (and, beside a resident collective, for the slots that holds) --
 // milliseconds; 4 s is far beyond any legitimate wait and still turns a lost member into an error instead of a hang.
 constexpr long long kWaitLimitTicks = 400'000'000ll;
+// tag layout of a granule's upper word: [31:28] XCC id of the sender, [27] poison (the sender is faulted), [26:0] sequence number
+constexpr unsigned kSeqMask = 0x07FFFFFFu, kPoison = 0x08000000u;
 }  // namespace
 
 // STATS (debug, IMP_CG_STATS=1): s_memtime ticks summed over waves -- [0] row start -> tile resident  [1] passes
@@ -48,7 +58,8 @@ template <int F, int CL, bool STATS, typename ST>
 __global__ __launch_bounds__(64 * kClusterWaves, 4) void als_cg_cluster_kernel(
     const int32_t *__restrict__ order, int first, int count, const int32_t *__restrict__ indptr,
     const int32_t *__restrict__ indices, const float *__restrict__ data, ST *__restrict__ X, const ST *__restrict__ Y,
-    const float *__restrict__ A0, int cg_steps, unsigned long long *xchg, unsigned *fault, int allow_plain, unsigned long long *__restrict__ stats = nullptr) {
+    const float *__restrict__ A0, int cg_steps, unsigned long long *xchg, unsigned *fault, int allow_plain, unsigned *fault_rows,
+    int fault_capacity, long long wait_limit, int debug_drop, unsigned long long *__restrict__ stats = nullptr) {
   unsigned long long tk[4] = {0, 0, 0, 0}, t_last = 0, t_rows = 0;
   auto tick = [&](int slot) {  // charge the time since the previous tick to `slot`
     if constexpr (STATS) {
@@ -69,6 +80,7 @@ __global__ __launch_bounds__(64 * kClusterWaves, 4) void als_cg_cluster_kernel(
   float *scratch = A0s + (size_t)F * F;  // [WAVES][F]  wave partials of the combine; between combines: wave-private operand copy
   float *xb = scratch + (size_t)WAVES * F;  // [CL][F]  the cluster's workgroup partials after the exchange
   int *xflag = reinterpret_cast<int *>(xb + (size_t)CL * F);  // [CL]  tag of member m's granules in the last exchange
+  int *wg_fault = xflag + 16;                                  // [1]   set by any wave of this workgroup that faulted
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
@@ -80,6 +92,7 @@ __global__ __launch_bounds__(64 * kClusterWaves, 4) void als_cg_cluster_kernel(
   const int j_begin = (F / WD) * g;
   if (m * WAVES < WD)
     for (int e = threadIdx.x; e < F * F; e += 64 * WAVES) A0s[e] = A0[e];
+  if (threadIdx.x == 0) *wg_fault = 0;
   __syncthreads();
   float *myvec = scratch + (size_t)wave * F;
   unsigned long long *slots = xchg + (size_t)cid * 2 * CL * 64 * FC;
@@ -110,7 +123,10 @@ __global__ __launch_bounds__(64 * kClusterWaves, 4) void als_cg_cluster_kernel(
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) s += scratch[w * F + QL<F>::cfactor(ln, c)];
-        const unsigned long long granule = ((unsigned long long)(seq | xcc_tag) << 32) | (unsigned long long)__float_as_uint(s);
+        const unsigned long long granule =
+            ((unsigned long long)(seq | xcc_tag | (faulted ? kPoison : 0u)) << 32) | (unsigned long long)__float_as_uint(s);
+        // test hook (IMP_DEBUG_CLUSTER_DROP=n): member 1 of cluster 0 never publishes its n-th exchange
+        if (debug_drop > 0 && cid == 0 && m == 1 && seq == (unsigned)debug_drop) continue;
         // members on one XCD share its L2: a plain store lands there and the readers' sc1 loads (which bypass only
         // their L1) hit it; an sc1 store writes through to the fabric and drops the line, which the readers then
         // fetch at the cross-XCD latency -- required when the members sit on different XCDs, whose L2s are not coherent
@@ -123,21 +139,30 @@ __global__ __launch_bounds__(64 * kClusterWaves, 4) void als_cg_cluster_kernel(
       int spins = 0;
       long long wait_since = 0;
       while (true) {
-        bool ok = true;
+        bool ok = true, ahead = false, poisoned = false;
 #pragma unroll
         for (int k = 0; k < PER; ++k)
 #pragma unroll
           for (int c = 0; c < FC; ++c) {
             granule[k][c] = __hip_atomic_load(slot + (((wave + k * WAVES) * 64 + ln) * FC + c), __ATOMIC_RELAXED,
                                               __HIP_MEMORY_SCOPE_AGENT);
-            ok = ok && ((unsigned)(granule[k][c] >> 32) & 0x0FFFFFFFu) == seq;
+            const unsigned tag = (unsigned)(granule[k][c] >> 32);
+            ok = ok && (tag & kSeqMask) == seq;
+            ahead = ahead || (tag & kSeqMask) > seq;   // the slot already belongs to a later exchange: this one is lost
+            poisoned = poisoned || ((tag & kSeqMask) == seq && (tag & kPoison));
           }
-        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-        bool expired = false;
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) {
+          if (__builtin_amdgcn_ballot_w64(poisoned) != 0ull) {  // a faulted member took part: its partial is not to be trusted
+            if (!faulted && lane == 0) __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            faulted = true;
+          }
+          break;
+        }
+        bool expired = __builtin_amdgcn_ballot_w64(ahead) != 0ull;
         if ((++spins & 255) == 0) {  // the clock is read once per 256 polls
           const long long now = (long long)wall_clock64();
           if (wait_since == 0) wait_since = now;
-          expired = now - wait_since > kWaitLimitTicks;
+          expired = expired || now - wait_since > wait_limit;
         }
         if (faulted || expired) {  // never expected: give up instead of hanging the device
           if (!faulted && lane == 0) __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -152,8 +177,10 @@ __global__ __launch_bounds__(64 * kClusterWaves, 4) void als_cg_cluster_kernel(
         for (int c = 0; c < FC; ++c) xb[(wave + k * WAVES) * F + QL<F>::cfactor(ln, c)] = __uint_as_float((unsigned)granule[k][c]);
 #pragma unroll
       for (int k = 0; k < PER; ++k) xflag[wave + k * WAVES] = (int)(granule[k][0] >> 32);  // the tag: read by the placement check
+      if (faulted && lane == 0) *wg_fault = 1;
     }
     __syncthreads();  // B2: all CL partials in LDS; wave 0 has finished reading the wave partials
+    faulted = *wg_fault != 0;  // a fault is the whole workgroup's: its next granules carry the poison bit, its rows are not stored
 #pragma unroll
     for (int c = 0; c < FC; ++c) {
       float s = 0.f;
@@ -260,7 +287,16 @@ __global__ __launch_bounds__(64 * kClusterWaves, 4) void als_cg_cluster_kernel(
         }
       }
     }
-    if (store) store_compact<F>(xrow, lane, x);
+    if (g == 0) {  // the owner of the row's store
+      if (faulted) {  // an exchange of this row (or an earlier one) was lost: the row keeps its iterate and goes to the fix-up list
+        if (lane == 0) {
+          const unsigned at = atomicAdd(fault_rows, 1u);
+          if ((int)at < fault_capacity) fault_rows[1 + at] = (unsigned)u;
+        }
+      } else if (store) {
+        store_compact<F>(xrow, lane, x);
+      }
+    }
     tick(3);
   }
   if constexpr (STATS) {
@@ -271,12 +307,94 @@ __global__ __launch_bounds__(64 * kClusterWaves, 4) void als_cg_cluster_kernel(
   }
 }
 
+// ---- fix-up of the rows a faulted cluster left unsolved -----------------------------------------------------------------
+// One wavefront per listed row, everything streamed: lane l owns the FC = F / 64 consecutive factors FC l ..; a nonzero is one
+// coalesced row read, one wave-wide dot product, one axpy; the gramian comes from global memory (L2) row by row with the
+// operand broadcast from a wave-private LDS copy.  The oracle's CG step by step (_als.pyx:179-244); only the summation order
+// differs from the cluster kernel's.  Slow (milliseconds for a 4096-nonzero row) and never expected to have work.
+template <int F, typename ST>
+__global__ __launch_bounds__(256) void als_cg_fault_fixup_kernel(const unsigned *__restrict__ fault_rows, int capacity,
+                                                                 const int32_t *__restrict__ indptr,
+                                                                 const int32_t *__restrict__ indices,
+                                                                 const float *__restrict__ data, ST *__restrict__ X,
+                                                                 const ST *__restrict__ Y, const float *__restrict__ A0, int cg_steps) {
+  constexpr int FC = F / 64, WAVES = 4;
+  __shared__ float vecs[WAVES][F];
+  const int n = min((int)fault_rows[0], capacity);
+  if (n == 0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float *vec = vecs[wave];
+  auto load_vec = [&](const ST *row, float (&v)[FC]) {
+#pragma unroll
+    for (int c = 0; c < FC; ++c) v[c] = load1(row + FC * lane + c);
+  };
+  // acc = sign * A0 v + sum_k w_k y_k,  w_k = FIRST ? c+ - (|c|-1) y_k.v : (|c|-1) y_k.v
+  auto apply = [&](bool first, int rb, int re, const float (&v)[FC], float (&acc)[FC]) {
+#pragma unroll
+    for (int c = 0; c < FC; ++c) vec[FC * lane + c] = v[c];  // wave-private: no barrier
+#pragma unroll
+    for (int c = 0; c < FC; ++c) acc[c] = 0.f;
+    for (int j = 0; j < F; ++j) {
+      const float vj = vec[j];
+#pragma unroll
+      for (int c = 0; c < FC; ++c) acc[c] = fmaf(A0[(size_t)j * F + FC * lane + c], vj, acc[c]);
+    }
+    if (first) {
+#pragma unroll
+      for (int c = 0; c < FC; ++c) acc[c] = -acc[c];
+    }
+    for (int k = rb; k < re; ++k) {
+      const float conf = data[k];
+      float y[FC];
+      load_vec(Y + (size_t)indices[k] * F, y);
+      const float d = wave_allsum(dot_local<FC>(y, v));
+      const float cm1 = fabsf(conf) - 1.f;
+      const float w = first ? fmaxf(conf, 0.f) - cm1 * d : cm1 * d;
+#pragma unroll
+      for (int c = 0; c < FC; ++c) acc[c] = fmaf(w, y[c], acc[c]);
+    }
+  };
+  for (int i = blockIdx.x * WAVES + wave; i < n; i += gridDim.x * WAVES) {
+    const int u = (int)fault_rows[1 + i];
+    const int rb = indptr[u], re = indptr[u + 1];
+    ST *xrow = X + (size_t)u * F;
+    float x[FC], r[FC], p[FC], Ap[FC];
+    load_vec(xrow, x);
+    apply(true, rb, re, x, r);
+#pragma unroll
+    for (int c = 0; c < FC; ++c) p[c] = r[c];
+    float rsold = wave_allsum(dot_local<FC>(r, r));
+    if (rsold < 1e-20f) continue;  // x untouched (_als.pyx:206)
+    for (int it = 0; it < cg_steps; ++it) {
+      apply(false, rb, re, p, Ap);
+      const float alpha = rsold / wave_allsum(dot_local<FC>(p, Ap));
+#pragma unroll
+      for (int c = 0; c < FC; ++c) {
+        x[c] = fmaf(alpha, p[c], x[c]);
+        r[c] = fmaf(-alpha, Ap[c], r[c]);
+      }
+      const float rsnew = wave_allsum(dot_local<FC>(r, r));
+      if (rsnew < 1e-20f) break;
+      const float beta = rsnew / rsold;
+#pragma unroll
+      for (int c = 0; c < FC; ++c) p[c] = fmaf(beta, p[c], r[c]);
+      rsold = rsnew;
+    }
+#pragma unroll
+    for (int c = 0; c < FC; ++c) store1(xrow + FC * lane + c, x[c]);
+  }
+}
+
 template <int F, int CL, typename T>
 static void launch_cluster(const imp_csr *C, int first, int count, T *X, const T *Y, const float *A0, int cg_steps,
-                           unsigned long long *xchg, const char *name) {
+                           unsigned long long *xchg, unsigned *fault_rows, int fault_capacity, const char *name) {
   if (count <= 0) return;
+  // IMP_CLUSTER_WAIT_MS: how long a poll waits before it declares the exchange lost (default 4 s; tests lower it);
+  // IMP_DEBUG_CLUSTER_DROP=n: member 1 of cluster 0 withholds its n-th exchange (exercises the fault path)
+  static const long long wait_limit = getenv("IMP_CLUSTER_WAIT_MS") ? std::max(1, atoi(getenv("IMP_CLUSTER_WAIT_MS"))) * 100'000ll : kWaitLimitTicks;
+  static const int debug_drop = getenv("IMP_DEBUG_CLUSTER_DROP") ? atoi(getenv("IMP_DEBUG_CLUSTER_DROP")) : 0;
   constexpr int FC = F / 64, BLOCK = 64 * kClusterWaves;
-  const size_t lds = ((size_t)F * F + (size_t)kClusterWaves * F + (size_t)CL * F + 16) * sizeof(float);
+  const size_t lds = ((size_t)F * F + (size_t)kClusterWaves * F + (size_t)CL * F + 32) * sizeof(float);
   auto kern = als_cg_cluster_kernel<F, CL, false, T>;
   IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // co-resident workgroups: what the occupancy query admits per CU (2 by design), never more than 2; the cluster
@@ -297,7 +415,7 @@ static void launch_cluster(const imp_csr *C, int first, int count, T *X, const T
     auto skern = als_cg_cluster_kernel<F, CL, true, T>;
     IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(skern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     skern<<<grid, BLOCK, lds, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(), C->data.data(), X, Y,
-                                         A0, cg_steps, xchg, ctx().cluster_fault, allow_plain ? 1 : 0, stats);
+                                         A0, cg_steps, xchg, ctx().cluster_fault, allow_plain ? 1 : 0, fault_rows, fault_capacity, wait_limit, debug_drop, stats);
     unsigned long long h[8];
     IMP_CHECK_HIP(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, stream()));
     IMP_CHECK_HIP(hipStreamSynchronize(stream()));
@@ -308,7 +426,7 @@ static void launch_cluster(const imp_csr *C, int first, int count, T *X, const T
   }
   IMP_PROF(name);
   kern<<<grid, BLOCK, lds, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(), C->data.data(), X, Y,
-                                      A0, cg_steps, xchg, ctx().cluster_fault, allow_plain ? 1 : 0, nullptr);
+                                      A0, cg_steps, xchg, ctx().cluster_fault, allow_plain ? 1 : 0, fault_rows, fault_capacity, wait_limit, debug_drop, nullptr);
   IMP_CHECK_HIP(hipGetLastError());
 }
 
@@ -335,22 +453,38 @@ template <int F, typename T> static void run_clusters(const imp_csr *C, T *X, co
     *c.cluster_fault = 0u;
   }
   unsigned long long *xchg = c.cluster_xchg.data();
+  // fix-up list: [0] = number of rows a faulted cluster left unsolved, [1 ..] = their ids (every cluster row at most once)
+  const int capacity = (cut[3] - cut[0]) + (with16 ? b[2] - b[1] : 0);
+  if (c.cluster_fault_rows.size < (size_t)capacity + 1) c.cluster_fault_rows.alloc((size_t)capacity + 1);
+  unsigned *fault_rows = c.cluster_fault_rows.data();
   {
     IMP_PROF("als_cg_cluster_reset");
     IMP_CHECK_HIP(hipMemsetAsync(xchg, 0, 4 * per_class * sizeof(unsigned long long), stream()));
+    IMP_CHECK_HIP(hipMemsetAsync(fault_rows, 0, sizeof(unsigned), stream()));
   }
-  launch_cluster<F, 16, T>(C, cut[0], cut[1] - cut[0], X, Y, A0, cg_steps, xchg, "als_cg_cluster16_rows");
-  launch_cluster<F, 8, T>(C, cut[1], cut[2] - cut[1], X, Y, A0, cg_steps, xchg + per_class, "als_cg_cluster8_rows");
-  launch_cluster<F, 4, T>(C, cut[2], cut[3] - cut[2], X, Y, A0, cg_steps, xchg + 2 * per_class, "als_cg_cluster4_rows");
-  if (with16) launch_cluster<F, 2, T>(C, b[1], b[2] - b[1], X, Y, A0, cg_steps, xchg + 3 * per_class, "als_cg_team16_rows");
+  launch_cluster<F, 16, T>(C, cut[0], cut[1] - cut[0], X, Y, A0, cg_steps, xchg, fault_rows, capacity, "als_cg_cluster16_rows");
+  launch_cluster<F, 8, T>(C, cut[1], cut[2] - cut[1], X, Y, A0, cg_steps, xchg + per_class, fault_rows, capacity, "als_cg_cluster8_rows");
+  launch_cluster<F, 4, T>(C, cut[2], cut[3] - cut[2], X, Y, A0, cg_steps, xchg + 2 * per_class, fault_rows, capacity, "als_cg_cluster4_rows");
+  if (with16)
+    launch_cluster<F, 2, T>(C, b[1], b[2] - b[1], X, Y, A0, cg_steps, xchg + 3 * per_class, fault_rows, capacity, "als_cg_team16_rows");
+  {
+    // normally reads a zero and exits; after a lost exchange it re-solves the rows the faulted clusters left untouched
+    IMP_PROF("als_cg_cluster_fixup");
+    als_cg_fault_fixup_kernel<F, T><<<std::min(capacity, c.num_cus * 2), 256, 0, stream()>>>(
+        fault_rows, capacity, C->indptr.data(), C->indices.data(), C->data.data(), X, Y, A0, cg_steps);
+    IMP_CHECK_HIP(hipGetLastError());
+  }
 }
 
-// true if a cluster kernel of an earlier launch on this device gave up on an exchange (checked by the solver entry point
-// after its stream synchronisation); clears the word
+// true if a cluster kernel of an earlier launch on this device gave up on an exchange (looked at after a stream
+// synchronisation); clears the word and says so on stderr -- the rows concerned were re-solved by the fix-up kernel, so this is
+// a performance event (a 4 s wait), not an error
 bool cluster_fault_pending() {
   auto &c = ctx();
   if (!c.cluster_fault || *c.cluster_fault == 0u) return false;
   *c.cluster_fault = 0u;
+  fprintf(stderr, "[implicit_amd] warning: a cluster exchange of the CG sweep timed out on device %d; the rows of the clusters "
+                  "concerned were re-solved by the streamed fix-up kernel (als_cg_cluster.hip)\n", c.device);
   return true;
 }
 
