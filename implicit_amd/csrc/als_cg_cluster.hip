@@ -58,8 +58,8 @@ template <int F, int CL, bool STATS, typename ST>
 __global__ __launch_bounds__(64 * kClusterWaves, 4) void als_cg_cluster_kernel(
     const int32_t *__restrict__ order, int first, int count, const int32_t *__restrict__ indptr,
     const int32_t *__restrict__ indices, const float *__restrict__ data, ST *__restrict__ X, const ST *__restrict__ Y,
-    const float *__restrict__ A0, int cg_steps, unsigned long long *xchg, unsigned *fault, int allow_plain, unsigned *fault_rows,
-    int fault_capacity, long long wait_limit, int debug_drop, unsigned long long *__restrict__ stats = nullptr) {
+    const float *__restrict__ A0, int cg_steps, unsigned long long *xchg, unsigned *fault, int allow_plain, unsigned *fault_count,
+    unsigned *fault_rows, int fault_capacity, long long wait_limit, int debug_drop, unsigned long long *__restrict__ stats = nullptr) {
   unsigned long long tk[4] = {0, 0, 0, 0}, t_last = 0, t_rows = 0;
   auto tick = [&](int slot) {  // charge the time since the previous tick to `slot`
     if constexpr (STATS) {
@@ -290,8 +290,8 @@ __global__ __launch_bounds__(64 * kClusterWaves, 4) void als_cg_cluster_kernel(
     if (g == 0) {  // the owner of the row's store
       if (faulted) {  // an exchange of this row (or an earlier one) was lost: the row keeps its iterate and goes to the fix-up list
         if (lane == 0) {
-          const unsigned at = atomicAdd(fault_rows, 1u);
-          if ((int)at < fault_capacity) fault_rows[1 + at] = (unsigned)u;
+          const unsigned at = atomicAdd(fault_count, 1u);
+          if ((int)at < fault_capacity) fault_rows[at] = (unsigned)u;
         }
       } else if (store) {
         store_compact<F>(xrow, lane, x);
@@ -313,14 +313,15 @@ __global__ __launch_bounds__(64 * kClusterWaves, 4) void als_cg_cluster_kernel(
 // operand broadcast from a wave-private LDS copy.  The oracle's CG step by step (_als.pyx:179-244); only the summation order
 // differs from the cluster kernel's.  Slow (milliseconds for a 4096-nonzero row) and never expected to have work.
 template <int F, typename ST>
-__global__ __launch_bounds__(256) void als_cg_fault_fixup_kernel(const unsigned *__restrict__ fault_rows, int capacity,
+__global__ __launch_bounds__(256) void als_cg_fault_fixup_kernel(const unsigned *__restrict__ fault_count,
+                                                                 const unsigned *__restrict__ fault_rows, int capacity,
                                                                  const int32_t *__restrict__ indptr,
                                                                  const int32_t *__restrict__ indices,
                                                                  const float *__restrict__ data, ST *__restrict__ X,
                                                                  const ST *__restrict__ Y, const float *__restrict__ A0, int cg_steps) {
   constexpr int FC = F / 64, WAVES = 4;
   __shared__ float vecs[WAVES][F];
-  const int n = min((int)fault_rows[0], capacity);
+  const int n = min((int)fault_count[0], capacity);
   if (n == 0) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float *vec = vecs[wave];
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(256) void als_cg_fault_fixup_kernel(const unsigned 
     }
   };
   for (int i = blockIdx.x * WAVES + wave; i < n; i += gridDim.x * WAVES) {
-    const int u = (int)fault_rows[1 + i];
+    const int u = (int)fault_rows[i];
     const int rb = indptr[u], re = indptr[u + 1];
     ST *xrow = X + (size_t)u * F;
     float x[FC], r[FC], p[FC], Ap[FC];
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(256) void als_cg_fault_fixup_kernel(const unsigned 
 
 template <int F, int CL, typename T>
 static void launch_cluster(const imp_csr *C, int first, int count, T *X, const T *Y, const float *A0, int cg_steps,
-                           unsigned long long *xchg, unsigned *fault_rows, int fault_capacity, const char *name) {
+                           unsigned long long *xchg, unsigned *fault_count, unsigned *fault_rows, int fault_capacity, const char *name) {
   if (count <= 0) return;
   // IMP_CLUSTER_WAIT_MS: how long a poll waits before it declares the exchange lost (default 4 s; tests lower it);
   // IMP_DEBUG_CLUSTER_DROP=n: member 1 of cluster 0 withholds its n-th exchange (exercises the fault path)
@@ -415,7 +416,7 @@ static void launch_cluster(const imp_csr *C, int first, int count, T *X, const T
     auto skern = als_cg_cluster_kernel<F, CL, true, T>;
     IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(skern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     skern<<<grid, BLOCK, lds, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(), C->data.data(), X, Y,
-                                         A0, cg_steps, xchg, ctx().cluster_fault, allow_plain ? 1 : 0, fault_rows, fault_capacity, wait_limit, debug_drop, stats);
+                                         A0, cg_steps, xchg, ctx().cluster_fault, allow_plain ? 1 : 0, fault_count, fault_rows, fault_capacity, wait_limit, debug_drop, stats);
     unsigned long long h[8];
     IMP_CHECK_HIP(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, stream()));
     IMP_CHECK_HIP(hipStreamSynchronize(stream()));
@@ -426,7 +427,7 @@ static void launch_cluster(const imp_csr *C, int first, int count, T *X, const T
   }
   IMP_PROF(name);
   kern<<<grid, BLOCK, lds, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(), C->data.data(), X, Y,
-                                      A0, cg_steps, xchg, ctx().cluster_fault, allow_plain ? 1 : 0, fault_rows, fault_capacity, wait_limit, debug_drop, nullptr);
+                                      A0, cg_steps, xchg, ctx().cluster_fault, allow_plain ? 1 : 0, fault_count, fault_rows, fault_capacity, wait_limit, debug_drop, nullptr);
   IMP_CHECK_HIP(hipGetLastError());
 }
 
@@ -447,31 +448,33 @@ template <int F, typename T> static void run_clusters(const imp_csr *C, T *X, co
   // exchange slots: [class][cluster][2][CL][64 FC] granules; clusters * CL <= workgroups in flight <= 2 per CU
   constexpr size_t FC = F / 64;
   const size_t per_class = (size_t)c.num_cus * 2 * c.oversub * 2 * 64 * FC;
-  if (c.cluster_xchg.size < 4 * per_class) c.cluster_xchg.alloc(4 * per_class);
+  // + one granule behind the slots: the counter of the fix-up list, so that ONE memset resets both
+  if (c.cluster_xchg.size < 4 * per_class + 1) c.cluster_xchg.alloc(4 * per_class + 1);
   if (!c.cluster_fault) {
     IMP_CHECK_HIP(hipHostMalloc(reinterpret_cast<void **>(&c.cluster_fault), sizeof(unsigned), hipHostMallocMapped));
     *c.cluster_fault = 0u;
   }
   unsigned long long *xchg = c.cluster_xchg.data();
-  // fix-up list: [0] = number of rows a faulted cluster left unsolved, [1 ..] = their ids (every cluster row at most once)
+  // fix-up list: *fault_count = number of rows a faulted cluster left unsolved, fault_rows[0 ..] = their ids (every cluster row
+  // at most once)
   const int capacity = (cut[3] - cut[0]) + (with16 ? b[2] - b[1] : 0);
-  if (c.cluster_fault_rows.size < (size_t)capacity + 1) c.cluster_fault_rows.alloc((size_t)capacity + 1);
+  if (c.cluster_fault_rows.size < (size_t)capacity) c.cluster_fault_rows.alloc((size_t)capacity);
   unsigned *fault_rows = c.cluster_fault_rows.data();
+  unsigned *fault_count = reinterpret_cast<unsigned *>(xchg + 4 * per_class);
   {
     IMP_PROF("als_cg_cluster_reset");
-    IMP_CHECK_HIP(hipMemsetAsync(xchg, 0, 4 * per_class * sizeof(unsigned long long), stream()));
-    IMP_CHECK_HIP(hipMemsetAsync(fault_rows, 0, sizeof(unsigned), stream()));
+    IMP_CHECK_HIP(hipMemsetAsync(xchg, 0, (4 * per_class + 1) * sizeof(unsigned long long), stream()));
   }
-  launch_cluster<F, 16, T>(C, cut[0], cut[1] - cut[0], X, Y, A0, cg_steps, xchg, fault_rows, capacity, "als_cg_cluster16_rows");
-  launch_cluster<F, 8, T>(C, cut[1], cut[2] - cut[1], X, Y, A0, cg_steps, xchg + per_class, fault_rows, capacity, "als_cg_cluster8_rows");
-  launch_cluster<F, 4, T>(C, cut[2], cut[3] - cut[2], X, Y, A0, cg_steps, xchg + 2 * per_class, fault_rows, capacity, "als_cg_cluster4_rows");
+  launch_cluster<F, 16, T>(C, cut[0], cut[1] - cut[0], X, Y, A0, cg_steps, xchg, fault_count, fault_rows, capacity, "als_cg_cluster16_rows");
+  launch_cluster<F, 8, T>(C, cut[1], cut[2] - cut[1], X, Y, A0, cg_steps, xchg + per_class, fault_count, fault_rows, capacity, "als_cg_cluster8_rows");
+  launch_cluster<F, 4, T>(C, cut[2], cut[3] - cut[2], X, Y, A0, cg_steps, xchg + 2 * per_class, fault_count, fault_rows, capacity, "als_cg_cluster4_rows");
   if (with16)
-    launch_cluster<F, 2, T>(C, b[1], b[2] - b[1], X, Y, A0, cg_steps, xchg + 3 * per_class, fault_rows, capacity, "als_cg_team16_rows");
+    launch_cluster<F, 2, T>(C, b[1], b[2] - b[1], X, Y, A0, cg_steps, xchg + 3 * per_class, fault_count, fault_rows, capacity, "als_cg_team16_rows");
   {
     // normally reads a zero and exits; after a lost exchange it re-solves the rows the faulted clusters left untouched
     IMP_PROF("als_cg_cluster_fixup");
     als_cg_fault_fixup_kernel<F, T><<<std::min(capacity, c.num_cus * 2), 256, 0, stream()>>>(
-        fault_rows, capacity, C->indptr.data(), C->indices.data(), C->data.data(), X, Y, A0, cg_steps);
+        fault_count, fault_rows, capacity, C->indptr.data(), C->indices.data(), C->data.data(), X, Y, A0, cg_steps);
     IMP_CHECK_HIP(hipGetLastError());
   }
 }

@@ -404,8 +404,26 @@ void launch_team_fused(const imp_csr *C, int f, int width, int first, int count,
 template <typename T>
 void launch_group_fused(const imp_csr *C, int f, int first, int count, T *X, const T *Y, const float *A0, int cg_steps, const char *name);
 
+// als_cg_qh.hip: float16 storage with the tile kept packed -- 64 entries per wavefront, half the wavefronts per row (round 4)
+void launch_team_half64(const imp_csr *C, int f, int width, int first, int count, __half *X, const __half *Y, const float *A0,
+                        int cg_steps, const char *name);
+
 template <int F, typename T> static void run_classes_q(const imp_csr *C, T *X, const T *Y, const float *A0, int cg_steps) {
   const int32_t *b = C->bin_start;  // classes: 1 (256,512]  2 (128,256]  3 (64,128]  4 (32,64]  5 (16,32]  6 (0,16]
+  if constexpr (std::is_same<T, __half>::value) {
+    // IMP_HALF_TILE64=0: the fp32-tile kernels below for float16 storage too (round 3; A/B: 4.9 against 4.4-4.5 ms per
+    // configs[2] iteration)
+    static const bool tile64 = !(getenv("IMP_HALF_TILE64") && atoi(getenv("IMP_HALF_TILE64")) == 0);
+    if (tile64) {
+      launch_team_half64(C, F, 8, b[1], b[2] - b[1], X, Y, A0, cg_steps, "als_cg_team16_rows");  // names: the row class, as for fp32
+      launch_team_half64(C, F, 4, b[2], b[3] - b[2], X, Y, A0, cg_steps, "als_cg_team8_rows");
+      launch_team_half64(C, F, 2, b[3], b[4] - b[3], X, Y, A0, cg_steps, "als_cg_team4_rows");
+      launch_team_half64(C, F, 1, b[4], b[5] - b[4], X, Y, A0, cg_steps, "als_cg_team2_rows");
+      if constexpr (F == 64) launch_team_fused<T>(C, F, 1, b[5], b[7] - b[5], X, Y, A0, cg_steps, "als_cg_short_rows");
+      else launch_group_fused<T>(C, F, b[5], b[7] - b[5], X, Y, A0, cg_steps, "als_cg_short_rows");
+      return;
+    }
+  }
   // IMP_TEAM_FUSED=0: the round-2 team kernels (dense part, then tile part; gathers at the row start) -- A/B and the
   // IMP_CG_STATS instrumentation; a bit mask selects the round-3 kernel per team width (1: 16 waves, 2: 8, 4: 4, 8: 2, 16: 1, 32: the lock-step short-row kernel)
   static const int fused = getenv("IMP_TEAM_FUSED") ? atoi(getenv("IMP_TEAM_FUSED")) : 63;

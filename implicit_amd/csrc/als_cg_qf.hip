@@ -3,7 +3,7 @@
 //
 // Arithmetic contract: the oracle's CG (implicit/cpu/_als.pyx:152-248).
 //
-// What bounds these kernels (profiles/micro/valu_rate.hip, profiles/r03_micro_valu_rate.txt): a SIMD of this part retires
+// What bounds these kernels (profiles/micro/valu_rate.hip, profiles/r04_micro_valu_rate.txt): a SIMD of this part retires
 // one vector instruction per ~3.1 ns whatever its kind (v_fma_f32, v_pk_fma_f32, DPP adds alike: 0.32 G wave-instructions
 // per second and SIMD, 330 G/s for the chip), and the round-2 team kernels executed 1.03 G of them per C3 iteration for the
 // mid-row classes -- 3.1 ms of pure issue time against the 3.3 ms measured.  They were instruction-issue bound at 100 %,
@@ -30,63 +30,10 @@
 // 3, entries 2).
 #include <type_traits>
 
-#include "als_qtile.h"
+#include "als_qf_common.h"
 #include "common.h"
 
 namespace imp {
-
-// The compiler hoists everything derived from the lane id out of the row loop (byte offsets, 64-bit gather bases, LDS
-// addresses: a dozen registers) and then spills it, because the tile fills the file.  Lane-derived values are therefore
-// re-derived where they are used, from a copy of the lane id the optimiser cannot see through.
-__device__ __forceinline__ int opaque(int v) {
-  asm volatile("" : "+v"(v));
-  return v;
-}
-
-// explicit packed math: pairs of adjacent expanded slots travel as one 64-bit register pair (v_pk_fma_f32); left to the
-// SLP vectoriser the dots came out as scalar v_fmac chains once the operand arrived by ds_read_b128
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-template <int I> using idx_t = std::integral_constant<int, I>;
-template <int N, typename Fn, int... Is> __device__ __forceinline__ void static_for_impl(Fn &&fn, std::integer_sequence<int, Is...>) {
-  (fn(idx_t<Is>{}), ...);
-}
-template <int N, typename Fn> __device__ __forceinline__ void static_for(Fn &&fn) {
-  static_for_impl<N>(fn, std::make_integer_sequence<int, N>{});
-}
-
-// The gramian rows of one wave and pass dealt to 16 ticks, four per pair of tile steps.  The wave's F / WPR rows are cut
-// into four runs of NJ consecutive rows, one per 16-lane group: step s of group g is row j_begin + g NJ + s, so a group's
-// operand entries p_j are consecutive and travel two at a time (ds_read_b64 costs the LDS the same two cycles as a b32).
-// One step = FE/4 ds_read_b128 in flight per tick (8 registers at f = 128) + the operand pair.
-template <int F, int NJ> struct DenseTicks {
-  static constexpr int FE = F / 16, Q4 = FE / 4;
-  static constexpr int EVERY = 16 / NJ;  // ticks K with K % EVERY == 0 carry one step
-  static_assert(NJ == 16 || NJ == 8 || NJ == 4 || NJ == 2 || NJ == 1, "steps per pass");
-  float4 a[Q4];
-  f32x2 vj2;
-  template <int K> __device__ __forceinline__ void issue(const float *row, const float *vp) {
-    if constexpr (K % EVERY == 0) {
-      constexpr int s = K / EVERY;
-      if constexpr (NJ == 1) vj2 = f32x2{vp[0], 0.f};
-      else if constexpr (s % 2 == 0) vj2 = *reinterpret_cast<const f32x2 *>(vp + s);
-#pragma unroll
-      for (int e = 0; e < Q4; ++e) a[e] = *reinterpret_cast<const float4 *>(row + (size_t)s * F + 64 * e);
-    }
-  }
-  template <int K> __device__ __forceinline__ void consume(f32x2 (&ae)[FE / 2]) {
-    if constexpr (K % EVERY == 0) {
-      constexpr int s = K / EVERY;
-      const float vj = (s % 2 == 0) ? vj2.x : vj2.y;
-      const f32x2 v2 = {vj, vj};
-#pragma unroll
-      for (int e = 0; e < Q4; ++e) {
-        ae[2 * e] = __builtin_elementwise_fma(v2, f32x2{a[e].x, a[e].y}, ae[2 * e]);
-        ae[2 * e + 1] = __builtin_elementwise_fma(v2, f32x2{a[e].z, a[e].w}, ae[2 * e + 1]);
-      }
-    }
-  }
-};
 
 // Entries of tile steps 2 P and 2 P + 1.  The staged registers hold entry min(l, cnt - 1) of the wave's slice in lanes l and
 // l + 32 (fetch_entries): the gather addresses travel by ds_bpermute (entry t = 4 q + g -> the 16 lanes of group g), the two
@@ -114,23 +61,6 @@ __device__ __forceinline__ void gather_pair(f32x2 (&y)[8][F / 32], float *cw, in
       y[q][e / 2] = f32x2{v.x, v.y}, y[q][e / 2 + 1] = f32x2{v.z, v.w};
     }
   }
-}
-
-// the dots of two tile steps, reduced over the 16 lanes of each group TOGETHER: after the first level the lower half-row
-// carries d0's pair sums and the upper half d1's, the remaining three levels (half-row mirror, quad xor 1, quad xor 2: all
-// inside a half-row) then serve both.  Lanes 0-7 of every row end with the total of d0, lanes 8-15 with the total of d1.
-__device__ __forceinline__ float reduce_pair(float d0, float d1) {
-  float u = d1 + dpp_mov<0x128>(d1);  // row_ror:8
-  const float s0 = d0 + dpp_mov<0x128>(d0);
-  u = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, u), __builtin_bit_cast(int, s0), 0xE4, 0xF, 0x3,
-                                                            false));  // quad_perm:[0,1,2,3] into banks 0, 1 = lanes 0-7
-  u += dpp_mov<0x141>(u);  // row_half_mirror
-  u += dpp_mov<0xB1>(u);   // quad_perm:[1,0,3,2]
-  u += dpp_mov<0x4E>(u);   // quad_perm:[2,3,0,1]
-  return u;
-}
-template <int LANE> __device__ __forceinline__ float row_bcast_from(float v) {  // row_newbcast:LANE (gfx90a+)
-  return dpp_mov<0x150 + LANE>(v);
 }
 
 // One pass over this wave's share of a row: acc (compact) = [its gramian rows] . v  +  [its tile entries] weights, v being
@@ -239,24 +169,6 @@ __device__ __forceinline__ void fused_pass(f32x2 (&y)[8][F / 32], float *cw, int
   }
 }
 
-// control word the leader publishes with every operand
-enum : unsigned { kGo = 1u, kLast = 2u };
-
-// tunables of the team protocol (compile-time: s_sleep / s_setprio take immediates; -D overrides for A/B builds,
-// implicit_amd/_build.py build_variant)
-#ifndef IMP_TEAM_NAP_FIRST
-#define IMP_TEAM_NAP_FIRST 6   // a worker's first nap while the leader updates (64-cycle units)
-#endif
-#ifndef IMP_TEAM_NAP_NEXT
-#define IMP_TEAM_NAP_NEXT 2    // its later naps
-#endif
-#ifndef IMP_TEAM_NAP_LEADER
-#define IMP_TEAM_NAP_LEADER 1  // the leader's naps while it waits for the arrivals
-#endif
-#ifndef IMP_TEAM_LEADER_PRIO
-#define IMP_TEAM_LEADER_PRIO 0 // wave priority of a leader from "arrivals complete" to "operand published" (the team idles meanwhile)
-#endif
-
 // STATS (debug, IMP_CG_STATS=1; timings only): shader-clock cycles summed over the waves of the launch --
 //   [0] waiting for the leader's operand  [1] passes (operand read, dense ticks + tile steps, reduce)  [2] partial -> LDS, arrival
 //   [3] leader: waiting for the team's arrivals  [4] leader: sum of the partials, CG update, publish  [5] row start (gathers
@@ -289,17 +201,7 @@ __global__ __launch_bounds__(BLOCK, F == 64 ? 8 : 4) void als_cg_qfteam_kernel(c
   unsigned *ctl = reinterpret_cast<unsigned *>(cws + (size_t)WAVES * 64);  // [TEAMS][4]  arrivals A, generation B, control words
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // IMP_TEAM_SAME_SIMD: the waves of a team are w, w + TEAMS, ... -- wave w of a workgroup sits on SIMD w mod 4, so a team of
-  // two shares ONE SIMD (and a team of four two SIMDs) instead of spreading over WPR of them
-#ifdef IMP_TEAM_SAME_SIMD
-  const int team = wave % TEAMS, sub = wave / TEAMS;
-  constexpr int kMemberStride = TEAMS;
-  const int first_member = team;
-#else
   const int team = wave / WPR, sub = wave % WPR;
-  constexpr int kMemberStride = 1;
-  const int first_member = team * WPR;
-#endif
   const bool leader = sub == 0;
   for (int e = threadIdx.x; e < F * F; e += BLOCK) A0s[e] = A0[e];
   if (threadIdx.x < 4 * TEAMS) ctl[threadIdx.x] = 0u;
@@ -367,16 +269,16 @@ __global__ __launch_bounds__(BLOCK, F == 64 ? 8 : 4) void als_cg_qfteam_kernel(c
     }
     if constexpr (IMP_TEAM_LEADER_PRIO > 0) __builtin_amdgcn_s_setprio(IMP_TEAM_LEADER_PRIO);
     tick(3);
-    const float *slot = reinterpret_cast<const float *>(reinterpret_cast<const char *>(parts + (size_t)first_member * F) + cf4);
+    const float *slot = reinterpret_cast<const float *>(reinterpret_cast<const char *>(parts + (size_t)(team * WPR) * F) + cf4);
 #pragma unroll
     for (int c = 0; c < FC; ++c) acc[c] = 0.f;
 #pragma unroll
     for (int w = 0; w < WPR; ++w) {
       if constexpr (FC == 2) {
-        const float2 t = *reinterpret_cast<const float2 *>(slot + (size_t)w * kMemberStride * F);
+        const float2 t = *reinterpret_cast<const float2 *>(slot + (size_t)w * F);
         acc[0] += t.x, acc[1] += t.y;
       } else {
-        acc[0] += slot[(size_t)w * kMemberStride * F];
+        acc[0] += slot[(size_t)w * F];
       }
     }
   };
@@ -401,23 +303,6 @@ __global__ __launch_bounds__(BLOCK, F == 64 ? 8 : 4) void als_cg_qfteam_kernel(c
   const int i_step = gridDim.x * TEAMS, i_first = blockIdx.x * TEAMS + team;
   auto slice = [&](int rb, int re, int &k0, int &cnt) {  // even shares rounded up to whole 4-entry tile steps
     const int chunk = min(T, (((re - rb) + WPR - 1) / WPR + 3) & ~3);
-#if defined(IMP_LEADER_LIGHT)
-    // the leader also carries the CG update between the passes: it takes IMP_LEADER_LIGHT entries less (as far as the other
-    // waves' tiles have room), the rest is dealt evenly to the other waves
-    if constexpr (WPR > 1) {
-      const int len = re - rb;
-      const int shift = min(IMP_LEADER_LIGHT, T - chunk);
-      const int cnt_l = max(0, min(chunk - shift, len));
-      if (sub == 0) {
-        k0 = rb, cnt = cnt_l;
-      } else {
-        const int chunk_o = min(T, (((len - cnt_l) + WPR - 2) / (WPR - 1) + 3) & ~3);
-        k0 = min(rb + cnt_l + chunk_o * (sub - 1), re);
-        cnt = min(chunk_o, re - k0);
-      }
-      return;
-    }
-#endif
     k0 = min(rb + chunk * sub, re);
     cnt = min(chunk, re - k0);
   };

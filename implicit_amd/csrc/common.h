@@ -152,7 +152,7 @@ struct Context {
   DeviceArray<float> barrier_word;              // operand of the RCCL barrier (comm.hip)
   DeviceArray<unsigned long long> cluster_xchg;  // partial-vector exchange slots of the cluster kernels (als_cg_cluster.hip)
   unsigned *cluster_fault = nullptr;             // host-mapped word: set by a cluster kernel whose exchange timed out
-  DeviceArray<unsigned> cluster_fault_rows;      // [0] count, [1 ..] rows a faulted cluster left to the fix-up kernel (als_cg_cluster.hip)
+  DeviceArray<unsigned> cluster_fault_rows;      // rows a faulted cluster left to the fix-up kernel; their count sits behind the exchange slots (als_cg_cluster.hip)
 };
 inline hipStream_t stream() { return ctx().stream; }
 

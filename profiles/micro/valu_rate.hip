@@ -71,6 +71,48 @@ template <int MODE> __global__ __launch_bounds__(1024) void rate_kernel(float *o
           asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(a[i + 1]));
           asm volatile("v_mov_b32 %0, %1" : "+v"(a[i + 1]) : "v"(b));
         }
+    } else if constexpr (MODE == 10) {  // round 4: f16 operand widened inside the FMA (the packed-half tile idea)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(a[i]) : "v"(c), "v"(b));
+    } else if constexpr (MODE == 13) {  // the HIGH half as the f16 operand
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a[i]) : "v"(c), "v"(b));
+    } else if constexpr (MODE == 14) {  // dependent chain of fma_mix: latency
+#pragma unroll
+      for (int r = 0; r < 64; ++r) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(a[0]) : "v"(c), "v"(b));
+    } else if constexpr (MODE == 15) {  // fma_mix and pk_fma alternating, independent
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(a[i]) : "v"(c), "v"(b));
+          asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(cc), "v"(bb));
+        }
+    } else if constexpr (MODE == 16) {  // two chains of 4 dependent fma_mix per "dot", as the packed-tile kernel issues them
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        float s0 = a[0], s1 = a[1];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(s0) : "v"(a[2 + h]), "v"(b));
+          asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(s1) : "v"(a[2 + h]), "v"(c));
+        }
+        a[0] = s0, a[1] = s1;
+      }
+    } else if constexpr (MODE == 11) {  // v_cvt_f32_f16
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("v_cvt_f32_f16 %0, %1" : "+v"(a[i]) : "v"(c));
+    } else if constexpr (MODE == 12) {  // v_dot2c_f32_f16: two f16 x f16 products accumulated in fp32
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(a[i]) : "v"(c), "v"(b));
     } else if constexpr (MODE == 5) {  // alternating pk / plain, independent
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -147,6 +189,14 @@ int main() {
   run<8>("v_mul_f32 v,v", 4, 64, 1, 8);
   run<9>("v_mov_b32", 4, 64, 0, 8);
   run<2>("v_fmac_f32_dpp newbcast", 4, 64, 2, 8);
+  run<10>("v_fma_mix_f32 f16,f32,f32", 4, 64, 2, 8);
+  run<13>("v_fma_mix_f32 hi half", 4, 64, 2, 8);
+  run<15>("fma_mix + pk_fma alternating", 4, 64, 3, 8);
+  run<16>("fma_mix 2 chains of 4", 4, 64, 2, 8);
+  run<16>("fma_mix 2 chains of 4, 1 wave/SIMD", 4, 64, 2);
+  run<14>("v_fma_mix_f32 dependent", 4, 64, 2);
+  run<11>("v_cvt_f32_f16", 4, 64, 0, 8);
+  run<12>("v_dot2c_f32_f16", 4, 64, 4, 8);
   run<3>("v_pk_fma_f32 dependent", 4, 64, 4);
   run<4>("v_fma_f32 dependent", 4, 64, 2);
   unsigned long long *o;

@@ -163,6 +163,14 @@ for f in (64, 128, 50, 100):   # 50 / 100: zero-padded onto the f = 64 / 128 ker
         want = X0.copy()
         oracle.least_squares_cg(M, want, Y0, 0.05, cg_steps=3, YtY=gram.to_numpy())
         assert rel(Xd.to_numpy(), want) < 1e-4, ("cg", f, rel(Xd.to_numpy(), want))
+        if f in (64, 128):   # float16 storage: packed 64-entry tiles (IMP_HALF_TILE64=0: the fp32-tile kernels)
+            X16, Y16 = X0.astype(np.float16), Y0.astype(np.float16)
+            Xh, Yh = gpu.Matrix(X16), gpu.Matrix(Y16)
+            solver.calculate_yty(Yh, gram, 0.05)
+            solver.least_squares(gpu.CSRMatrix(M), Xh, gram, Yh, 3)
+            want = X16.astype(np.float32)
+            oracle.least_squares_cg(M, want, Y16.astype(np.float32), 0.05, cg_steps=3, YtY=gram.to_numpy())
+            assert rel(Xh.to_numpy().astype(np.float32), want) < 1e-3, ("cg fp16", f)
     if f == 64:
         Xd = gpu.Matrix.zeros(C.shape[0], f)
         solver.calculate_yty(Yd if Yd.shape[0] == C.shape[1] else gpu.Matrix(Y0), gram, 0.0)
@@ -198,7 +206,7 @@ print("switch ok")
                                     "IMP_CHOL_NO_MFMA=1", "IMP_CHOL_NO_WAVE=1", "IMP_TOPK_NO_FAST=1", "IMP_NO_CLUSTER=1", "IMP_CLUSTER_SC1=1",
                                     "IMP_GRAM_NO_VEC=1", "IMP_CHOL_NO_SPLIT=1", "IMP_TEAM16_CLUSTER=1", "IMP_F256_GENERIC=1",
                                     "IMP_OVERSUB=3", "IMP_STRIPE_REUSE=1", "IMP_QGROUP_PER_CU=1", "IMP_TEAM_FUSED=0", "IMP_TEAM_FUSED=31", "IMP_SHORT_STAGGER=0", "IMP_SHORT_BF16X3=0",
-                                    "IMP_TOPK_FP32_MFMA=1", "IMP_NO_PAD=1", "IMP_TOPK_NO_PAD=1", "IMP_TOPK_NO_QSPLIT=1"])
+                                    "IMP_TOPK_FP32_MFMA=1", "IMP_NO_PAD=1", "IMP_TOPK_NO_PAD=1", "IMP_TOPK_NO_QSPLIT=1", "IMP_HALF_TILE64=0"])
 def test_ab_switch_paths_keep_parity(gpu, switch):
     """Every debug / A-B environment switch selects kernels the default run does not take (they are read once per
     process, hence the subprocess): CG both orientations at f = 64 / 128, Cholesky f = 64 and top-k against the oracle."""
@@ -334,9 +342,10 @@ def test_topk_emit_path_and_its_fallbacks(gpu, oracle):
 @pytest.mark.parametrize("f", [64, 128])
 def test_native_fp16_factor_storage(gpu, oracle, f):
     """fp16 factor storage is read and written by the f = 64 / 128 kernels themselves (half2 / 8-byte loads converted in
-    registers, fp32 arithmetic and CG state, as implicit/gpu/als.cu:41,55,109): equal, bit for bit, to solving an fp32 copy
-    of the fp16 matrices and rounding the result (the IMP_FP16_CONVERT=1 path), and within 1e-3 of the oracle run on the
-    fp16-rounded inputs (the result is stored in fp16)."""
+    registers or inside the FMA, fp32 arithmetic and CG state, as implicit/gpu/als.cu:41,55,109): equal to solving an fp32
+    copy of the fp16 matrices and rounding the result (the IMP_FP16_CONVERT=1 path) -- bit for bit where both storages share
+    a kernel, to the last fp16 place elsewhere -- and within 1e-3 of the oracle run on the fp16-rounded inputs (the result is
+    stored in fp16)."""
     C = synthetic_csr(4000, 1500, 200_000, seed=2, neg_frac=0.05, empty_frac=0.01)   # item side has rows > 512 nnz
     rng = np.random.default_rng(4)
     for M in (C, C.T.tocsr()):
@@ -355,7 +364,17 @@ def test_native_fp16_factor_storage(gpu, oracle, f):
         # the same solve on an fp32 copy, rounded at the end
         X32, Y32 = gpu.Matrix(X16.astype(np.float32)), gpu.Matrix(Y16.astype(np.float32))
         solver.least_squares(gpu.CSRMatrix(M), X32, gram, Y32, 3)
-        np.testing.assert_array_equal(got, X32.to_numpy().astype(np.float16))
+        want16 = X32.to_numpy().astype(np.float16)
+        # Round 4: the mid-row classes of fp16 storage run on HALF the wavefronts with a packed 64-entry tile
+        # (als_cg_qh.hip), so a row's partial sums associate differently from the fp32 kernels': the fp32 results agree to
+        # rounding noise and the rounded fp16 values to one unit in the last place on a small fraction of the elements.  The
+        # other classes (short rows, clusters, streamed rows) share their kernels with fp32 storage and stay bit-identical.
+        lens = np.diff(M.indptr)
+        same_kernel = (lens <= 32) | (lens > 512)
+        np.testing.assert_array_equal(got[same_kernel], want16[same_kernel])
+        a, b = got.astype(np.float32), want16.astype(np.float32)
+        ulp = np.spacing(np.abs(b).astype(np.float16)).astype(np.float32)
+        assert (np.abs(a - b) <= ulp).all() and (a != b).mean() < 0.02
         want = X16.astype(np.float32)
         oracle.least_squares_cg(M, want, Y16.astype(np.float32), 0.05, cg_steps=3, YtY=gram.to_numpy())
         assert rel(got.astype(np.float32), want) < 1e-3
