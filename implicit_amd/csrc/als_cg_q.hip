@@ -404,21 +404,30 @@ void launch_team_fused(const imp_csr *C, int f, int width, int first, int count,
 template <typename T>
 void launch_group_fused(const imp_csr *C, int f, int first, int count, T *X, const T *Y, const float *A0, int cg_steps, const char *name);
 
-// als_cg_qh.hip: float16 storage with the tile kept packed -- 64 entries per wavefront, half the wavefronts per row (round 4)
-void launch_team_half64(const imp_csr *C, int f, int width, int first, int count, __half *X, const __half *Y, const float *A0,
-                        int cg_steps, const char *name);
+// als_cg_qh.hip: 64-entry tiles, half the wavefronts per row (round 4): packed halves for float16 storage, "fat" wavefronts
+// (two per SIMD at f = 128) for fp32
+template <typename ST>
+void launch_team_tile64(const imp_csr *C, int f, int width, int first, int count, ST *X, const ST *Y, const float *A0, int cg_steps,
+                        const char *name);
 
 template <int F, typename T> static void run_classes_q(const imp_csr *C, T *X, const T *Y, const float *A0, int cg_steps) {
   const int32_t *b = C->bin_start;  // classes: 1 (256,512]  2 (128,256]  3 (64,128]  4 (32,64]  5 (16,32]  6 (0,16]
-  if constexpr (std::is_same<T, __half>::value) {
-    // IMP_HALF_TILE64=0: the fp32-tile kernels below for float16 storage too (round 3; A/B: 4.9 against 4.4-4.5 ms per
-    // configs[2] iteration)
-    static const bool tile64 = !(getenv("IMP_HALF_TILE64") && atoi(getenv("IMP_HALF_TILE64")) == 0);
-    if (tile64) {
-      launch_team_half64(C, F, 8, b[1], b[2] - b[1], X, Y, A0, cg_steps, "als_cg_team16_rows");  // names: the row class, as for fp32
-      launch_team_half64(C, F, 4, b[2], b[3] - b[2], X, Y, A0, cg_steps, "als_cg_team8_rows");
-      launch_team_half64(C, F, 2, b[3], b[4] - b[3], X, Y, A0, cg_steps, "als_cg_team4_rows");
-      launch_team_half64(C, F, 1, b[4], b[5] - b[4], X, Y, A0, cg_steps, "als_cg_team2_rows");
+  {
+    // 64-entry tiles.  fp16 storage: on by default (IMP_HALF_TILE64=0: the fp32-tile kernels below; 4.9 against 4.4-4.5 ms per
+    // configs[2] iteration).  fp32 storage: IMP_TILE64=<mask> selects it per class (1: (256,512]  2: (128,256]  4: (64,128]
+    // 8: (32,64]).
+    static const bool half64 = !(getenv("IMP_HALF_TILE64") && atoi(getenv("IMP_HALF_TILE64")) == 0);
+    static const int float64 = getenv("IMP_TILE64") ? atoi(getenv("IMP_TILE64")) : 0;
+    const int mask = std::is_same<T, __half>::value ? (half64 ? 15 : 0) : float64;
+    if (mask) {
+      auto cls = [&](int bit, int width64, int width32, int lo, int hi, const char *name) {
+        if (mask & bit) launch_team_tile64<T>(C, F, width64, lo, hi - lo, X, Y, A0, cg_steps, name);
+        else launch_team_fused<T>(C, F, width32, lo, hi - lo, X, Y, A0, cg_steps, name);
+      };
+      cls(1, 8, 16, b[1], b[2], "als_cg_team16_rows");  // names: the row class
+      cls(2, 4, 8, b[2], b[3], "als_cg_team8_rows");
+      cls(4, 2, 4, b[3], b[4], "als_cg_team4_rows");
+      cls(8, 1, 2, b[4], b[5], "als_cg_team2_rows");
       if constexpr (F == 64) launch_team_fused<T>(C, F, 1, b[5], b[7] - b[5], X, Y, A0, cg_steps, "als_cg_short_rows");
       else launch_group_fused<T>(C, F, b[5], b[7] - b[5], X, Y, A0, cg_steps, "als_cg_short_rows");
       return;

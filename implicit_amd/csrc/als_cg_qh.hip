@@ -46,34 +46,9 @@ __device__ __forceinline__ void fetch_entries64(const int32_t *__restrict__ indi
   c = data[k];
 }
 
-// Entries of tile steps 2 P and 2 P + 1 (lanes 8 P .. 8 P + 7 of the staged registers): gather addresses by ds_bpermute, weights
-// |c| - 1 and c+ to the wave's LDS table (cw[t], cw[64 + t]), the factor rows as they are stored -- 8-byte loads of 4 halves.
-template <int F, int P>
-__device__ __forceinline__ void gather_pair_h(unsigned (&y)[kHT / 4][F / 32], float *cw, int col_reg, float c_reg, int cnt,
-                                              const __half *__restrict__ Y, int lane) {
-  constexpr int FE = F / 16;
-  lane = opaque(lane);
-  if ((lane >> 3) == P) {
-    const bool ok = lane < cnt;
-    cw[lane] = ok ? fabsf(c_reg) - 1.f : 0.f;
-    cw[kHT + lane] = ok ? fmaxf(c_reg, 0.f) : 0.f;
-  }
-  const int src = 4 * (lane >> 4);  // byte address of the source lane: entry t = 4 q + g sits in lane t
-#pragma unroll
-  for (int q = 2 * P; q < 2 * P + 2; ++q) {
-    const unsigned col = (unsigned)__builtin_amdgcn_ds_bpermute(src + 16 * q, col_reg);
-    const __half *p = Y + (size_t)col * F + 4 * (lane & 15);
-#pragma unroll
-    for (int e = 0; e < FE; e += 4) {  // expanded slots e .. e + 3 = factors 64 (e / 4) + 4 m ..: one 8-byte load
-      const uint2 raw = *reinterpret_cast<const uint2 *>(p + 16 * e);
-      y[q][e / 2] = raw.x, y[q][e / 2 + 1] = raw.y;
-    }
-  }
-}
-
 // d = float(half of yh) * b + c in ONE instruction.  Written as asm: given fmaf(half -> float, ..) twice on the same register (the
 // dot and the axpy of an entry) the compiler converts the tile to fp32 once per pass and keeps the copy -- 64 more live registers,
-// i.e. the very thing this kernel exists to avoid (150 spilled registers).
+// i.e. the very thing the packed tile exists to avoid (150 spilled registers).
 __device__ __forceinline__ float fma_mix_lo(unsigned yh, float b, float c) {
   float d;
   asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(yh), "v"(b), "v"(c));
@@ -95,6 +70,77 @@ __device__ __forceinline__ float mul_mix_hi(unsigned yh, float b) {
   return d;
 }
 
+// One register-resident element of the tile = expanded slots (2 h, 2 h + 1) of an entry: a packed fp32 pair for fp32 storage,
+// two halves in one register for fp16 storage.  The products associate alike in both (and as in als_cg_qf.hip): even slots in
+// one running sum, odd slots in the other.
+template <typename ST> struct Tile64;
+template <> struct Tile64<float> {
+  typedef f32x2 elem;
+  template <int H> static __device__ __forceinline__ void gather(elem (&yq)[H], const float *p) {
+#pragma unroll
+    for (int h = 0; h < H; h += 2) {  // expanded slots 2 h .. 2 h + 3 = factors 64 (h / 2) + 4 m ..: one 16-byte load
+      const float4 v = load4(p + 32 * h);
+      yq[h] = f32x2{v.x, v.y}, yq[h + 1] = f32x2{v.z, v.w};
+    }
+  }
+  template <int H> static __device__ __forceinline__ float dot(const elem (&yq)[H], const f32x2 (&ve)[H]) {
+    f32x2 s = yq[0] * ve[0];
+#pragma unroll
+    for (int h = 1; h < H; ++h) s = __builtin_elementwise_fma(yq[h], ve[h], s);
+    return s.x + s.y;
+  }
+  template <int H> static __device__ __forceinline__ void axpy(const elem (&yq)[H], float w, f32x2 (&ae)[H]) {
+    const f32x2 w2 = {w, w};
+#pragma unroll
+    for (int h = 0; h < H; ++h) ae[h] = __builtin_elementwise_fma(w2, yq[h], ae[h]);
+  }
+};
+template <> struct Tile64<__half> {
+  typedef unsigned elem;
+  template <int H> static __device__ __forceinline__ void gather(elem (&yq)[H], const __half *p) {
+#pragma unroll
+    for (int h = 0; h < H; h += 2) {  // 4 halves = one 8-byte load
+      const uint2 raw = *reinterpret_cast<const uint2 *>(p + 32 * h);
+      yq[h] = raw.x, yq[h + 1] = raw.y;
+    }
+  }
+  template <int H> static __device__ __forceinline__ float dot(const elem (&yq)[H], const f32x2 (&ve)[H]) {
+    float s0 = mul_mix_lo(yq[0], ve[0].x), s1 = mul_mix_hi(yq[0], ve[0].y);
+#pragma unroll
+    for (int h = 1; h < H; ++h) {
+      s0 = fma_mix_lo(yq[h], ve[h].x, s0);
+      s1 = fma_mix_hi(yq[h], ve[h].y, s1);
+    }
+    return s0 + s1;
+  }
+  template <int H> static __device__ __forceinline__ void axpy(const elem (&yq)[H], float w, f32x2 (&ae)[H]) {
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      ae[h].x = fma_mix_lo(yq[h], w, ae[h].x);
+      ae[h].y = fma_mix_hi(yq[h], w, ae[h].y);
+    }
+  }
+};
+
+// Entries of tile steps 2 P and 2 P + 1 (lanes 8 P .. 8 P + 7 of the staged registers): gather addresses by ds_bpermute, weights
+// |c| - 1 and c+ to the wave's LDS table (cw[t], cw[64 + t]), the factor rows as they are stored.
+template <int F, int P, typename ST>
+__device__ __forceinline__ void gather_pair64(typename Tile64<ST>::elem (&y)[kHT / 4][F / 32], float *cw, int col_reg, float c_reg, int cnt,
+                                              const ST *__restrict__ Y, int lane) {
+  lane = opaque(lane);
+  if ((lane >> 3) == P) {
+    const bool ok = lane < cnt;
+    cw[lane] = ok ? fabsf(c_reg) - 1.f : 0.f;
+    cw[kHT + lane] = ok ? fmaxf(c_reg, 0.f) : 0.f;
+  }
+  const int src = 4 * (lane >> 4);  // byte address of the source lane: entry t = 4 q + g sits in lane t
+#pragma unroll
+  for (int q = 2 * P; q < 2 * P + 2; ++q) {
+    const unsigned col = (unsigned)__builtin_amdgcn_ds_bpermute(src + 16 * q, col_reg);
+    Tile64<ST>::template gather<F / 32>(y[q], Y + (size_t)col * F + 4 * (lane & 15));
+  }
+}
+
 template <int H> struct NoDenseTicks {  // IMP_QH_KO_DENSE
   template <int K> __device__ __forceinline__ void issue(const float *, const float *) {}
   template <int K> __device__ __forceinline__ void consume(f32x2 (&)[H]) {}
@@ -102,10 +148,10 @@ template <int H> struct NoDenseTicks {  // IMP_QH_KO_DENSE
 
 // One pass over this wave's share of a row (fused_pass of als_cg_qf.hip with a packed tile of 8 pairs and 32 dense ticks).
 // The products associate exactly as in the fp32 kernel: even expanded slots in one running sum, odd slots in the other.
-template <int F, int NJ, bool FIRST, bool LAST>
-__device__ __forceinline__ void fused_pass_h(unsigned (&y)[kHT / 4][F / 32], float *cw, int cnt, const float *vt, int j_begin,
-                                             const float *A0s, float (&acc)[F / 64], int lane, int cnt_nx, int &col_nx, float &c_nx,
-                                             const __half *__restrict__ Y, const int32_t *__restrict__ indices,
+template <int F, int NJ, bool FIRST, bool LAST, typename ST>
+__device__ __forceinline__ void fused_pass64(typename Tile64<ST>::elem (&y)[kHT / 4][F / 32], float *cw, int cnt, const float *vt,
+                                             int j_begin, const float *A0s, float (&acc)[F / 64], int lane, int cnt_nx, int &col_nx,
+                                             float &c_nx, const ST *__restrict__ Y, const int32_t *__restrict__ indices,
                                              const float *__restrict__ data, int k0_nx2, int end_nx2) {
   constexpr int FE = F / 16, H = FE / 2;
   if constexpr (LAST) {  // one wait for the staged entries, before any rolling gather
@@ -135,26 +181,16 @@ __device__ __forceinline__ void fused_pass_h(unsigned (&y)[kHT / 4][F / 32], flo
 #endif
   auto partial = [&](int q) {
 #ifdef IMP_QH_KO_TILE  // timing-only knock-out: no tile arithmetic (results wrong)
-    return __uint_as_float(y[q][0]) + ve[0].x;
+    return ve[0].x;
 #endif
-    float s0 = mul_mix_lo(y[q][0], ve[0].x), s1 = mul_mix_hi(y[q][0], ve[0].y);
-#pragma unroll
-    for (int h = 1; h < H; ++h) {
-      s0 = fma_mix_lo(y[q][h], ve[h].x, s0);
-      s1 = fma_mix_hi(y[q][h], ve[h].y, s1);
-    }
-    return s0 + s1;
+    return Tile64<ST>::template dot<H>(y[q], ve);
   };
   auto axpy = [&](int q, float w) {
 #ifdef IMP_QH_KO_TILE
     ae[0].x += w;
     return;
 #endif
-#pragma unroll
-    for (int h = 0; h < H; ++h) {
-      ae[h].x = fma_mix_lo(y[q][h], w, ae[h].x);
-      ae[h].y = fma_mix_hi(y[q][h], w, ae[h].y);
-    }
+    Tile64<ST>::template axpy<H>(y[q], w, ae);
   };
   static_for<kHPairs>([&](auto Pc) {
     constexpr int P = decltype(Pc)::value;
@@ -196,7 +232,7 @@ __device__ __forceinline__ void fused_pass_h(unsigned (&y)[kHT / 4][F / 32], flo
       });
     }
     if constexpr (LAST) {
-      if (8 * P < cnt_nx) gather_pair_h<F, P>(y, cw, col_nx, c_nx, cnt_nx, Y, lane);
+      if (8 * P < cnt_nx) gather_pair64<F, P, ST>(y, cw, col_nx, c_nx, cnt_nx, Y, lane);
     }
     __builtin_amdgcn_sched_barrier(0);
   });
@@ -209,13 +245,11 @@ __device__ __forceinline__ void fused_pass_h(unsigned (&y)[kHT / 4][F / 32], flo
 }  // namespace
 
 // Rows [first, first + count) of the schedule, a team of WPR wavefronts per row, up to 64 WPR nonzeros per row.
-template <int F, int WPR, int BLOCK>
-__global__ __launch_bounds__(BLOCK, F == 64 ? 8 : 4) void als_cg_qhteam_kernel(const int32_t *__restrict__ order, int first, int count,
-                                                                             const int32_t *__restrict__ indptr,
-                                                                             const int32_t *__restrict__ indices,
-                                                                             const float *__restrict__ data, __half *__restrict__ X,
-                                                                             const __half *__restrict__ Y,
-                                                                             const float *__restrict__ A0, int cg_steps) {
+// Registers: the 64-entry tile is F / 2 registers for fp32 storage (128 at f = 128: two "fat" wavefronts per SIMD), F / 4 for fp16.
+template <int F, int WPR, int BLOCK, typename ST>
+__global__ __launch_bounds__(BLOCK, (F == 64 ? 8 : 4) / (int)(sizeof(ST) / 2)) void als_cg_q64team_kernel(
+    const int32_t *__restrict__ order, int first, int count, const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+    const float *__restrict__ data, ST *__restrict__ X, const ST *__restrict__ Y, const float *__restrict__ A0, int cg_steps) {
   constexpr int FC = F / 64, FE = F / 16, T = kHT, WAVES = BLOCK / 64, TEAMS = WAVES / WPR, NJ = F / WPR / 4;
   static_assert(WPR <= WAVES && (F / WPR) % 4 == 0 && NJ <= 4 * kHPairs, "team width");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -322,18 +356,18 @@ __global__ __launch_bounds__(BLOCK, F == 64 ? 8 : 4) void als_cg_qhteam_kernel(c
   };
   bool tile_ready = false;
   int cnt = 0;
-  unsigned y[T / 4][FE / 2];  // the resident tile: 64 entries, two halves per register
+  typename Tile64<ST>::elem y[T / 4][FE / 2];  // the resident tile: 64 entries
   float x[FC];
   kill(x);
   for (int i = i_first; i < count; i += i_step) {
-    __half *xrow = X + (size_t)id0 * F;
+    ST *xrow = X + (size_t)id0 * F;
     if (!tile_ready) {  // first row of the wave, or the previous row ended before its last pass: plain row start
       cnt = ent_cnt;
       ent_col = opaque(ent_col);
       ent_c = __int_as_float(opaque(__float_as_int(ent_c)));
       static_for<kHPairs>([&](auto Pc) {
         constexpr int P = decltype(Pc)::value;
-        if (8 * P < cnt) gather_pair_h<F, P>(y, cw, ent_col, ent_c, cnt, Y, lane);
+        if (8 * P < cnt) gather_pair64<F, P, ST>(y, cw, ent_col, ent_c, cnt, Y, lane);
       });
       slice(b1, e1, k0, ent_cnt);
       fetch_entries64(indices, data, opaque(lane), k0, max(k0 + ent_cnt, b1 + 1), ent_col, ent_c);
@@ -354,7 +388,7 @@ __global__ __launch_bounds__(BLOCK, F == 64 ? 8 : 4) void als_cg_qhteam_kernel(c
     unsigned w = await_operand();
     {
       float acc[FC];
-      fused_pass_h<F, NJ, true, false>(y, cw, cnt, vt, j_begin, A0s, acc, lane, 0, ent_col, ent_c, Y, nullptr, nullptr, 0, 0);
+      fused_pass64<F, NJ, true, false, ST>(y, cw, cnt, vt, j_begin, A0s, acc, lane, 0, ent_col, ent_c, Y, nullptr, nullptr, 0, 0);
       arrive(acc);
     }
     if (leader) {
@@ -373,7 +407,7 @@ __global__ __launch_bounds__(BLOCK, F == 64 ? 8 : 4) void als_cg_qhteam_kernel(c
     w = await_operand();
     for (int it = 0; (w & (kGo | kLast)) == kGo; ++it) {  // all steps but the last
       float acc[FC];
-      fused_pass_h<F, NJ, false, false>(y, cw, cnt, vt, j_begin, A0s, acc, lane, 0, ent_col, ent_c, Y, nullptr, nullptr, 0, 0);
+      fused_pass64<F, NJ, false, false, ST>(y, cw, cnt, vt, j_begin, A0s, acc, lane, 0, ent_col, ent_c, Y, nullptr, nullptr, 0, 0);
       arrive(acc);
       if (leader) {
         collect(Ap);
@@ -405,7 +439,7 @@ __global__ __launch_bounds__(BLOCK, F == 64 ? 8 : 4) void als_cg_qhteam_kernel(c
       int k2, cnt2;
       slice(b2, e2, k2, cnt2);
       if (i + i_step >= count) ent_cnt = 0;  // no next row: nothing to gather
-      fused_pass_h<F, NJ, false, true>(y, cw, cnt, vt, j_begin, A0s, acc, lane, ent_cnt, ent_col, ent_c, Y, indices, data, k2,
+      fused_pass64<F, NJ, false, true, ST>(y, cw, cnt, vt, j_begin, A0s, acc, lane, ent_cnt, ent_col, ent_c, Y, indices, data, k2,
                                        max(k2 + cnt2, b2 + 1));
       cnt = ent_cnt;
       ent_cnt = cnt2;
@@ -431,15 +465,16 @@ __global__ __launch_bounds__(BLOCK, F == 64 ? 8 : 4) void als_cg_qhteam_kernel(c
   }
 }
 
-template <int F, int WPR, int BLOCK>
-static void launch_qhteam(const imp_csr *C, int first, int count, __half *X, const __half *Y, const float *A0, int cg_steps,
-                          const char *name) {
+template <int F, int WPR, int BLOCK, typename ST>
+static void launch_q64team(const imp_csr *C, int first, int count, ST *X, const ST *Y, const float *A0, int cg_steps, const char *name) {
   if (count <= 0) return;
   constexpr int WAVES = BLOCK / 64, TEAMS = WAVES / WPR;
   const size_t lds = ((size_t)F * F + (size_t)WAVES * F + (size_t)TEAMS * F + 2 * kHT * WAVES + 4 * TEAMS) * sizeof(float);
-  auto kern = als_cg_qhteam_kernel<F, WPR, BLOCK>;
+  auto kern = als_cg_q64team_kernel<F, WPR, BLOCK, ST>;
   IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / BLOCK, (160 * 1024) / lds));
+  int per_cu = 0;  // registers decide at f = 128 / fp32 (one 8-wave workgroup per CU), the LDS elsewhere
+  IMP_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, BLOCK, lds));
+  per_cu = std::max(1, per_cu);
   constexpr int kBaseOversub = WPR <= 2 ? 4 : 2;  // as launch_qfteam for the same row classes
   const int grid = std::min((count + TEAMS - 1) / TEAMS, ctx().num_cus * per_cu * std::max(kBaseOversub, ctx().oversub));
   IMP_PROF(name);
@@ -449,21 +484,24 @@ static void launch_qhteam(const imp_csr *C, int first, int count, __half *X, con
 }
 
 // width: wavefronts per row, 1 / 2 / 4 / 8 (rows of up to 64 / 128 / 256 / 512 nonzeros)
-void launch_team_half64(const imp_csr *C, int f, int width, int first, int count, __half *X, const __half *Y, const float *A0,
-                        int cg_steps, const char *name) {
+template <typename ST>
+void launch_team_tile64(const imp_csr *C, int f, int width, int first, int count, ST *X, const ST *Y, const float *A0, int cg_steps,
+                        const char *name) {
   auto run = [&](auto Fc) {
     constexpr int F = decltype(Fc)::value;
     switch (width) {
-      case 8: launch_qhteam<F, 8, 512>(C, first, count, X, Y, A0, cg_steps, name); break;
-      case 4: launch_qhteam<F, 4, 512>(C, first, count, X, Y, A0, cg_steps, name); break;
-      case 2: launch_qhteam<F, 2, 512>(C, first, count, X, Y, A0, cg_steps, name); break;
-      case 1: launch_qhteam<F, 1, 512>(C, first, count, X, Y, A0, cg_steps, name); break;
-      default: throw std::invalid_argument("launch_team_half64: team width");
+      case 8: launch_q64team<F, 8, 512, ST>(C, first, count, X, Y, A0, cg_steps, name); break;
+      case 4: launch_q64team<F, 4, 512, ST>(C, first, count, X, Y, A0, cg_steps, name); break;
+      case 2: launch_q64team<F, 2, 512, ST>(C, first, count, X, Y, A0, cg_steps, name); break;
+      case 1: launch_q64team<F, 1, 512, ST>(C, first, count, X, Y, A0, cg_steps, name); break;
+      default: throw std::invalid_argument("launch_team_tile64: team width");
     }
   };
   if (f == 128) run(idx_t<128>{});
   else if (f == 64) run(idx_t<64>{});
-  else throw std::invalid_argument("launch_team_half64: f must be 64 or 128");
+  else throw std::invalid_argument("launch_team_tile64: f must be 64 or 128");
 }
+template void launch_team_tile64<float>(const imp_csr *, int, int, int, int, float *, const float *, const float *, int, const char *);
+template void launch_team_tile64<__half>(const imp_csr *, int, int, int, int, __half *, const __half *, const float *, int, const char *);
 
 }  // namespace imp

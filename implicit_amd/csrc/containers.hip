@@ -292,6 +292,21 @@ int imp_device_synchronize(void) {
                                     // its rows were re-solved on the device)
   });
 }
+int imp_release_workspaces(void) {
+  return guarded([&] {
+    sync();
+    auto &c = ctx();
+    // scratch the solver paths grow on demand and otherwise keep for the life of the process (a 10 M-row replica padded from
+    // f = 100 to 128 is 5 GB): dropped here, re-allocated by the next call that needs them
+    c.gram_ws = {};
+    c.long_ws = {};
+    c.pad_x = {};
+    c.pad_y = {};
+    c.pad_gram = {};
+    c.cluster_xchg = {};
+    c.cluster_fault_rows = {};
+  });
+}
 int imp_mem_get_info(size_t *free_bytes, size_t *total_bytes) {
   return guarded([&] { IMP_CHECK_HIP(hipMemGetInfo(free_bytes, total_bytes)); });
 }
@@ -318,29 +333,47 @@ int imp_host_csr_transpose(int32_t rows, int32_t cols, int64_t nnz, const int32_
       cut[t] = (int32_t)(std::lower_bound(indptr, indptr + rows + 1, (int32_t)target) - indptr);
       cut[t] = std::min(rows, std::max(cut[t], cut[t - 1]));
     }
+    // a decreasing indptr would send the scatter below out of bounds: checked before anything is indexed through it
+    for (int32_t r = 0; r < rows; ++r)
+      if (indptr[r + 1] < indptr[r]) throw std::invalid_argument("host_csr_transpose: indptr must be non-decreasing (row " + std::to_string(r) + ")");
     std::vector<std::vector<int32_t>> hist(T);
+    for (auto &h : hist) h.assign((size_t)cols, 0);  // allocated HERE: a bad_alloc inside a worker thread would terminate the process
     std::string error;
     std::mutex error_mutex;
     auto parallel = [&](auto &&fn) {
+      // an exception escaping a std::thread body calls std::terminate, and so does destroying a joinable thread: every
+      // body is fenced, every started thread joined, and the first failure is re-thrown on the calling thread
+      auto fenced = [&](int t) {
+        try {
+          fn(t);
+        } catch (const std::exception &e) {
+          std::lock_guard<std::mutex> g(error_mutex);
+          if (error.empty()) error = std::string("host_csr_transpose: ") + e.what();
+        } catch (...) {
+          std::lock_guard<std::mutex> g(error_mutex);
+          if (error.empty()) error = "host_csr_transpose: unknown failure in a worker thread";
+        }
+      };
       std::vector<std::thread> pool;
-      for (int t = 1; t < T; ++t) pool.emplace_back([&, t] { fn(t); });
-      fn(0);
+      pool.reserve((size_t)T);
+      int started = 1;
+      try {
+        for (; started < T; ++started) pool.emplace_back(fenced, started);
+      } catch (...) {  // the system refused another thread: the caller's thread does the remaining shares
+      }
+      fenced(0);
+      for (int t = started; t < T; ++t) fenced(t);
       for (auto &th : pool) th.join();
+      if (!error.empty()) throw std::invalid_argument(error);
     };
     parallel([&](int t) {
       auto &h = hist[t];
-      h.assign((size_t)cols, 0);
       for (int64_t k = indptr[cut[t]]; k < indptr[cut[t + 1]]; ++k) {
         const int32_t c = indices[k];
-        if (c < 0 || c >= cols) {
-          std::lock_guard<std::mutex> g(error_mutex);
-          error = "host_csr_transpose: column index out of range";
-          return;
-        }
+        if (c < 0 || c >= cols) throw std::invalid_argument("column index out of range");
         ++h[c];
       }
     });
-    if (!error.empty()) throw std::invalid_argument(error);
     // column totals -> t_indptr; then every thread's histogram becomes its first output slot per column
     parallel([&](int t) {  // columns split evenly over the threads
       const int32_t c0 = (int32_t)((int64_t)cols * t / T), c1 = (int32_t)((int64_t)cols * (t + 1) / T);

@@ -456,6 +456,11 @@ def set_deferred_sync(on):
     check(lib().imp_set_deferred_sync(1 if on else 0))
 
 
+def release_workspaces():
+    """Free the library's per-device scratch buffers (they are re-allocated on demand); fit() calls it when it returns."""
+    check(lib().imp_release_workspaces())
+
+
 def debug_occupy(workgroups, microseconds):
     """Measurement aid: park `workgroups` spinning workgroups on the device for about `microseconds`."""
     check(lib().imp_debug_occupy(int(workgroups), int(microseconds)))

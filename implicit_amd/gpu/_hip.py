@@ -26,6 +26,7 @@ _SIGNATURES = {
     "imp_debug_occupy": [ctypes.c_int, ctypes.c_int],
     "imp_device_synchronize": [],
     "imp_mem_get_info": [ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)],
+    "imp_release_workspaces": [],
     "imp_host_csr_transpose": [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int],
     "imp_matrix_create": [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, c_void_pp],

@@ -127,6 +127,8 @@ class AlternatingLeastSquares(MatrixFactorizationBase):
                     cb(iteration, time.time() - t0, loss)
         finally:
             gpu.set_deferred_sync(False)
+            if self.factors not in (64, 128, 256):
+                gpu.release_workspaces()  # the zero-padded factor copies: rows x F floats per side, not worth keeping
         progress.close()
         if self.calculate_training_loss:
             log.info("Final training loss %s", loss)
@@ -158,6 +160,8 @@ class AlternatingLeastSquares(MatrixFactorizationBase):
                                            csr=gpu.CSRMatrix, users=users)
         finally:
             backend.close()
+            if self.factors not in (64, 128, 256):
+                gpu.release_workspaces()
         if self.calculate_training_loss:
             # the objective restricted to this rank's user rows (each rank logs its own; there is no global reduction)
             r = self.comm.rank

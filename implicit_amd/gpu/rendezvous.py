@@ -9,6 +9,7 @@ store, so the exchange listens on MASTER_PORT + 1 + IMP_RDZV_PORT_OFFSET (overri
 IMP_RDZV_PORT) or, if that is taken, on one of the 7 ports after it; peers are recognised by a magic + job-token
 handshake (two jobs with overlapping candidate ranges cannot serve each other) and count once they ACK the payload.  No reference counterpart (implicit/gpu/als.cu:169 "TODO: multi-gpu support").
 """
+import errno
 import os
 import socket
 import struct
@@ -105,7 +106,11 @@ def broadcast_bytes(payload, rank, world, timeout=300.0):
     if rank == 0:
         srv, last = None, None
         for port in ports:
-            for host in (addr, ""):  # MASTER_ADDR's interface where this host owns it, every interface otherwise
+            # Every interface by default: MASTER_ADDR may be a host name that resolves to a loopback address ON the master
+            # (Debian maps the host name to 127.0.1.1) while the peers on other nodes resolve it to the routable one -- bound
+            # to the loopback only they would be refused until the timeout.  IMP_RDZV_BIND_ADDR=<ip> restricts the listener
+            # to one interface (single-node jobs on a shared host: 127.0.0.1).
+            for host in ((os.environ["IMP_RDZV_BIND_ADDR"],) if os.environ.get("IMP_RDZV_BIND_ADDR") else ("",)):
                 cand = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
                 cand.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
                 try:
@@ -116,7 +121,7 @@ def broadcast_bytes(payload, rank, world, timeout=300.0):
                 except OSError as e:  # taken (or not a local address): next choice
                     last = e
                     cand.close()
-                    if getattr(e, "errno", None) == 98:  # EADDRINUSE: the wildcard bind would fail alike
+                    if getattr(e, "errno", None) == errno.EADDRINUSE:
                         break
             if srv is not None:
                 break

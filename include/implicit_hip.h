@@ -68,6 +68,10 @@ int imp_set_deferred_sync(int on);
 int imp_debug_occupy(int workgroups, int microseconds);
 int imp_device_synchronize(void);
 int imp_mem_get_info(size_t *free_bytes, size_t *total_bytes);
+/* NEW: frees the per-device scratch buffers the solver paths grow on demand (split-K gramian partials, long-row CG state, the
+ * zero-padded copies other factor counts ride the f = 64 / 128 / 256 kernels on, cluster exchange slots); the next call that
+ * needs one allocates it again.  fit() calls it when it returns. */
+int imp_release_workspaces(void);
 const char *imp_version(void);
 
 /* NEW, host-side helper (no device work, usable without a GPU): stable parallel transpose of a CSR matrix with int32 offsets

@@ -139,3 +139,8 @@ def test_threaded_transpose_equals_scipy(threads):
     bad.has_canonical_format = True
     with pytest.raises(ValueError):
         transpose_csr(bad, threads=threads)
+    bent = synthetic_csr(300, 200, 4000, seed=4)                    # a decreasing indptr: refused before anything is scattered
+    bent.indptr[10], bent.indptr[11] = bent.indptr[11], bent.indptr[10]
+    bent.has_canonical_format = True
+    with pytest.raises(ValueError):
+        transpose_csr(bent, threads=threads)
