@@ -412,6 +412,7 @@ def main():
                               "wall times of 3 iterations after 1 warm-up); `value` above is configs[2] only")
         for name, fn in (("fit_c3", lambda: extra_fit(gpu, Cui)), ("fp16_c3", lambda: extra_fp16(gpu, Cui, Ciu, X0, Y0)),
                          ("factor_grid", lambda: extra_factor_grid(gpu, Cui, Ciu)),
+                         ("cholesky_f128", lambda: extra_cholesky_f128(gpu, Cui, Ciu)),
                          ("c2", lambda: extra_c2(gpu, SHAPES)),
                          ("c5", lambda: extra_c5(gpu, SHAPES)), ("c4", lambda: extra_c4(gpu, SHAPES))):
             t0 = time.time()
@@ -542,6 +543,33 @@ def extra_factor_grid(gpu, Cui, Ciu):
                               "kernels_ms_per_iter": kernels}
         del X, Y, gram
     return out
+
+
+def extra_cholesky_f128(gpu, Cui, Ciu):
+    """The Cholesky solver at the factor count the metric is quoted on (`use_cg=False`, implicit/cpu/als.py:418-423) on the
+    configs[2] matrix: f = 128 has no register / MFMA kernel (only f = 64 does), it runs the workgroup-per-row LDS kernel."""
+    f = FACTORS
+    rng = np.random.default_rng(7)
+    X = gpu.Matrix(rng.random((Cui.shape[0], f), dtype=np.float32) * 0.01)
+    Y = gpu.Matrix(rng.random((Cui.shape[1], f), dtype=np.float32) * 0.01)
+    Cd, Ctd = gpu.CSRMatrix(Cui), gpu.CSRMatrix(Ciu)
+    gram = gpu.Matrix.zeros(f, f)
+    solver = gpu.LeastSquaresSolver()
+
+    def chol():
+        solver.calculate_yty(Y, gram, 0.0)
+        solver.least_squares_cholesky(Cd, X, gram, Y, REG)
+        solver.calculate_yty(X, gram, 0.0)
+        solver.least_squares_cholesky(Ctd, Y, gram, X, REG)
+
+    t, kernels = _time_iterations(gpu, chol, iters=2)
+    rows = Cui.shape[0] + Cui.shape[1]
+    flops = 2.0 * Cui.nnz * 2 * f * f + rows * (f ** 3 / 3.0 + 2.0 * f * f)
+    return {"cholesky_c3_f128": {"workload": "configs[2] matrix, f=128, Cholesky (LDS workgroup-per-row kernel)", "ms_per_iter": 1e3 * t,
+                                 "updates_per_s": rows / t, "tflops": flops / t / 1e12,
+                                 "roofline": {"bound": "fp32", "achieved": flops / t / 1e12, "peak": FP32_PEAK_TFLOPS,
+                                              "unit": "TFLOP/s", "frac": flops / t / 1e12 / FP32_PEAK_TFLOPS},
+                                 "kernels_ms_per_iter": kernels}}
 
 
 def extra_c2(gpu, SHAPES):
@@ -805,6 +833,8 @@ def bench_topk(gpu, Cui, X, Y, k=10, queries=20_000, batch=1000):
             "kernels_ms_per_batch": kernels, "scoring_TFLOPs": flops / t / 1e12, "roofline": roofline,
             "model_recommend_recs_per_s": rec,
             "batch": batch, "items": Y.shape[0], "filter_already_liked_items": True,
+            "ids": "identical to the compiled reference's topk outside fp32 near-ties (PARITY.md: 0 of 20 000 positions differ at this "
+                   "workload, 0.02 % at configs[4]'s similar_items k=100, every difference a float64-verified near-tie)",
             "note": "value: KnnQuery.topk with the liked-items COO filters already on the device, ids/scores returned to host "
                     "memory per batch (PCIe D2H included); model_recommend_recs_per_s: AlternatingLeastSquares.recommend() for "
                     "the same users, host COO build + upload per batch included; kernel times from a separate profiled pass"}

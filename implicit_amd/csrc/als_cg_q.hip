@@ -424,7 +424,7 @@ template <int F, typename T> static void run_classes_q(const imp_csr *C, T *X, c
         if (mask & bit) launch_team_tile64<T>(C, F, width64, lo, hi - lo, X, Y, A0, cg_steps, name);
         else launch_team_fused<T>(C, F, width32, lo, hi - lo, X, Y, A0, cg_steps, name);
       };
-      cls(1, 8, 16, b[1], b[2], "als_cg_team16_rows");  // names: the row class
+      if (!team16_as_cluster()) cls(1, 8, 16, b[1], b[2], "als_cg_team16_rows");  // names: the row class
       cls(2, 4, 8, b[2], b[3], "als_cg_team8_rows");
       cls(4, 2, 4, b[3], b[4], "als_cg_team4_rows");
       cls(8, 1, 2, b[4], b[5], "als_cg_team2_rows");

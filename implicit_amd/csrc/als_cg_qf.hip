@@ -3,17 +3,17 @@
 //
 // Arithmetic contract: the oracle's CG (implicit/cpu/_als.pyx:152-248).
 //
-// What bounds these kernels (profiles/micro/valu_rate.hip, profiles/r04_micro_valu_rate.txt): a SIMD of this part retires
-// one vector instruction per ~3.1 ns whatever its kind (v_fma_f32, v_pk_fma_f32, DPP adds alike: 0.32 G wave-instructions
-// per second and SIMD, 330 G/s for the chip), and the round-2 team kernels executed 1.03 G of them per C3 iteration for the
-// mid-row classes -- 3.1 ms of pure issue time against the 3.3 ms measured.  They were instruction-issue bound at 100 %,
-// not at the 50 % round 2 derived from a 4-cycle issue model; hiding latencies (fused passes, rolling gathers: built first,
-// kept below) therefore changed nothing by itself.  Only ~55 % of those instructions were the FMAs of the dense part and
-// of the tile; the rest was per-wavefront bookkeeping, REPLICATED in every wavefront of a team:
+// What the round-2 team kernels spent (profiles/micro/valu_rate.hip, profiles/r04_micro_valu_rate.txt; DESIGN.md section 4.1 has
+// the full picture): saturated, a SIMD retires a plain vector instruction every 2.3 cycles and a packed FMA, a DPP form or an
+// SGPR-operand form every 4.1-4.4; one wave alone issues only every 5.5-6 cycles.  The round-2 kernels executed 1.03 G vector
+// instructions per C3 iteration for the mid-row classes, and only ~55 % of them were the FMAs of the dense part and of the tile;
+// the rest was per-wavefront bookkeeping, REPLICATED in every wavefront of a team:
 //   - the CG scalars (two wave-wide dot reductions, two IEEE divisions, the x / r / p updates) -- every wave of a team
 //     did the identical arithmetic on identical bits;
 //   - the operand's expansion from the compact to the quarter layout (6 v_permlane swaps + 12 register copies per pass)
 //     and the sum of the team's partial vectors in every wave.
+// (A first version of the micro-benchmark, run on a box in a low-power state, read 7.5 cycles for everything and led to the
+// conclusion "100 % issue bound"; the instruction count was worth cutting anyway: 808 M now.)
 // This kernel gives that work to ONE wavefront per team (the leader, sub == 0) and turns the rest into LDS traffic, which
 // has issue slots of its own:
 //   * the leader alone sums the team's partial vectors, does the CG update and PUBLISHES the next operand in LDS (natural

@@ -103,10 +103,18 @@ bool prof_enabled();
 #define IMP_PROF(name) ::imp::ProfScope _prof_scope_(name)
 
 // ---- device storage ---------------------------------------------------------------------------
+struct Context;
 struct Storage {
   void *ptr = nullptr;
   size_t bytes = 0;
   bool owned = true;
+  // small blocks (<= kSmallMax) come from, and return to, their device's free lists instead of hipMalloc / hipFree: a
+  // recommend() batch creates and destroys an IntVector and a COO filter (20-50 us of allocator time per object, hipFree
+  // synchronises).  Safe without a synchronisation: everything that touches such a block runs on the ONE library stream of
+  // its device, so a recycled block's next use is ordered behind its last.
+  Context *home = nullptr;
+  int size_class = -1;
+  static constexpr size_t kSmallMax = (size_t)4 << 20;
   Storage(size_t bytes_, bool zero);
   Storage(void *foreign) : ptr(foreign), owned(false) {}
   ~Storage();
@@ -144,6 +152,8 @@ struct Context {
   bool deferred = false;
   hipStream_t occupy_stream = nullptr;  // imp_debug_occupy
   std::recursive_mutex mutex;
+  std::mutex small_mutex;                  // the free lists below (a Storage may die on a thread that holds another device's lock)
+  std::vector<void *> small_free[24];      // [log2 size]: recycled device blocks of 256 B .. 4 MB (Storage)
   DeviceArray<float> gram_ws;     // split-K partial gramians (gramian.hip)
   DeviceArray<float> long_ws;     // partial vectors / CG state of the long rows (als_cg.hip)
   DeviceArray<float> pad_x, pad_y, pad_gram;  // zero-padded copies for factor counts that ride the f = 64 / 128 kernels (als_cg.hip)

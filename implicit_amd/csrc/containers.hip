@@ -131,12 +131,36 @@ static void prof_flush() {
 // ---- storage ------------------------------------------------------------------------------------
 Storage::Storage(size_t bytes_, bool zero) : bytes(bytes_) {
   if (bytes) {
-    IMP_CHECK_HIP(hipMalloc(&ptr, bytes));
+    if (bytes <= kSmallMax) {
+      size_class = 8;
+      while (((size_t)1 << size_class) < bytes) ++size_class;
+      home = &ctx();
+      {
+        std::lock_guard<std::mutex> g(home->small_mutex);
+        auto &list = home->small_free[size_class];
+        if (!list.empty()) {
+          ptr = list.back();
+          list.pop_back();
+        }
+      }
+      if (!ptr) IMP_CHECK_HIP(hipMalloc(&ptr, (size_t)1 << size_class));
+    } else {
+      IMP_CHECK_HIP(hipMalloc(&ptr, bytes));
+    }
     if (zero) IMP_CHECK_HIP(hipMemsetAsync(ptr, 0, bytes, stream()));
   }
 }
 Storage::~Storage() {
-  if (owned && ptr) (void)hipFree(ptr);
+  if (!owned || !ptr) return;
+  if (home) {
+    std::lock_guard<std::mutex> g(home->small_mutex);
+    auto &list = home->small_free[size_class];
+    if (list.size() < 32) {
+      list.push_back(ptr);
+      return;
+    }
+  }
+  (void)hipFree(ptr);
 }
 
 // ---- small kernels ------------------------------------------------------------------------------
@@ -305,6 +329,11 @@ int imp_release_workspaces(void) {
     c.pad_gram = {};
     c.cluster_xchg = {};
     c.cluster_fault_rows = {};
+    std::lock_guard<std::mutex> g(c.small_mutex);
+    for (auto &list : c.small_free) {
+      for (void *p : list) (void)hipFree(p);
+      list.clear();
+    }
   });
 }
 int imp_mem_get_info(size_t *free_bytes, size_t *total_bytes) {
