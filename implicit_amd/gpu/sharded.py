@@ -428,7 +428,8 @@ def bench(args, gpu, shapes, factors, reg, cg_steps, roofline_fn=None):
     fence()
     gpu.Profiler.enable(False)
     kernels = {name: gpu.Profiler.get(name)[0] for name in gpu.Profiler.names()}
-    compute_ms = float(sum(ms for name, ms in kernels.items() if not name.startswith("rccl")))
+    # `als_cg_half_sweep` brackets the kernels of a least_squares call: an umbrella, not a kernel of its own
+    compute_ms = float(sum(ms for name, ms in kernels.items() if not name.startswith("rccl") and name != "als_cg_half_sweep"))
     step_s = elapsed / args.steps
     result = {
         "metric": "ALS user+item updates/sec per iteration (factors=128)",
@@ -458,6 +459,12 @@ def bench(args, gpu, shapes, factors, reg, cg_steps, roofline_fn=None):
         "rank0_compute_ms_per_step": compute_ms,
         "rank0_exposed_exchange_ms_per_step": max(0.0, 1e3 * step_s - compute_ms),
         "exchange_GB_received_per_rank_per_step": 4.0 * factors * (users_total + items_total) * (world - 1) / world / 1e9,
+        # (B) is what runs -- rows of both sides sharded, solved rows all-gathered; (A) is north_star's
+        # literal scheme -- users sharded, the item half sweep as a distributed CG with a ring all-reduce of the I x f buffer per
+        # pass -- not built (every pass would re-gather X from HBM and wait for a collective that cannot overlap)
+        "exchange_schemes_GB_per_rank_per_step": {
+            "B_built_allgather_of_solved_rows": 4.0 * factors * (users_total + items_total) * (world - 1) / world / 1e9,
+            "A_not_built_allreduce_of_item_factors_per_cg_pass": (1 + cg_steps) * 2.0 * 4.0 * factors * items_total * (world - 1) / world / 1e9},
         "oversubscription": int(os.environ.get("IMP_SHARD_OVERSUB", "4")) if world > 1 else 1,
         "rank0_shard": {"user_rows": int(Cui.shape[0]), "item_rows": int(Ciu.shape[0]), "user_nnz": int(Cui.nnz),
                         "item_nnz": int(Ciu.nnz)},
