@@ -450,6 +450,55 @@ __global__ __launch_bounds__(256, 3) void als_cholesky_f64_kernel(const int32_t 
     // pipeline: the chunks of row k+1 that do not contain column k are already final, so their reads are issued right
     // after step k's dot product and fly during its pivot chain (v_readlane -> v_rsq -> Newton -> column scale -> store);
     // only the chunk holding column k is read after the store.  lrow is free by then: no extra registers.
+#ifndef IMP_CHOL_COLUMNWISE
+    // Round 4: four columns per step.  Column by column (the form kept below for A/B builds) the row's critical path was 64
+    // times [dot product -> pivot chain -> LDS store of the column -> LDS read of the next row's last chunk]: an LDS round trip
+    // per column that nothing covers at three waves per SIMD (IMP_CHOL_STATS: 34.8 K of a 50-nonzero row's 60 K cycles).  A
+    // block of columns k0 .. k0 + 3 needs rows k0 .. k0 + 3 of L only in columns < k0, all final when the block starts: their
+    // chunks are streamed as broadcast ds_read_b128, four rows at a time into 16 accumulators (the same products, the same
+    // four running sums per column as before); the 4 x 4 diagonal block is then factorised in registers -- the three
+    // sub-diagonal entries a pivot step needs travel by v_readlane, not through the image -- and the four new columns go to
+    // the image in ONE ds_write_b128 per lane.  16 LDS round trips per row instead of 64; the forward substitution rides
+    // along as before.
+    static_for<F / 4>([&](auto bc) {
+      constexpr int k0 = 4 * decltype(bc)::value;
+      f32x2 acc[4][2];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c][0] = acc[c][1] = f32x2{0.f, 0.f};
+      static_for<k0 / 4>([&](auto cc) {
+        constexpr int j = 4 * decltype(cc)::value;
+        float4 l[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) l[c] = *reinterpret_cast<const float4 *>(As + chol_rowoff(k0 + c) + j);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          acc[c][0] = __builtin_elementwise_fma(A2[j / 2], (f32x2){l[c].x, l[c].y}, acc[c][0]);
+          acc[c][1] = __builtin_elementwise_fma(A2[j / 2 + 1], (f32x2){l[c].z, l[c].w}, acc[c][1]);
+        }
+      });
+      float t[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) t[c] = A(k0 + c) - ((acc[c][0].x + acc[c][0].y) + (acc[c][1].x + acc[c][1].y));
+      static_for<4>([&](auto cc) {
+        constexpr int c = decltype(cc)::value, k = k0 + c;
+        const float d = bcast_lane(t[c], k);  // pivot
+        if (!(d > 0.f)) ok = false;
+        const float r0 = __builtin_amdgcn_rsqf(d);  // 1 / sqrt(d): v_rsq_f32 + one Newton step (see the column-wise form)
+        const float inv = fmaf(r0, fmaf(-0.5f * d * r0, r0, 0.5f), r0);
+        const float lik = t[c] * inv;  // L[i][k] for i >= k
+        A(k) = lik;
+#pragma unroll
+        for (int c2 = c + 1; c2 < 4; ++c2) t[c2] = fmaf(-lik, bcast_lane(lik, k0 + c2), t[c2]);  // - L[i][k] L[k0+c2][k]
+        const float zk = bcast_lane(b, k) * inv;  // z_k = b_k / L_kk; the forward substitution rides along
+        b = lane_v == k ? zk : (lane_v > k ? fmaf(-lik, zk, b) : b);
+        dinv = lane_v == k ? inv : dinv;
+        asm volatile("" : "+v"(dinv));  // here and now (see the column-wise form)
+      });
+      // rows k0 and below get their four new columns; a row inside the block writes words beyond its diagonal into its own
+      // padding (rows are padded to whole 4-float chunks), which nothing reads
+      if (lane_v >= k0) *reinterpret_cast<float4 *>(As + my_off + k0) = make_float4(A(k0), A(k0 + 1), A(k0 + 2), A(k0 + 3));
+    });
+#else
     float4 lrow[F / 4];
     static_for<F>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
@@ -491,6 +540,7 @@ __global__ __launch_bounds__(256, 3) void als_cholesky_f64_kernel(const int32_t 
       // instead of 172: the difference between two and three waves per SIMD)
       asm volatile("" : "+v"(dinv));
     });
+#endif
     tick(3);
     if (!ok) {
       if (lane == 0) atomicMin(failed_row, (unsigned long long)u);
