@@ -677,7 +677,9 @@ bool cg_native_half(int f) { return f == 64 || f == 128; }
 // the gramian extended by a unit diagonal block, residual, search direction and iterate stay zero in the padded components
 // (b = 0, x0 = 0 there), and every dot product only gains exact zeros.  Cost: one padded copy of Y and of the solved rows of X
 // in, the rows of X out -- (R_y + 2 R_x)(f + F) 4 bytes per half sweep, ~0.2 ms at configs[2] -- and the workspaces.
-__global__ void pad_rows_kernel(const float *__restrict__ src, float *__restrict__ dst, size_t rows, int f, int F) {
+__global__ void pad_rows_kernel(const float *__restrict__ src, float *__restrict__ dst, size_t rows, int f, int F,
+                                const int *__restrict__ skip = nullptr) {
+  if (skip && *skip) return;  // the padded copy is still the one this call needs (pad_check_kernel)
   const size_t n = rows * (size_t)F;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const size_t r = i / F;
@@ -692,6 +694,18 @@ __global__ void unpad_rows_kernel(const float *__restrict__ src, float *__restri
     dst[i] = src[r * F + (i - r * f)];
   }
 }
+// *same = 1 iff the f x f gramian of this call equals, bit for bit, the top-left block of the padded gramian of the previous
+// one (single workgroup; the flag starts at 1 and any differing element clears it)
+__global__ void pad_check_kernel(const float *__restrict__ gram, const float *__restrict__ padded, int f, int F, int *same) {
+  if (threadIdx.x == 0) *same = 1;
+  __syncthreads();
+  bool differ = false;
+  for (int i = threadIdx.x; i < f * f; i += blockDim.x) {
+    const int r = i / f, c = i - r * f;
+    differ |= __float_as_uint(gram[i]) != __float_as_uint(padded[(size_t)r * F + c]);
+  }
+  if (differ) *same = 0;
+}
 __global__ void pad_gram_kernel(const float *__restrict__ src, float *__restrict__ dst, int f, int F) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < F * F; i += gridDim.x * blockDim.x) {
     const int r = i / F, c = i - r * F;
@@ -704,12 +718,27 @@ static void least_squares_cg_padded(const imp_csr *C, imp_matrix *X, const imp_m
   auto &c = ctx();
   const size_t rx = (size_t)C->rows, ry = Y->rows;
   if (c.pad_x.size < rx * F) c.pad_x.alloc(rx * F);
-  if (c.pad_y.size < ry * F) c.pad_y.alloc(ry * F);
+  if (c.pad_y.size < ry * F) {
+    c.pad_y_src = nullptr;  // the old copy goes with its buffer (before the alloc: freeing it reports a write to that memory)
+    c.pad_y.alloc(ry * F);
+  }
   if (c.pad_gram.size < (size_t)F * F) c.pad_gram.alloc((size_t)F * F);
   auto grid = [&](size_t n) { return (int)std::max<size_t>(1, std::min<size_t>((n + 255) / 256, (size_t)c.num_cus * 16)); };
   {
     IMP_PROF("pad_factors");
-    if (ry) pad_rows_kernel<<<grid(ry * F), 256, 0, stream()>>>(Y->f32(), c.pad_y.data(), ry, f, F);
+    // The padded copy of Y is re-used when this call solves against the SAME matrix under the SAME gramian as the previous
+    // one -- the K row chunks of a sharded half sweep (4 redundant copies of a 10 M-row replica otherwise).  Same address, shape
+    // and factor counts are checked here; "same contents" is decided on the device, with no host wait, through the gramian:
+    // whoever changes Y recomputes YtY (the solve is meaningless otherwise), so a gramian equal bit for bit to the one the copy
+    // was made under vouches for it.  The flag is read by the pad kernel itself, which then returns at once.
+    const int *skip = nullptr;
+    if (ry && c.pad_y_src == Y->data && c.pad_y_rows == ry && c.pad_y_f == f && c.pad_y_F == F) {
+      if (c.pad_same.size < 1) c.pad_same.alloc(1);
+      pad_check_kernel<<<1, 1024, 0, stream()>>>(YtY->f32(), c.pad_gram.data(), f, F, c.pad_same.data());
+      skip = c.pad_same.data();
+    }
+    if (ry) pad_rows_kernel<<<grid(ry * F), 256, 0, stream()>>>(Y->f32(), c.pad_y.data(), ry, f, F, skip);
+    c.pad_y_src = Y->data, c.pad_y_rows = ry, c.pad_y_f = f, c.pad_y_F = F;
     if (rx) pad_rows_kernel<<<grid(rx * F), 256, 0, stream()>>>(X->f32(), c.pad_x.data(), rx, f, F);
     pad_gram_kernel<<<grid((size_t)F * F), 256, 0, stream()>>>(YtY->f32(), c.pad_gram.data(), f, F);
     IMP_CHECK_HIP(hipGetLastError());
@@ -725,6 +754,7 @@ static void least_squares_cg_padded(const imp_csr *C, imp_matrix *X, const imp_m
 }
 
 void least_squares_cg(const imp_csr *C, imp_matrix *X, const imp_matrix *YtY, const imp_matrix *Y, int cg_steps) {
+  note_device_write(X->data, (size_t)C->rows * X->cols * X->itemsize);  // the rows this call solves
   // one event pair around ALL launches of the half sweep (every row class): what bench.py's whole-step `roofline` is timed on
   IMP_PROF("als_cg_half_sweep");
   const int f = (int)X->cols;

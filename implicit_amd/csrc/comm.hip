@@ -75,6 +75,7 @@ int imp_comm_destroy(imp_comm *c) {
 // shard on each link exactly once and all links work at the same time -- a ring would pipe every shard through the
 // neighbours' links instead.
 static void exchange_rows(imp_comm *c, imp_matrix *full, const int64_t *row_lo, const int64_t *row_hi, hipStream_t on) {
+  note_device_write(full->data, full->bytes());
   const size_t row_bytes = full->cols * full->itemsize;
   char *base = reinterpret_cast<char *>(full->data);
   const size_t mine = (size_t)(row_hi[c->rank] - row_lo[c->rank]) * row_bytes;
@@ -91,6 +92,7 @@ static void exchange_rows(imp_comm *c, imp_matrix *full, const int64_t *row_lo, 
 int imp_comm_allreduce_sum(imp_comm *c, imp_matrix *m) {
   return guarded([&] {
     if (m->itemsize != 4) throw std::invalid_argument("allreduce_sum needs a float32 matrix");
+    note_device_write(m->data, m->bytes());
     IMP_PROF("rccl_allreduce");
     IMP_CHECK_NCCL(ncclAllReduce(m->data, m->data, m->rows * m->cols, ncclFloat, ncclSum, c->comm, stream()));
     sync_call();
@@ -114,6 +116,7 @@ int imp_comm_alltoall_rows(imp_comm *c, const imp_matrix *send, const int64_t *s
     }
     if (send_hi[c->rank] - send_lo[c->rank] != recv_hi[c->rank] - recv_lo[c->rank])
       throw std::invalid_argument("alltoall_rows: the piece a rank keeps must have the same size on both sides");
+    note_device_write(recv->data, recv->bytes());
     IMP_PROF("rccl_alltoall_rows");
     const char *sbase = reinterpret_cast<const char *>(send->data);
     char *rbase = reinterpret_cast<char *>(recv->data);

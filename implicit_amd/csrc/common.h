@@ -156,7 +156,13 @@ struct Context {
   std::vector<void *> small_free[24];      // [log2 size]: recycled device blocks of 256 B .. 4 MB (Storage)
   DeviceArray<float> gram_ws;     // split-K partial gramians (gramian.hip)
   DeviceArray<float> long_ws;     // partial vectors / CG state of the long rows (als_cg.hip)
-  DeviceArray<float> pad_x, pad_y, pad_gram;  // zero-padded copies for factor counts that ride the f = 64 / 128 kernels (als_cg.hip)
+  DeviceArray<float> pad_x, pad_y, pad_gram;  // zero-padded copies for factor counts that ride the f = 64 / 128 / 256 kernels (als_cg.hip)
+  // which matrix pad_y currently holds a padded copy of (als_cg.hip least_squares_cg_padded): the chunks of a sharded half sweep
+  // solve against the same Y, one padded copy serves them all
+  const void *pad_y_src = nullptr;
+  size_t pad_y_rows = 0;
+  int pad_y_f = 0, pad_y_F = 0;
+  DeviceArray<int> pad_same;  // device flag: the gramian of this call equals the one pad_y was made under
   DeviceArray<double> loss_buf;   // 4 accumulators of the loss kernel (solver.hip)
   DeviceArray<unsigned long long> chol_failed;  // smallest failing row of a Cholesky sweep (als_cholesky.hip)
   DeviceArray<float> barrier_word;              // operand of the RCCL barrier (comm.hip)
@@ -165,6 +171,15 @@ struct Context {
   DeviceArray<unsigned> cluster_fault_rows;      // rows a faulted cluster left to the fix-up kernel; their count sits behind the exchange slots (als_cg_cluster.hip)
 };
 inline hipStream_t stream() { return ctx().stream; }
+// a C-ABI entry point is about to write `bytes` at `dst` through the library: a padded copy of Y made from memory it overlaps
+// (least_squares_cg_padded) is no longer to be trusted
+inline void note_device_write(const void *dst, size_t bytes) {
+  auto &c = ctx();
+  if (!c.pad_y_src) return;
+  const char *a = static_cast<const char *>(dst), *b = static_cast<const char *>(c.pad_y_src);
+  const size_t b_bytes = c.pad_y_rows * (size_t)c.pad_y_f * sizeof(float);
+  if (a < b + b_bytes && b < a + bytes) c.pad_y_src = nullptr;
+}
 
 }  // namespace imp
 

@@ -152,6 +152,10 @@ Storage::Storage(size_t bytes_, bool zero) : bytes(bytes_) {
 }
 Storage::~Storage() {
   if (!owned || !ptr) return;
+  try {
+    note_device_write(ptr, bytes);  // the memory is about to be re-used for something else
+  } catch (...) {
+  }
   if (home) {
     std::lock_guard<std::mutex> g(home->small_mutex);
     auto &list = home->small_free[size_class];
@@ -326,6 +330,7 @@ int imp_release_workspaces(void) {
     c.long_ws = {};
     c.pad_x = {};
     c.pad_y = {};
+    c.pad_y_src = nullptr;
     c.pad_gram = {};
     c.cluster_xchg = {};
     c.cluster_fault_rows = {};
@@ -524,6 +529,7 @@ int imp_matrix_assign_rows(imp_matrix *m, const imp_intvector *rowids, const imp
     // model's partial_fit_* stays on the device
     if (other->itemsize != m->itemsize) throw std::invalid_argument("dtype mismatch for Matrix::assign_rows");
     size_t total = other->rows * other->cols;
+    note_device_write(m->data, m->bytes());
     if (total) {
       IMP_PROF("scatter_rows");
       if (m->itemsize == 4)
@@ -585,6 +591,7 @@ int imp_matrix_to_host(const imp_matrix *m, void *host_out) {
 
 int imp_matrix_from_host(imp_matrix *m, const void *host_in) {
   return guarded([&] {
+    note_device_write(m->data, m->bytes());
     if (m->bytes()) IMP_CHECK_HIP(hipMemcpyAsync(m->data, host_in, m->bytes(), hipMemcpyHostToDevice, stream()));
     sync();
   });
@@ -596,6 +603,7 @@ int imp_matrix_copy_rows(imp_matrix *dst, size_t dst_row, const imp_matrix *src,
       throw std::invalid_argument("copy_rows: the two matrices must have rows of the same width and itemsize");
     if (dst_row + rows > dst->rows || src_row + rows > src->rows) throw imp::out_of_range_error("copy_rows: row range out of bounds");
     const size_t row_bytes = dst->cols * dst->itemsize;
+    note_device_write(static_cast<char *>(dst->data) + dst_row * row_bytes, rows * row_bytes);
     if (rows && row_bytes)
       IMP_CHECK_HIP(hipMemcpyAsync(static_cast<char *>(dst->data) + dst_row * row_bytes,
                                    static_cast<const char *>(src->data) + src_row * row_bytes, rows * row_bytes,

@@ -243,3 +243,49 @@ def test_more_than_1024_factors_is_an_error_like_the_reference(gpu):
     X, Y, gram = gpu.Matrix.zeros(10, f), gpu.Matrix.zeros(10, f), gpu.Matrix.zeros(f, f)
     with pytest.raises(ValueError):
         gpu.LeastSquaresSolver().least_squares(gpu.CSRMatrix(C), X, gram, Y, 3)
+
+
+def test_padded_copy_of_y_is_reused_only_while_it_is_valid(gpu, oracle):
+    """f = 100 rides the f = 128 kernels on a zero-padded copy of Y.  The row chunks of a half sweep solve against the same Y
+    under the same gramian: the copy is made once (decided on the device through the gramian, als_cg.hip).  It must NOT
+    survive a write to Y through the library, nor a different gramian."""
+    f = 100
+    C = synthetic_csr(2400, 900, 60_000, seed=41, neg_frac=0.05, empty_frac=0.02)
+    rng = np.random.default_rng(5)
+    X0 = rng.random((C.shape[0], f), dtype=np.float32) * 0.2 - 0.1
+    Y0 = rng.random((C.shape[1], f), dtype=np.float32) * 0.2 - 0.1
+    solver = gpu.LeastSquaresSolver()
+    Yd, gram = gpu.Matrix(Y0), gpu.Matrix.zeros(f, f)
+    solver.calculate_yty(Yd, gram, 0.05)
+
+    def oracle_rows(Y, rows=slice(None)):
+        want = X0[rows].copy()
+        oracle.least_squares_cg(C[rows], want, Y, 0.05, cg_steps=3, YtY=oracle.gramian(Y) + np.float32(0.05) * np.eye(f, dtype=np.float32))
+        return want
+
+    # three chunks against one Y: the second and third call find the copy in place
+    Xd = gpu.Matrix(X0)
+    cuts = [0, 800, 1600, 2400]
+    gpu.Profiler.reset()
+    gpu.Profiler.enable(True)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        solver.least_squares(gpu.CSRMatrix(C[a:b]), Xd[a:b], gram, Yd, 3)
+    gpu.Profiler.enable(False)
+    assert rel(Xd.to_numpy(), oracle_rows(Y0)) < TOL
+    # Y rewritten in place through the library, gramian recomputed: the copy is remade
+    Y1 = (Y0 * 0.5 + 0.03).astype(np.float32)
+    Yd.copy_from_numpy(Y1)
+    solver.calculate_yty(Yd, gram, 0.05)
+    Xd = gpu.Matrix(X0)
+    solver.least_squares(gpu.CSRMatrix(C), Xd, gram, Yd, 3)
+    assert rel(Xd.to_numpy(), oracle_rows(Y1)) < TOL
+    # Y rewritten, the caller's gramian NOT recomputed (a stale gramian is the caller's business -- the factors used must
+    # still be the ones in Y now): same result as a fresh solver state given the same (Y, gramian) pair
+    Y2 = (Y0 * 0.25 - 0.01).astype(np.float32)
+    Yd.copy_from_numpy(Y2)
+    Xa = gpu.Matrix(X0)
+    solver.least_squares(gpu.CSRMatrix(C), Xa, gram, Yd, 3)
+    fresh_Y, fresh_gram = gpu.Matrix(Y2), gpu.Matrix(gram.to_numpy())
+    Xb = gpu.Matrix(X0)
+    solver.least_squares(gpu.CSRMatrix(C), Xb, fresh_gram, fresh_Y, 3)
+    np.testing.assert_array_equal(Xa.to_numpy(), Xb.to_numpy())
