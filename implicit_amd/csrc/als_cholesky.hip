@@ -137,6 +137,254 @@ __global__ __launch_bounds__(256) void als_cholesky_kernel(const int32_t *__rest
 }
 
 
+// ---- round 4: the same workgroup-per-row scheme with REGISTER BLOCKS and PANELS -------------------------------------------------
+// The kernel above meets a workgroup barrier three times per column and pays 16 LDS reads for 8 FMAs in its A-build: 546 ms per
+// configs[2]-shaped iteration at f = 128, 0.02 of the fp32 peak -- 400 barrier phases of ~2 K cycles per row.  Here:
+//   * A-build: a thread owns up to four 4 x 4 blocks of the lower triangle and keeps them in registers across ALL tiles of the
+//     row (two 16-byte LDS reads per 16 FMAs), the triangle is written once;
+//   * factorisation in panels of 8 columns: wavefront 0 alone factors the panel (no barrier inside: a wave's LDS operations
+//     execute in order; lane l owns rows k0 + l, k0 + l + 64, ...) and leaves a dense, aligned copy L[., k0 .. k0+7] in a side
+//     buffer; all four waves then apply the rank-8 update to the trailing triangle block by block from that copy (8 LDS reads
+//     of 16 bytes per 128 FMAs) -- two barriers per PANEL;
+//   * the augmented row f (b^T -> z^T) rides along as before, the back substitution is unchanged.
+// Arithmetic: the same products, panel by panel instead of column by column (association of the trailing sums differs).
+constexpr int kCholPanel = 8;
+template <bool PACKED>
+__global__ __launch_bounds__(256) void als_cholesky_blocked_kernel(const int32_t *__restrict__ order, int first, int count,
+                                                                   const int32_t *__restrict__ indptr,
+                                                                   const int32_t *__restrict__ indices,
+                                                                   const float *__restrict__ data, float *__restrict__ X,
+                                                                   const float *__restrict__ Y, const float *__restrict__ YtY,
+                                                                   int f, float reg, int lda, unsigned long long *failed_row) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int m = f + 1;                         // rows of the augmented triangle (row f = b^T -> z^T), f columns
+  const int nbr = (m + 3) >> 2, nbc = (f + 3) >> 2;  // 4 x 4 blocks
+  const int FS = 4 * nbc, US = 4 * nbr;        // padded strides of the staged tile
+  float *A = smem;
+  auto at = [&](int i, int j) { return PACKED ? i * (i + 1) / 2 + j : i * lda + j; };  // j <= i
+  const size_t a_words = PACKED ? (size_t)m * (m + 1) / 2 : (size_t)m * lda;
+  float *yt = A + ((a_words + 3) & ~(size_t)3);  // [TILE][FS]  gathered rows, zero beyond f
+  float *ut = yt + (size_t)kCholTile * FS;       // [TILE][US]  (|c|-1) y, c+ at index f, zero beyond
+  float *panel = ut + (size_t)kCholTile * US;    // [m][8]      L[i][k0 .. k0+7] of the current panel
+  int *flag = reinterpret_cast<int *>(panel + (size_t)m * kCholPanel);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // this thread's blocks of the lower triangle: block-row bi has min(bi + 1, nbc) blocks, numbered row after row
+  const int n_blocks = nbc * (nbc + 1) / 2 + (nbr > nbc ? nbc : 0);
+  auto block_of = [&](int blk, int &bi, int &bj) {
+    if (blk >= nbc * (nbc + 1) / 2) {
+      bi = nbc, bj = blk - nbc * (nbc + 1) / 2;
+    } else {
+      bi = (int)((sqrtf(8.f * (float)blk + 1.f) - 1.f) * 0.5f);
+      while (bi * (bi + 1) / 2 > blk) --bi;
+      while ((bi + 1) * (bi + 2) / 2 <= blk) ++bi;
+      bj = blk - bi * (bi + 1) / 2;
+    }
+  };
+  constexpr int MAXB = 4;  // blocks held at a time: n_blocks <= 1024 covers f <= 176 in one round, f = 256 takes three
+
+  for (int ri = blockIdx.x; ri < count; ri += gridDim.x) {
+    const int u = order[first + ri];
+    const int row_begin = indptr[u], row_end = indptr[u + 1];
+    if (tid == 0) *flag = 0;
+    // ---- A = YtY + reg I + sum (|c|-1) y y^T, b = sum c+ y: register blocks, rounds of MAXB blocks per thread -----------------
+    for (int round0 = 0; round0 < n_blocks; round0 += 256 * MAXB) {
+      float acc[MAXB][4][4];
+      int bi[MAXB], bj[MAXB];
+#pragma unroll
+      for (int b = 0; b < MAXB; ++b) {
+        const int blk = round0 + tid + 256 * b;
+        bi[b] = bj[b] = -1;
+        if (blk < n_blocks) block_of(blk, bi[b], bj[b]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int i = 4 * bi[b] + r, j = 4 * bj[b] + c;
+            acc[b][r][c] = (bi[b] >= 0 && i < f && j < f && j <= i) ? YtY[(size_t)i * f + j] + (i == j ? reg : 0.f) : 0.f;
+          }
+      }
+      for (int k0 = row_begin; k0 < row_end; k0 += kCholTile) {
+        const int cnt = min(kCholTile, row_end - k0);
+        __syncthreads();  // the previous tile has been consumed
+        for (int e = tid; e < kCholTile * US; e += 256) {  // US >= FS: one sweep fills both
+          const int t = e / US, c = e - t * US;
+          float yv = 0.f, uv = 0.f;
+          if (t < cnt) {
+            const float conf = data[k0 + t];
+            if (c < f) {
+              yv = Y[(size_t)indices[k0 + t] * f + c];
+              uv = (fabsf(conf) - 1.f) * yv;
+            } else if (c == f) {
+              uv = conf > 0.f ? conf : 0.f;
+            }
+          }
+          if (c < FS) yt[t * FS + c] = yv;
+          ut[t * US + c] = uv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) {
+          if (bi[b] < 0) continue;
+#pragma unroll
+          for (int t = 0; t < kCholTile; ++t) {
+            const float4 u4 = *reinterpret_cast<const float4 *>(ut + t * US + 4 * bi[b]);
+            const float4 y4 = *reinterpret_cast<const float4 *>(yt + t * FS + 4 * bj[b]);
+            const float uu[4] = {u4.x, u4.y, u4.z, u4.w}, yy[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int c = 0; c < 4; ++c) acc[b][r][c] = fmaf(uu[r], yy[c], acc[b][r][c]);
+          }
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < MAXB; ++b) {
+        if (bi[b] < 0) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int i = 4 * bi[b] + r, j = 4 * bj[b] + c;
+            if (i < m && j < f && j <= i) A[at(i, j)] = acc[b][r][c];
+          }
+      }
+    }
+    __syncthreads();
+
+    // ---- right-looking Cholesky of the first f columns, 8 columns per panel ---------------------------------------------------
+    for (int k0 = 0; k0 < f; k0 += kCholPanel) {
+      const int nb = min(kCholPanel, f - k0);
+      if (wave == 0) {
+        // The panel -- columns k0 .. k0 + nb - 1 over rows k0 .. f -- in REGISTERS of one wavefront: lane l holds rows
+        // k0 + l + 64 r.  Row k0 + c is lane c's first row, so the pivot and the sub-diagonal entries a column step needs travel
+        // by v_readlane; nothing touches the LDS between the load and the store of the panel (a first version walked the
+        // panel through the LDS column by column: ~70 dependent LDS round trips per column, 640 K cycles per row).
+        constexpr int R = 5;  // 64 R >= 257 rows (f <= 256)
+        float pr[R][kCholPanel];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int i = k0 + lane + 64 * r;
+#pragma unroll
+          for (int c = 0; c < kCholPanel; ++c) pr[r][c] = (i < m && c < nb && k0 + c <= i) ? A[at(i, k0 + c)] : 0.f;
+        }
+        bool bad = false;
+#pragma unroll
+        for (int c = 0; c < kCholPanel; ++c) {
+          if (c < nb && !bad) {  // wave-uniform
+            const float d = bcast_lane(pr[0][c], c);  // the pivot: row k0 + c lives in lane c
+            if (!(d > 0.f)) {
+              bad = true;
+            } else {
+              const float root = sqrtf(d), inv = 1.0f / root;
+#pragma unroll
+              for (int r = 0; r < R; ++r) pr[r][c] = (r == 0 && lane == c) ? root : pr[r][c] * inv;  // rows above the pivot: unused
+#pragma unroll
+              for (int c2 = c + 1; c2 < kCholPanel; ++c2) {
+                const float l2 = bcast_lane(pr[0][c], c2);  // L[k0 + c2][k0 + c]
+#pragma unroll
+                for (int r = 0; r < R; ++r) pr[r][c2] = fmaf(-pr[r][c], l2, pr[r][c2]);
+              }
+            }
+          }
+        }
+        if (bad && lane == 0) *flag = 1;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int i = k0 + lane + 64 * r;
+          if (i < m) {
+#pragma unroll
+            for (int c = 0; c < kCholPanel; ++c) {
+              if (c < nb && k0 + c <= i) A[at(i, k0 + c)] = pr[r][c];
+              panel[i * kCholPanel + c] = pr[r][c];  // dense copy for the trailing update (rows below the panel only are read)
+            }
+          }
+        }
+      }
+      __syncthreads();
+      if (*flag) break;  // uniform
+      // trailing update: A[i][j] -= sum_c L[i][k0+c] L[j][k0+c] for j >= k0 + nb (a multiple of 4 unless this is the last panel)
+      const int jb0 = (k0 + nb) >> 2;
+      if (nb == kCholPanel && jb0 < nbr) {
+        // blocks (bi, bj) with jb0 <= bj <= bi: numbered row after row from block-row jb0
+        const int rows_b = nbr - jb0;
+        for (int t = tid;; t += 256) {
+          // decode t -> (bi, bj) inside the trailing triangle of block-rows jb0 .. nbr-1 with min(bi - jb0 + 1, nbc - jb0) blocks each
+          int bi2, bj2;
+          {
+            const int w = nbc - jb0;  // full width of the trailing block triangle (block-columns jb0 .. nbc-1)
+            const int tri = w * (w + 1) / 2;
+            if (t >= tri + (rows_b > w ? w : 0) || w <= 0) break;
+            if (t >= tri) {
+              bi2 = nbc, bj2 = jb0 + (t - tri);
+            } else {
+              int q = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+              while (q * (q + 1) / 2 > t) --q;
+              while ((q + 1) * (q + 2) / 2 <= t) ++q;
+              bi2 = jb0 + q, bj2 = jb0 + (t - q * (q + 1) / 2);
+            }
+          }
+          float li[4][kCholPanel], lj[4][kCholPanel];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = min(4 * bi2 + r, m - 1), j = min(4 * bj2 + r, m - 1);
+            const float4 a0 = *reinterpret_cast<const float4 *>(panel + i * kCholPanel), a1 = *reinterpret_cast<const float4 *>(panel + i * kCholPanel + 4);
+            const float4 b0 = *reinterpret_cast<const float4 *>(panel + j * kCholPanel), b1 = *reinterpret_cast<const float4 *>(panel + j * kCholPanel + 4);
+            li[r][0] = a0.x, li[r][1] = a0.y, li[r][2] = a0.z, li[r][3] = a0.w, li[r][4] = a1.x, li[r][5] = a1.y, li[r][6] = a1.z, li[r][7] = a1.w;
+            lj[r][0] = b0.x, lj[r][1] = b0.y, lj[r][2] = b0.z, lj[r][3] = b0.w, lj[r][4] = b1.x, lj[r][5] = b1.y, lj[r][6] = b1.z, lj[r][7] = b1.w;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const int i = 4 * bi2 + r, j = 4 * bj2 + c;
+              if (i < m && j < f && j <= i) {
+                float s = A[at(i, j)];
+#pragma unroll
+                for (int k = 0; k < kCholPanel; ++k) s = fmaf(-li[r][k], lj[c][k], s);
+                A[at(i, j)] = s;
+              }
+            }
+        }
+      }
+      __syncthreads();
+    }
+    if (*flag) {
+      if (tid == 0) atomicMin(failed_row, (unsigned long long)u);
+      __syncthreads();
+      continue;
+    }
+    // back substitution L^T x = z with one wavefront; lane l owns z[l + 64 m]
+    if (tid < 64) {
+      constexpr int MAXV = 4;  // f <= 256
+      float z[MAXV];
+#pragma unroll
+      for (int mm = 0; mm < MAXV; ++mm) {
+        int i = tid + 64 * mm;
+        z[mm] = i < f ? A[at(f, i)] : 0.f;
+      }
+      for (int k = f - 1; k >= 0; --k) {
+        float zk = 0.f;
+#pragma unroll
+        for (int mm = 0; mm < MAXV; ++mm)
+          if ((k >> 6) == mm) zk = bcast_lane(z[mm], k & 63);
+        float xk = zk / A[at(k, k)];
+#pragma unroll
+        for (int mm = 0; mm < MAXV; ++mm) {
+          int i = tid + 64 * mm;
+          if (i < k) z[mm] = fmaf(-A[at(k, i)], xk, z[mm]);
+          if (i == k) z[mm] = xk;
+        }
+      }
+#pragma unroll
+      for (int mm = 0; mm < MAXV; ++mm) {
+        int i = tid + 64 * mm;
+        if (i < f) X[(size_t)u * f + i] = z[mm];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ---- f <= 64: one WAVEFRONT per row, the whole system in registers ---------------------------------------------
 // Lane i owns row i of A (64 VGPRs) and b[i].  A-build: for every nonzero the gathered factor row arrives as one
 // coalesced wave load (lane j holds y[j]); y[j] is broadcast with v_readlane and lane i accumulates
@@ -672,10 +920,18 @@ int64_t least_squares_cholesky(const imp_csr *C, imp_matrix *X, const imp_matrix
     IMP_CHECK_HIP(hipGetLastError());
   }
   if (n_block > 0) {
-    auto kern = packed ? als_cholesky_kernel<true> : als_cholesky_kernel<false>;
+    // IMP_CHOL_UNBLOCKED=1: the round-1 column-by-column kernel (A/B, parity)
+    static const bool unblocked = getenv("IMP_CHOL_UNBLOCKED") != nullptr;
+    if (!unblocked) {
+      const int m = f + 1, nbr = (m + 3) / 4, nbc = (f + 3) / 4;
+      const size_t a_words = packed ? (size_t)m * (m + 1) / 2 : (size_t)m * lda;
+      lds = (((a_words + 3) & ~(size_t)3) + (size_t)kCholTile * 4 * (nbc + nbr) + (size_t)m * kCholPanel + 4) * sizeof(float);
+    }
+    auto kern = unblocked ? (packed ? als_cholesky_kernel<true> : als_cholesky_kernel<false>)
+                          : (packed ? als_cholesky_blocked_kernel<true> : als_cholesky_blocked_kernel<false>);
     IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
-    int grid = std::min(n_block, ctx().num_cus * per_cu);
+    int grid = std::min(n_block, ctx().num_cus * per_cu * (unblocked ? 1 : 4));  // smaller fixed shares of the length-sorted schedule
     IMP_PROF("als_cholesky_rows");
     kern<<<grid, 256, lds, stream()>>>(C->order.data(), 0, n_block, C->indptr.data(), C->indices.data(), C->data.data(), X->f32(),
                                        Y->f32(), YtY->f32(), f, (float)reg, lda, g_failed);

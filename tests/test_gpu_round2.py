@@ -193,6 +193,13 @@ solver.least_squares_cholesky(gpu.CSRMatrix(Cc), Xd, gram, Yd, 0.05)
 want = np.zeros((2000, 64), dtype=np.float32)
 oracle.least_squares(Cc, want, Y0, 0.05)
 assert rel(Xd.to_numpy(), want) < 1e-4, ("cholesky", rel(Xd.to_numpy(), want))
+Y1 = rng.random((500, 100), dtype=np.float32) * 0.2 - 0.1   # f = 100: the workgroup-per-row kernel (blocked / IMP_CHOL_UNBLOCKED=1)
+Yd, gram, Xd = gpu.Matrix(Y1), gpu.Matrix.zeros(100, 100), gpu.Matrix.zeros(2000, 100)
+solver.calculate_yty(Yd, gram, 0.0)
+solver.least_squares_cholesky(gpu.CSRMatrix(Cc), Xd, gram, Yd, 0.05)
+want = np.zeros((2000, 100), dtype=np.float32)
+oracle.least_squares(Cc, want, Y1, 0.05)
+assert rel(Xd.to_numpy(), want) < 1e-4, ("cholesky f=100", rel(Xd.to_numpy(), want))
 items = (rng.standard_normal((5000, 64)) * 0.1).astype(np.float32)
 q = (rng.standard_normal((40, 64)) * 0.1).astype(np.float32)
 ids, d = gpu.KnnQuery().topk(gpu.Matrix(items), gpu.Matrix(q), 10)
@@ -206,7 +213,7 @@ print("switch ok")
                                     "IMP_CHOL_NO_MFMA=1", "IMP_CHOL_NO_WAVE=1", "IMP_TOPK_NO_FAST=1", "IMP_NO_CLUSTER=1", "IMP_CLUSTER_SC1=1",
                                     "IMP_GRAM_NO_VEC=1", "IMP_CHOL_NO_SPLIT=1", "IMP_TEAM16_CLUSTER=1", "IMP_F256_GENERIC=1",
                                     "IMP_OVERSUB=3", "IMP_STRIPE_REUSE=1", "IMP_QGROUP_PER_CU=1", "IMP_TEAM_FUSED=0", "IMP_TEAM_FUSED=31", "IMP_SHORT_STAGGER=0", "IMP_SHORT_BF16X3=0",
-                                    "IMP_TOPK_FP32_MFMA=1", "IMP_NO_PAD=1", "IMP_TOPK_NO_PAD=1", "IMP_TOPK_NO_QSPLIT=1", "IMP_HALF_TILE64=0", "IMP_TILE64=15", "IMP_TILE64=0"])
+                                    "IMP_TOPK_FP32_MFMA=1", "IMP_NO_PAD=1", "IMP_TOPK_NO_PAD=1", "IMP_TOPK_NO_QSPLIT=1", "IMP_HALF_TILE64=0", "IMP_TILE64=15", "IMP_CHOL_UNBLOCKED=1"])
 def test_ab_switch_paths_keep_parity(gpu, switch):
     """Every debug / A-B environment switch selects kernels the default run does not take (they are read once per
     process, hence the subprocess): CG both orientations at f = 64 / 128, Cholesky f = 64 and top-k against the oracle."""
