@@ -32,6 +32,7 @@ namespace imp {
 
 template <typename T> void least_squares_cg_q(const imp_csr *C, T *X, const T *Y, const float *A0, int f, int cg_steps);  // als_cg_q.hip
 template <typename T> void least_squares_cg_cluster(const imp_csr *C, T *X, const T *Y, const float *A0, int f, int cg_steps);  // als_cg_cluster.hip
+template <typename T> void least_squares_cg_nm(const imp_csr *C, T *X, const T *Y, const float *A0, int f, int cg_steps);  // als_cg_nm.hip
 
 // ---- generic per-nnz pass (any f): 4 gathers in flight, one DPP all-reduce per dot -------------------
 template <int VPL, bool VEC, bool FIRST>
@@ -641,8 +642,12 @@ static void launch_all(const imp_csr *C, T *X, const T *Y, const float *A0, int 
     // f = 64 / 128: rows of 513 .. kClusterRow nonzeros are resident across a cluster of workgroups (als_cg_cluster.hip);
     // only the rows beyond that are streamed.  IMP_NO_CLUSTER=1: every long row streamed (A/B, parity)
     static const bool no_cluster = getenv("IMP_NO_CLUSTER") != nullptr;
-    launch_long<VPL, VEC, A_LDS, T>(C, no_cluster ? C->plan_all : C->plan_xl, X, Y, A0, f, cg_steps);
-    if (!no_cluster) least_squares_cg_cluster<T>(C, X, Y, A0, f, cg_steps);
+    if (nm_enabled() && !no_cluster && !team16_as_cluster()) {
+      least_squares_cg_nm<T>(C, X, Y, A0, f, cg_steps);  // round 4: the row's normal matrix on the matrix cores, CG on the LDS image
+    } else {
+      launch_long<VPL, VEC, A_LDS, T>(C, no_cluster ? C->plan_all : C->plan_xl, X, Y, A0, f, cg_steps);
+      if (!no_cluster) least_squares_cg_cluster<T>(C, X, Y, A0, f, cg_steps);
+    }
     least_squares_cg_q<T>(C, X, Y, A0, f, cg_steps);  // quarter-layout register tiles, wave teams (als_cg_q.hip)
   } else if constexpr (std::is_same<T, float>::value) {
     launch_long<VPL, VEC, A_LDS, T>(C, C->plan_all, X, Y, A0, f, cg_steps);

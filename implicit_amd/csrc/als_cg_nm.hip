@@ -1,0 +1,518 @@
+// CG for the LONG rows (> 512 nonzeros) of the f = 64 / 128 path through the row's explicit normal matrix, built on the matrix cores.
+//
+// What it replaces.  The reference's kernel (implicit/gpu/als.cu:23-111) applies A_u = YtY + sum_k (c_k - 1) y_k y_k^T to a vector
+// once per CG pass by walking the row's nonzeros: 1 + cg_steps gathers of every y_k.  The resident-tile kernels of the shorter
+// classes gather once and keep the tile in registers; a row of thousands of nonzeros does not fit a workgroup's registers, so
+// rounds 2-3 spread it over a cluster of workgroups that meet through memory after every pass (als_cg_cluster.hip: latency-bound,
+// 0.28 of the HBM roofline) and streamed the rows beyond 4096 nonzeros once per pass (2.7x the algorithmic traffic).
+//
+// Here a long row's A_u is formed ONCE, explicitly -- a rank-nnz symmetric update, i.e. matrix-core work -- and the CG passes then
+// run on that f x f matrix in the LDS (1 + cg_steps dense products of 16 K multiply-adds: nothing beside nnz * f^2).  Every y_k is
+// gathered exactly once, by exactly one wavefront.
+//
+//   * Operand layout without a transpose: lane (a = l % M, g = l / M) gathers FOUR consecutive factors 4a .. 4a+3 of EIGHT
+//     nonzeros (8 x global_load_dwordx4, each a fully coalesced 512-byte row at f = 128).  Component c of those loads, over the 8
+//     nonzeros, is precisely what v_mfma_f32_32x32x16_f16 wants from lane l as its A or B operand (row a of a 32 x K block, K
+//     positions 8g .. 8g+7) if the factor index is READ AS i = 4 m + I: the f factors split into 4 interleaved blocks I = i % 4 of
+//     M = f/4 rows m = i / 4.  A_u then consists of 4 x 4 tiles T(I,J)[m][n] = A_u[4m+I][4n+J]; the 10 tiles with I >= J cover
+//     every unordered pair.  f = 64: the same with v_mfma_f32_16x16x32_f16 (M = 16, 4 lane groups, 32 nonzeros per step).
+//   * Precision: fp32 operands are split into two fp16 halves x = h + l (h = rn16(x), l = rn16(x - h): 22 significant bits) and
+//     the tile takes three products  u_h y_h + u_h y_l + u_l y_h  (u = w y, w = |c| - 1); the dropped u_l y_l is 2^-22 of the
+//     term, fp32 accumulation.  The weights of a segment are scaled by a power of two so that |w| <= 1 (fp16 range: a
+//     confidence of 10^5 would overflow otherwise), undone exactly when the tile leaves the accumulators.  fp16 factor storage:
+//     y IS an fp16 number, two products.   Factors beyond +-65504 would overflow the operands (no ALS factor is).
+//   * Parallelism inside the workgroup: the four wavefronts take every fourth step of 16 (32) nonzeros and keep their own ten
+//     accumulator tiles (160 registers at f = 128); at the end they add them into the LDS image of A_u with ds_add_f32.  No
+//     barrier and no LDS traffic inside the nonzero loop.
+//   * Rows of more than `segment` nonzeros (imp_csr::plan_nm: 2048 .. 16384, by the amount of long-row work) are cut into
+//     segments, one workgroup each; their partial matrices go through a workspace and a second kernel sums them in segment order
+//     and runs the CG.  Every other row is finished by the workgroup that built its matrix.
+//   * CG on the LDS image: the reference's recurrences (als.cu:45-109) with the product A_u p evaluated from the explicit matrix;
+//     256 threads, 256/f threads per matrix row.
+//
+// Cost model (f = 128, per 64 nonzeros and CU): 4 x 30 MFMA of 32 cycles on 4 SIMDs = 960 cycles of matrix pipe, ~220 VALU
+// instructions per wavefront for the splits; 32 KB gathered.  IMP_NM=0 restores the cluster + streamed kernels (A/B, parity).
+#include "als_qf_common.h"
+#include "common.h"
+#include "wave_ops.h"
+
+namespace imp {
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int F> struct NmShape;
+template <> struct NmShape<128> {
+  static constexpr int M = 32, KG = 2, NACC = 16;
+  using acc_t = f32x16;
+  __device__ static __forceinline__ acc_t mfma(half8 a, half8 b, acc_t c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+  // C/D layout of the 32 x 32 tile: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+  __device__ static __forceinline__ int row(int lane, int e) { return (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5); }
+  __device__ static __forceinline__ int col(int lane) { return lane & 31; }
+};
+template <> struct NmShape<64> {
+  static constexpr int M = 16, KG = 4, NACC = 4;
+  using acc_t = f32x4v;
+  __device__ static __forceinline__ acc_t mfma(half8 a, half8 b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+  // 16 x 16 tile: column = lane & 15, row = 4 (lane >> 4) + e
+  __device__ static __forceinline__ int row(int lane, int e) { return 4 * (lane >> 4) + e; }
+  __device__ static __forceinline__ int col(int lane) { return lane & 15; }
+};
+
+template <int F> struct NmLayout {
+  static constexpr int M = F / 4;              // rows of a tile
+  static constexpr int TS = M + 1;             // row stride inside a tile: rows m and columns n both walk all LDS banks
+  static constexpr int IMG = 16 * M * TS;      // floats of the image: 16 tiles (I, J), tile (I, J)[m][n] = A[4m+I][4n+J]
+  static constexpr int KCH = 8 * NmShape<F>::KG;  // nonzeros per step (one wavefront's gathers)
+  static constexpr int ROUND = 4 * KCH;        // nonzeros per round: one step from each of the four wavefronts
+  static constexpr int kTiles = 10;            // (I, J), I >= J
+  static constexpr int kSlots = 3;             // tiles per wavefront: 3, 3, 2, 2
+  // operand exchange: [step][kind: uh ul yh yl][block][lane] quads of 16 bytes
+  static constexpr int QUAD = 64 * 4;          // floats of one operand quad (one b128 per lane)
+  static constexpr int OPS = 4 * 16 * QUAD;    // floats of the exchange buffer (64 KB); the image re-uses the space afterwards
+  static constexpr int NP = 256 / F;           // thread groups sharing a matrix row in the CG phase
+  static constexpr int kVec = IMG > OPS ? IMG : OPS;  // offset of the vectors behind the image / exchange buffer
+  static constexpr size_t lds_floats = (size_t)kVec + 2 * F + NP * F + 64;  // image / operands | b | p | partial products | reduction slots
+  __host__ __device__ static constexpr int at(int I, int J, int m, int n) { return ((I * 4 + J) * M + m) * TS + n; }
+};
+__device__ constexpr int nm_tile_i(int t) { return t < 1 ? 0 : t < 3 ? 1 : t < 6 ? 2 : 3; }
+__device__ constexpr int nm_tile_j(int t) { return t - (nm_tile_i(t) * (nm_tile_i(t) + 1)) / 2; }
+
+// two fp32 -> (high halves, low halves), both packed
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned &hi, unsigned &lo) {
+  const f32x2 v = {x0, x1};
+  const half2v h = __builtin_convertvector(v, half2v);
+  const f32x2 r = v - __builtin_convertvector(h, f32x2);
+  const half2v l = __builtin_convertvector(r, half2v);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ unsigned pack_pair(float x0, float x1) {
+  const f32x2 v = {x0, x1};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, half2v));
+}
+__device__ __forceinline__ float comp(const float4 &v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
+
+// The regularised gramian in image order (once per launch; the workgroups copy it linearly)
+template <int F> __global__ void nm_gram_image_kernel(const float *__restrict__ A0, float *__restrict__ img, int *__restrict__ ticket) {
+  using L = NmLayout<F>;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < L::IMG; e += gridDim.x * blockDim.x) {
+    const int n = e % L::TS, m = (e / L::TS) % L::M, t = e / (L::TS * L::M);
+    img[e] = n < L::M ? A0[(size_t)(4 * m + t / 4) * F + 4 * n + t % 4] : 0.f;
+  }
+}
+
+// Workgroup barrier that orders the LDS only.  __syncthreads() is a fence over ALL memory: it drains vmcnt, i.e. waits for the
+// gathers of the coming rounds that are in flight on purpose (measured: 12 K cycles per round instead of ~4 K).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---- the rank-(end - begin) update of one segment ---------------------------------------------------------------------------
+// Rounds of 4 steps.  Wavefront w PRODUCES step w of a round -- gathers its 8 x 4 factors per lane, scales, splits, and leaves the
+// sixteen operand quads (uh ul yh yl x 4 blocks) in the LDS -- and, behind a barrier, CONSUMES all four steps for the tiles it
+// OWNS (3, 3, 2, 2 of the ten): a tile's sum over the nonzeros lives in one wavefront's accumulators from the first round to the
+// last, so there is no reduction across wavefronts at the end (a first version split the nonzeros instead, every wavefront with
+// all ten tiles: 509 registers = one wavefront per SIMD at 6 cycles per instruction, and 156 K cycles of ds_add_f32 per row to
+// add the four copies up).  Registers: 48 accumulators + 32 landing + the operands in transit; two workgroups per CU.
+//
+// Weights without a pre-pass: w = |c| - 1 is dealt to the two operands as w 2^-e and 2^e with e = floor(log2|w| / 2) clamped to
+// +-12 -- exact scalings; both operands stay within sqrt(2 |w|) |y| of the fp16 range for confidences up to 10^7.
+//
+// Returns with the image complete in the LDS (gramian added when `whole`), behind a barrier.
+template <int F, typename T>
+__device__ __forceinline__ void nm_build(const int32_t *__restrict__ indices, const float *__restrict__ data, const T *__restrict__ Y,
+                                         const float *__restrict__ gram_img, bool whole, int begin, int end, float *smem, float *bvec,
+                                         int tid, int ko) {
+  using S = NmShape<F>;
+  using L = NmLayout<F>;
+  constexpr bool kHalf = !std::is_same<T, float>::value;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int a = lane % S::M, g = lane / S::M;
+  // this wavefront's tiles: slots 0 .. n_slots-1 = tiles first .. first + n_slots - 1
+  const int first = wave < 2 ? 3 * wave : 2 * wave + 2;  // 0, 3, 6, 8
+  const int n_slots = wave < 2 ? 3 : 2;
+  int tI[L::kSlots], tJ[L::kSlots];
+#pragma unroll
+  for (int k = 0; k < L::kSlots; ++k) {
+    const int t = min(first + k, L::kTiles - 1);
+    tI[k] = t < 1 ? 0 : t < 3 ? 1 : t < 6 ? 2 : 3;
+    tJ[k] = t - tI[k] * (tI[k] + 1) / 2;
+  }
+  typename S::acc_t acc[L::kSlots];
+#pragma unroll
+  for (int k = 0; k < L::kSlots; ++k)
+#pragma unroll
+    for (int e = 0; e < S::NACC; ++e) acc[k][e] = 0.f;
+  float b4[4] = {0.f, 0.f, 0.f, 0.f};
+
+  // Every round issues the same loads whether they are needed or not: s_waitcnt counts loads statically, and one conditional
+  // gather makes the compiler assume the worst path -- the counts it then emits (vmcnt 7 .. 0) drain the whole queue at every
+  // round, prefetch included.
+  const int n_rounds = (ko & 1) ? 0 : (end - begin + L::ROUND - 1) / L::ROUND;
+  // entry `lane % KCH` of this wavefront's step: column, the two weight factors, c+
+  struct Entry {
+    int col;
+    float c;
+  };
+  auto load_entry = [&](int r) {
+    Entry en;
+    const int k = begin + r * L::ROUND + wave * L::KCH + (lane % L::KCH);
+    const int kk = min(k, end - 1);
+    en.col = indices[kk];
+    const float c = data[kk];          // unconditional (see n_rounds)
+    en.c = k < end ? c : -1.f;         // beyond the segment: confidence -1 -> weight 0, no share in b
+    return en;
+  };
+  // One round of gathers in flight per wavefront beside the one being worked on (a second landing buffer is 32 registers this
+  // kernel does not have: measured 0.90 against 0.95 ms with it, before the consume phase was pipelined)
+  float4 yb[8];
+  auto gather = [&](const Entry &en, float4 (&y)[8]) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int col = __shfl(en.col, 8 * g + q, 64);
+      y[q] = load4(Y + (size_t)col * F + 4 * a);
+    }
+  };
+  float *ops = smem;
+  // entries: e0 = this round, e1 = next (its gather is issued at the end of this round's produce phase), e2 = the one after
+  Entry e0{0, -1.f}, e1 = e0, e2 = e0;
+  if (n_rounds > 0) {
+    e0 = load_entry(0), e1 = load_entry(1);  // beyond the segment: the last entry with weight 0
+    gather(e0, yb);
+  }
+  struct Operands {
+    half8 uh, ul, yh, yl;
+  };
+  const float *op_i[L::kSlots], *op_j[L::kSlots];  // this lane's quads of block I (uh; ul one kind further) and J (yh; yl)
+#pragma unroll
+  for (int k = 0; k < L::kSlots; ++k) {
+    op_i[k] = ops + (0 * 4 + tI[k]) * L::QUAD + 4 * lane;
+    op_j[k] = ops + (2 * 4 + tJ[k]) * L::QUAD + 4 * lane;
+  }
+  auto fetch_ops = [&](int st, int k) {
+    Operands o;
+    o.uh = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4 *>(op_i[k] + st * 16 * L::QUAD));
+    o.ul = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4 *>(op_i[k] + st * 16 * L::QUAD + 4 * L::QUAD));
+    o.yh = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4 *>(op_j[k] + st * 16 * L::QUAD));
+    if constexpr (!kHalf) o.yl = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4 *>(op_j[k] + st * 16 * L::QUAD + 4 * L::QUAD));
+    return o;
+  };
+  auto products = [&](auto k, const Operands &o) {
+    acc[k.value] = S::mfma(o.uh, o.yh, acc[k.value]);
+    acc[k.value] = S::mfma(o.ul, o.yh, acc[k.value]);
+    if constexpr (!kHalf) acc[k.value] = S::mfma(o.uh, o.yl, acc[k.value]);  // fp16 factors: 2^e y is an fp16 number too, no low half
+  };
+  auto consume = [&](auto ns) {
+    constexpr int NS = ns.value;
+    Operands o0 = fetch_ops(0, 0);
+#pragma unroll 1
+    for (int st = 0; st < 4; ++st) {
+      const Operands o1 = fetch_ops(st, 1);
+      products(idx_t<0>{}, o0);
+      if constexpr (NS == 3) {
+        const Operands o2 = fetch_ops(st, 2);
+        products(idx_t<1>{}, o1);
+        o0 = fetch_ops(min(st + 1, 3), 0);  // after the last step: a re-read nobody uses
+        products(idx_t<2>{}, o2);
+      } else {
+        o0 = fetch_ops(min(st + 1, 3), 0);
+        products(idx_t<1>{}, o1);
+      }
+    }
+  };
+  auto round = [&](int r, float4 (&y)[8]) {
+    // The entries rotate HERE, not where e2 is loaded: a register move of a value still in flight makes the compiler wait for
+    // its load, and -- the queue being in order -- at the end of the produce phase that wait would also cover the gathers just
+    // issued.  Here it covers the loads older than e2: the rows of THIS round, which are due anyway.
+    if (r > 0) e0 = e1, e1 = e2;
+    e2 = load_entry(r + 2);  // ahead of this round's gathers in the (in-order) load queue
+    // ---- produce step `wave` of this round
+    {
+      // this lane's entry: w = |c| - 1 dealt as wa = w 2^-e and sb = 2^e, e = floor((exponent of |w|) / 2) clamped to [-12, 12]
+      const float w_mine = fabsf(e0.c) - 1.f;
+      unsigned hb = (((__float_as_uint(w_mine) & 0x7f800000u) + (127u << 23)) >> 1) & 0x7f800000u;
+      hb = min(max(hb, (127u - 12u) << 23), (127u + 12u) << 23);
+      const float sb_mine = __uint_as_float(hb), wa_mine = w_mine * __uint_as_float((254u << 23) - hb);
+      const float cp_mine = e0.c > 0.f ? e0.c : 0.f;
+      float wa[8], sb[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        wa[q] = __shfl(wa_mine, 8 * g + q, 64);
+        sb[q] = __shfl(sb_mine, 8 * g + q, 64);
+        const float cp = __shfl(cp_mine, 8 * g + q, 64);
+        b4[0] = fmaf(cp, y[q].x, b4[0]);
+        b4[1] = fmaf(cp, y[q].y, b4[1]);
+        b4[2] = fmaf(cp, y[q].z, b4[2]);
+        b4[3] = fmaf(cp, y[q].w, b4[3]);
+      }
+      float *mine = ops + (size_t)wave * 16 * L::QUAD + 4 * lane;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        u32x4 uh, ul, yh, yl;
+#pragma unroll
+        for (int q = 0; q < 8; q += 2) {
+          const float y0 = comp(y[q], c), y1 = comp(y[q + 1], c);
+          unsigned h, l;
+          split_pair(sb[q] * y0, sb[q + 1] * y1, h, l);
+          yh[q / 2] = h, yl[q / 2] = l;
+          split_pair(wa[q] * y0, wa[q + 1] * y1, h, l);
+          uh[q / 2] = h, ul[q / 2] = l;
+        }
+        *reinterpret_cast<u32x4 *>(mine + (0 * 4 + c) * L::QUAD) = uh;
+        *reinterpret_cast<u32x4 *>(mine + (1 * 4 + c) * L::QUAD) = ul;
+        *reinterpret_cast<u32x4 *>(mine + (2 * 4 + c) * L::QUAD) = yh;
+        if constexpr (!kHalf) *reinterpret_cast<u32x4 *>(mine + (3 * 4 + c) * L::QUAD) = yl;
+        __builtin_amdgcn_sched_barrier(0);  // one block's quads at a time: interleaved blocks spill, and a spill reload is a
+      }                                     // vector-memory load -- waiting for it (vmcnt 0) drains the gathers in flight
+    }
+    gather(e1, y);  // the landing registers are free again (beyond the last round: the segment's last row, unused)
+    lds_barrier();
+    // ---- consume the four steps for the tiles of this wavefront: the operands of the next (step, tile) are on their way from
+    // the LDS while the three products of the current one run (one tile-step at a time left ~250 cycles of LDS + dependent
+    // matrix-instruction latency exposed per tile-step: 7.8 K cycles per round; all of a step's operands at once cost 32 more
+    // registers than this kernel has)
+    if (n_slots == 3) consume(std::integral_constant<int, 3>{});
+    else consume(std::integral_constant<int, 2>{});
+    lds_barrier();  // the exchange buffer is free again (and, after the last round, free for the image)
+  };
+#pragma unroll 1
+  for (int r = 0; r < n_rounds; ++r) round(r, yb);
+  // b: lane (a, g) holds its nonzeros' share of factors 4a .. 4a+3 = positions c M + a
+  if (!(ko & 2)) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) __hip_atomic_fetch_add(bvec + c * L::M + a, b4[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // the image: every tile (and its mirror) is written by its one owner, gramian added on the way
+    float *img = smem;
+    const int n = S::col(lane);
+#pragma unroll
+    for (int k = 0; k < L::kSlots; ++k) {
+      if (k < n_slots) {
+        const int I = tI[k], J = tJ[k];
+        float gv[S::NACC];  // the tile's share of the gramian: all loads in flight before the first store
+#pragma unroll
+        for (int e = 0; e < S::NACC; ++e) gv[e] = 0.f;
+        if (whole) {
+#pragma unroll
+          for (int e = 0; e < S::NACC; ++e) gv[e] = gram_img[L::at(I, J, S::row(lane, e), n)];
+        }
+#pragma unroll
+        for (int e = 0; e < S::NACC; ++e) {
+          const int m = S::row(lane, e);
+          const float v = acc[k][e] + gv[e];
+          img[L::at(I, J, m, n)] = v;
+          if (I != J) img[L::at(J, I, n, m)] = v;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// ---- CG on the LDS image (als.cu:45-109 with A_u p from the explicit matrix) ----------------------------------------------------
+// Vectors live in image order: position r = I M + m is factor 4m + I.  Thread (r = tid % F, grp = tid / F) forms the products of
+// row r with the column blocks J of its group: lanes walk m, i.e. consecutive tile rows of stride M + 1 -- conflict-free.
+template <int F, typename T>
+__device__ __forceinline__ void nm_cg(const float *img, const float *bvec, float *pv, float *parts, float *red, T *xrow, int cg_steps, int tid) {
+  using L = NmLayout<F>;
+  constexpr int M = L::M, NP = L::NP, JPG = 4 / NP;
+  const int r = tid % F, grp = tid / F, lane = tid & 63, wave = tid >> 6;
+  const int I = r / M, m = r % M;
+  int slot = 0;
+  auto matvec = [&]() {
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jj = 0; jj < JPG; ++jj) {
+      const int J = grp * JPG + jj;
+      const float *row = img + L::at(I, J, m, 0);
+#pragma unroll
+      for (int n = 0; n < M; n += 4) {
+        const float4 p4 = *reinterpret_cast<const float4 *>(pv + J * M + n);
+        s[0] = fmaf(row[n], p4.x, s[0]), s[1] = fmaf(row[n + 1], p4.y, s[1]);
+        s[2] = fmaf(row[n + 2], p4.z, s[2]), s[3] = fmaf(row[n + 3], p4.w, s[3]);
+      }
+    }
+    parts[grp * F + r] = (s[0] + s[1]) + (s[2] + s[3]);
+    __syncthreads();
+    float q = parts[r];
+#pragma unroll
+    for (int gq = 1; gq < NP; ++gq) q += parts[gq * F + r];
+    return q;
+  };
+  auto block_sum = [&](float v) {  // over the F positions (the threads of group 0 contribute)
+    v = wave_allsum(grp == 0 ? v : 0.f);
+    if (lane == 0) red[4 * slot + wave] = v;
+    __syncthreads();
+    const float s = (red[4 * slot] + red[4 * slot + 1]) + (red[4 * slot + 2] + red[4 * slot + 3]);
+    slot = (slot + 1) & 7;
+    return s;
+  };
+  float x = load1(xrow + 4 * m + I);
+  if (grp == 0) pv[r] = x;
+  __syncthreads();
+  float res = bvec[r] - matvec();
+  float p = res;
+  float rsold = block_sum(res * res);
+  if (rsold < 1e-20f) return;
+  for (int it = 0; it < cg_steps; ++it) {
+    if (grp == 0) pv[r] = p;
+    __syncthreads();
+    const float Ap = matvec();
+    const float alpha = rsold / block_sum(p * Ap);
+    x = fmaf(alpha, p, x);
+    res = fmaf(-alpha, Ap, res);
+    const float rsnew = block_sum(res * res);
+    if (rsnew < 1e-20f) break;
+    p = fmaf(rsnew / rsold, p, res);
+    rsold = rsnew;
+  }
+  if (grp == 0) store1(xrow + 4 * m + I, x);
+}
+
+// One workgroup per segment of plan_nm at a time; a row that is ONE segment is solved here, the others leave partial[seg] =
+// (image part, b part).  Segments are handed out through a ticket counter in plan order (longest first): with fixed shares the
+// average wavefront was alive for 66 % of the launch (segments of up to `nm_segment` nonzeros = up to 100 us each in a 320 us launch).
+template <int F, typename T>
+__global__ __launch_bounds__(256, 2) void als_cg_nm_kernel(const LongPlanDev plan, const int32_t *__restrict__ indices,
+                                                           const float *__restrict__ data, T *__restrict__ X, const T *__restrict__ Y,
+                                                           const float *__restrict__ gram_img, int cg_steps, float *__restrict__ partial,
+                                                           int *__restrict__ ticket,
+                                                           int ko) {  // ko: timing-only knock-outs (IMP_NM_KO), 0 in production
+  using L = NmLayout<F>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ int next_item;
+  float *img = smem, *bvec = img + L::kVec, *pv = bvec + F, *parts = pv + F, *red = parts + L::NP * F;
+  const int tid = threadIdx.x;
+  for (int s = blockIdx.x; s < plan.n_seg;) {
+    const int li = plan.seg_row[s];
+    const int begin = plan.seg_begin[s], end = plan.seg_end[s];
+    const bool whole = plan.row_seg[li + 1] - plan.row_seg[li] == 1;
+    __syncthreads();  // the previous item's CG has read the image and b
+    if (tid < F) bvec[tid] = 0.f;
+    nm_build<F, T>(indices, data, Y, gram_img, whole, begin, end, smem, bvec, tid, ko);
+    // the next ticket is drawn here: its round trip hides behind the CG / the store of the partial image
+    int drawn = 0;
+    if (tid == 0) drawn = (int)gridDim.x + atomicAdd(ticket, 1);
+    if (!(ko & 4)) {
+      if (whole) {
+        nm_cg<F, T>(img, bvec, pv, parts, red, X + (size_t)plan.rows[li] * F, cg_steps, tid);
+      } else {
+        float *out = partial + (size_t)s * (L::IMG + F);
+        for (int e = tid; e < L::IMG / 4; e += 256) reinterpret_cast<float4 *>(out)[e] = reinterpret_cast<const float4 *>(img)[e];
+        if (tid < F) out[L::IMG + tid] = bvec[tid];
+      }
+    }
+    if (tid == 0) next_item = drawn;
+    __syncthreads();
+    s = next_item;
+  }
+}
+
+// Rows of more than one segment (the first n_multi rows of the plan), step 1: partial[first segment] = gramian + the sum of the
+// row's partial images in segment order.  One workgroup per (row, sixteenth of the image); the loads of eight segments are in
+// flight per thread (a first version had one workgroup walk a row's partials, four loads in flight: 143 us per launch, a third
+// of the long rows' time).
+template <int F>
+__global__ __launch_bounds__(256) void als_cg_nm_reduce_kernel(const LongPlanDev plan, int n_multi, const float *__restrict__ gram_img,
+                                                               float *__restrict__ partial) {
+  using L = NmLayout<F>;
+  constexpr int CH = 16, PER = L::IMG / CH / 4;  // float4 pieces per chunk
+  static_assert(L::IMG % (CH * 4) == 0, "chunks of whole float4 pieces");
+  for (int item = blockIdx.x; item < n_multi * CH; item += gridDim.x) {
+    const int li = item / CH, chunk = item % CH;
+    const int s0 = plan.row_seg[li], s1 = plan.row_seg[li + 1];
+    const size_t stride = (size_t)(L::IMG + F) / 4;  // float4 pieces per partial (IMG + F is a multiple of 4)
+    for (int e = threadIdx.x; e < PER + (chunk == 0 ? F / 4 : 0); e += 256) {
+      // chunk 0 also sums the b parts (they sit behind the image)
+      const size_t off = e < PER ? (size_t)chunk * PER + e : (size_t)L::IMG / 4 + (e - PER);
+      float4 *base = reinterpret_cast<float4 *>(partial) + off;
+      float4 sum = e < PER ? reinterpret_cast<const float4 *>(gram_img)[off] : make_float4(0.f, 0.f, 0.f, 0.f);
+      int s = s0;
+      for (; s + 8 <= s1; s += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = base[(size_t)(s + q) * stride];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sum.x += v[q].x, sum.y += v[q].y, sum.z += v[q].z, sum.w += v[q].w;
+      }
+      for (; s < s1; ++s) {
+        const float4 v = base[(size_t)s * stride];
+        sum.x += v.x, sum.y += v.y, sum.z += v.z, sum.w += v.w;
+      }
+      base[(size_t)s0 * stride] = sum;
+    }
+  }
+}
+
+// step 2: the CG of those rows on the summed image
+template <int F, typename T>
+__global__ __launch_bounds__(256) void als_cg_nm_finish_kernel(const LongPlanDev plan, int n_multi, T *__restrict__ X, int cg_steps,
+                                                               const float *__restrict__ partial) {
+  using L = NmLayout<F>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *img = smem, *bvec = img + L::kVec, *pv = bvec + F, *parts = pv + F, *red = parts + L::NP * F;
+  const int tid = threadIdx.x;
+  for (int li = blockIdx.x; li < n_multi; li += gridDim.x) {
+    const float *in = partial + (size_t)plan.row_seg[li] * (L::IMG + F);
+    __syncthreads();
+    for (int e = tid; e < L::IMG / 4; e += 256) reinterpret_cast<float4 *>(img)[e] = reinterpret_cast<const float4 *>(in)[e];
+    if (tid < F) bvec[tid] = in[L::IMG + tid];
+    __syncthreads();
+    nm_cg<F, T>(img, bvec, pv, parts, red, X + (size_t)plan.rows[li] * F, cg_steps, tid);
+  }
+}
+
+template <int F, typename T> void launch_nm(const imp_csr *C, T *X, const T *Y, const float *A0, int cg_steps) {
+  const LongPlan &lp = C->plan_nm;
+  if (lp.n_seg <= 0) return;
+  using L = NmLayout<F>;
+  static_assert(L::IMG % 4 == 0, "the image is copied in 16-byte pieces");
+  const size_t lds = L::lds_floats * sizeof(float);
+  const int n_multi = C->nm_multi_rows, n_multi_seg = C->nm_multi_segs;
+  auto &ws = ctx().long_ws;
+  const size_t need = (size_t)L::IMG + (size_t)n_multi_seg * (L::IMG + F);  // gramian image | partial images
+  if (ws.size < need) ws.alloc(need);
+  float *gram_img = ws.data(), *partial = gram_img + L::IMG;
+  auto &tk = ctx().nm_ticket;
+  if (tk.size < 1) tk.alloc(1, true);
+  LongPlanDev plan = lp.dev(C->order.data());
+  auto kern = als_cg_nm_kernel<F, T>;
+  auto fin = als_cg_nm_finish_kernel<F, T>;
+  IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  {
+    IMP_PROF("als_cg_nm_rows");
+    nm_gram_image_kernel<F><<<(L::IMG + 255) / 256, 256, 0, stream()>>>(A0, gram_img, tk.data());
+    const int grid = std::min(lp.n_seg, ctx().num_cus * 2);  // two resident workgroups per CU; the ticket counter balances them
+    static const int ko = getenv("IMP_NM_KO") ? atoi(getenv("IMP_NM_KO")) : 0;
+    kern<<<grid, 256, lds, stream()>>>(plan, C->indices.data(), C->data.data(), X, Y, gram_img, cg_steps, partial, tk.data(), ko);
+    IMP_CHECK_HIP(hipGetLastError());
+  }
+  if (n_multi > 0) {
+    IMP_PROF("als_cg_nm_finish");
+    als_cg_nm_reduce_kernel<F><<<std::min(n_multi * 16, ctx().num_cus * 16), 256, 0, stream()>>>(plan, n_multi, gram_img, partial);
+    fin<<<std::min(n_multi, ctx().num_cus * 2), 256, lds, stream()>>>(plan, n_multi, X, cg_steps, partial);
+    IMP_CHECK_HIP(hipGetLastError());
+  }
+}
+
+}  // namespace
+
+bool nm_enabled() {
+  static const bool on = !(getenv("IMP_NM") && atoi(getenv("IMP_NM")) == 0);
+  return on;
+}
+
+template <typename T> void least_squares_cg_nm(const imp_csr *C, T *X, const T *Y, const float *A0, int f, int cg_steps) {
+  if (f == 128) launch_nm<128, T>(C, X, Y, A0, cg_steps);
+  else if (f == 64) launch_nm<64, T>(C, X, Y, A0, cg_steps);
+  else throw std::invalid_argument("least_squares_cg_nm: f must be 64 or 128");
+}
+template void least_squares_cg_nm<float>(const imp_csr *, float *, const float *, const float *, int, int);
+template void least_squares_cg_nm<__half>(const imp_csr *, __half *, const __half *, const float *, int, int);
+
+}  // namespace imp

@@ -155,7 +155,8 @@ __global__ __launch_bounds__(256) void als_cholesky_blocked_kernel(const int32_t
                                                                    const int32_t *__restrict__ indices,
                                                                    const float *__restrict__ data, float *__restrict__ X,
                                                                    const float *__restrict__ Y, const float *__restrict__ YtY,
-                                                                   int f, float reg, int lda, unsigned long long *failed_row) {
+                                                                   int f, float reg, int lda, unsigned long long *failed_row,
+                                                                   int ko) {  // ko: timing-only knock-out mask (IMP_CHOL_KO), 0 in production
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int m = f + 1;                         // rows of the augmented triangle (row f = b^T -> z^T), f columns
   const int nbr = (m + 3) >> 2, nbc = (f + 3) >> 2;  // 4 x 4 blocks
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(256) void als_cholesky_blocked_kernel(const int32_t
         __syncthreads();
 #pragma unroll
         for (int b = 0; b < MAXB; ++b) {
-          if (bi[b] < 0) continue;
+          if (bi[b] < 0 || (ko & 1)) continue;
 #pragma unroll
           for (int t = 0; t < kCholTile; ++t) {
             const float4 u4 = *reinterpret_cast<const float4 *>(ut + t * US + 4 * bi[b]);
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(256) void als_cholesky_blocked_kernel(const int32_t
     // ---- right-looking Cholesky of the first f columns, 8 columns per panel ---------------------------------------------------
     for (int k0 = 0; k0 < f; k0 += kCholPanel) {
       const int nb = min(kCholPanel, f - k0);
-      if (wave == 0) {
+      if (wave == 0 && !(ko & 2)) {
         // The panel -- columns k0 .. k0 + nb - 1 over rows k0 .. f -- in REGISTERS of one wavefront: lane l holds rows
         // k0 + l + 64 r.  Row k0 + c is lane c's first row, so the pivot and the sub-diagonal entries a column step needs travel
         // by v_readlane; nothing touches the LDS between the load and the store of the panel (a first version walked the
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(256) void als_cholesky_blocked_kernel(const int32_t
       if (*flag) break;  // uniform
       // trailing update: A[i][j] -= sum_c L[i][k0+c] L[j][k0+c] for j >= k0 + nb (a multiple of 4 unless this is the last panel)
       const int jb0 = (k0 + nb) >> 2;
-      if (nb == kCholPanel && jb0 < nbr) {
+      if (nb == kCholPanel && jb0 < nbr && !(ko & 4)) {
         // blocks (bi, bj) with jb0 <= bj <= bi: numbered row after row from block-row jb0
         const int rows_b = nbr - jb0;
         for (int t = tid;; t += 256) {
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(256) void als_cholesky_blocked_kernel(const int32_t
       continue;
     }
     // back substitution L^T x = z with one wavefront; lane l owns z[l + 64 m]
-    if (tid < 64) {
+    if (tid < 64 && !(ko & 8)) {
       constexpr int MAXV = 4;  // f <= 256
       float z[MAXV];
 #pragma unroll
@@ -927,14 +928,21 @@ int64_t least_squares_cholesky(const imp_csr *C, imp_matrix *X, const imp_matrix
       const size_t a_words = packed ? (size_t)m * (m + 1) / 2 : (size_t)m * lda;
       lds = (((a_words + 3) & ~(size_t)3) + (size_t)kCholTile * 4 * (nbc + nbr) + (size_t)m * kCholPanel + 4) * sizeof(float);
     }
-    auto kern = unblocked ? (packed ? als_cholesky_kernel<true> : als_cholesky_kernel<false>)
-                          : (packed ? als_cholesky_blocked_kernel<true> : als_cholesky_blocked_kernel<false>);
-    IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
     int grid = std::min(n_block, ctx().num_cus * per_cu * (unblocked ? 1 : 4));  // smaller fixed shares of the length-sorted schedule
     IMP_PROF("als_cholesky_rows");
-    kern<<<grid, 256, lds, stream()>>>(C->order.data(), 0, n_block, C->indptr.data(), C->indices.data(), C->data.data(), X->f32(),
-                                       Y->f32(), YtY->f32(), f, (float)reg, lda, g_failed);
+    if (unblocked) {
+      auto kern = packed ? als_cholesky_kernel<true> : als_cholesky_kernel<false>;
+      IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      kern<<<grid, 256, lds, stream()>>>(C->order.data(), 0, n_block, C->indptr.data(), C->indices.data(), C->data.data(), X->f32(),
+                                         Y->f32(), YtY->f32(), f, (float)reg, lda, g_failed);
+    } else {
+      static const int ko = getenv("IMP_CHOL_KO") ? atoi(getenv("IMP_CHOL_KO")) : 0;  // timing-only knock-outs of the phases
+      auto kern = packed ? als_cholesky_blocked_kernel<true> : als_cholesky_blocked_kernel<false>;
+      IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      kern<<<grid, 256, lds, stream()>>>(C->order.data(), 0, n_block, C->indptr.data(), C->indices.data(), C->data.data(), X->f32(),
+                                         Y->f32(), YtY->f32(), f, (float)reg, lda, g_failed, ko);
+    }
     IMP_CHECK_HIP(hipGetLastError());
   }
   zero_rows(C->order.data(), C->first_empty(), C->n_empty(), X->f32(), f);

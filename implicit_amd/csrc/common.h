@@ -91,6 +91,7 @@ void sync();  // hipStreamSynchronize on the library stream
 void sync_call();
 bool team16_as_cluster();    // als_cg_cluster.hip: rows of (256,512] nnz on clusters of two workgroups instead of team16
 bool cluster_fault_pending();  // als_cg_cluster.hip: a cluster exchange timed out since the last check (clears the flag)
+bool nm_enabled();           // als_cg_nm.hip: long rows of the f = 64 / 128 path through their explicit normal matrix (IMP_NM=0: clusters + streamed)
 
 // ---- launch-time profiler (HIP events on the library stream) ------------------------------------
 struct ProfScope {
@@ -168,6 +169,7 @@ struct Context {
   DeviceArray<float> barrier_word;              // operand of the RCCL barrier (comm.hip)
   DeviceArray<unsigned long long> cluster_xchg;  // partial-vector exchange slots of the cluster kernels (als_cg_cluster.hip)
   unsigned *cluster_fault = nullptr;             // host-mapped word: set by a cluster kernel whose exchange timed out
+  DeviceArray<int> nm_ticket;                    // work counter of the normal-matrix kernel (als_cg_nm.hip), reset by every launch
   DeviceArray<unsigned> cluster_fault_rows;      // rows a faulted cluster left to the fix-up kernel; their count sits behind the exchange slots (als_cg_cluster.hip)
 };
 inline hipStream_t stream() { return ctx().stream; }
@@ -261,6 +263,11 @@ struct imp_csr {
   static constexpr int kCholLongRow = 1024, kCholSegment = 1024;
   LongPlan plan_chol;
   int32_t cluster_cut[4] = {0, 0, 0, 0};
+  // every row of class 0 cut into plain runs of `nm_segment` nonzeros (2048 .. 16384: about eight segments per CU and launch, so
+  // that neither the tail of the launch nor the partial matrices of the cut rows weigh): the work list of the normal-matrix
+  // kernels (als_cg_nm.hip).  The first nm_multi_rows rows (those longer than one segment) own the first nm_multi_segs segments.
+  LongPlan plan_nm;
+  int32_t nm_segment = 2048, nm_multi_rows = 0, nm_multi_segs = 0;
   // A matrix with more than 2^31 - 1 nonzeros (imp_csr_create64) is held as consecutive row blocks, each a complete
   // imp_csr of its own with int32 offsets; the top-level object then only carries rows / cols / nnz and the solver
   // entry points walk the blocks (every row solve is independent of the others).

@@ -833,8 +833,23 @@ int imp_csr_create(int32_t rows, int32_t cols, int64_t nnz, const int32_t *indpt
     build_plan(m->cluster_cut[0], m->plan_xl, std::min(stripe_reuse, 2.0), segment);
     static_assert(imp_csr::kCholLongRow == imp_csr::kClusterRow >> 2, "plan_chol covers order[0 .. cluster_cut[2])");
     build_plan(m->cluster_cut[2], m->plan_chol, 1e30, imp_csr::kCholSegment);  // never striped
+    {
+      int64_t long_nnz = 0;
+      for (int32_t li = 0; li < n_long; ++li) long_nnz += indptr[order[li] + 1] - indptr[order[li]];
+      int32_t seg = 2048;
+      while (seg < 16384 && (int64_t)seg * ctx().num_cus * 8 < long_nnz) seg *= 2;
+      if (const char *e = getenv("IMP_NM_SEGMENT")) seg = std::max(64, atoi(e));
+      m->nm_segment = seg;
+      for (int32_t li = 0; li < n_long; ++li) {
+        const int32_t len = indptr[order[li] + 1] - indptr[order[li]];
+        if (len <= seg) break;  // descending lengths
+        m->nm_multi_rows++;
+        m->nm_multi_segs += (len + seg - 1) / seg;
+      }
+      build_plan(n_long, m->plan_nm, 1e30, seg);  // never striped: a row's segments are consecutive runs
+    }
     sync();
-    lap("long-row plans (xl, chol)");
+    lap("long-row plans (xl, chol, nm)");
     *out = m.release();
   });
 }
