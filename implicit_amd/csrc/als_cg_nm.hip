@@ -17,21 +17,23 @@
 //     M = f/4 rows m = i / 4.  A_u then consists of 4 x 4 tiles T(I,J)[m][n] = A_u[4m+I][4n+J]; the 10 tiles with I >= J cover
 //     every unordered pair.  f = 64: the same with v_mfma_f32_16x16x32_f16 (M = 16, 4 lane groups, 32 nonzeros per step).
 //   * Precision: fp32 operands are split into two fp16 halves x = h + l (h = rn16(x), l = rn16(x - h): 22 significant bits) and
-//     the tile takes three products  u_h y_h + u_h y_l + u_l y_h  (u = w y, w = |c| - 1); the dropped u_l y_l is 2^-22 of the
-//     term, fp32 accumulation.  The weights of a segment are scaled by a power of two so that |w| <= 1 (fp16 range: a
-//     confidence of 10^5 would overflow otherwise), undone exactly when the tile leaves the accumulators.  fp16 factor storage:
-//     y IS an fp16 number, two products.   Factors beyond +-65504 would overflow the operands (no ALS factor is).
-//   * Parallelism inside the workgroup: the four wavefronts take every fourth step of 16 (32) nonzeros and keep their own ten
-//     accumulator tiles (160 registers at f = 128); at the end they add them into the LDS image of A_u with ds_add_f32.  No
-//     barrier and no LDS traffic inside the nonzero loop.
+//     the tile takes three products  u_h y_h + u_l y_h + u_h y_l  (u and y carry the weight w = |c| - 1 between them, see
+//     nm_build); the dropped u_l y_l is 2^-22 of the term, fp32 accumulation.  fp16 factor storage: y IS an fp16 number, two
+//     products.  Factors beyond +-16 would overflow the operands of a 10^7 confidence (no ALS factor is that large).
+//   * Inside the workgroup the TILES are dealt to the four wavefronts (3, 3, 2, 2) and the converted operands travel through the
+//     LDS: every nonzero is converted once, every tile's sum lives in one wavefront's accumulators from the first nonzero to
+//     the last, and the image of A_u is written by the tiles' owners with plain stores (nm_build).
 //   * Rows of more than `segment` nonzeros (imp_csr::plan_nm: 2048 .. 16384, by the amount of long-row work) are cut into
-//     segments, one workgroup each; their partial matrices go through a workspace and a second kernel sums them in segment order
-//     and runs the CG.  Every other row is finished by the workgroup that built its matrix.
+//     segments; their partial images go through a workspace, a second kernel sums them in segment order (one workgroup per
+//     sixteenth of an image) and a third runs the CG.  Every other row is finished by the workgroup that built its matrix.
+//     Segments are handed out by a ticket counter, longest first.
 //   * CG on the LDS image: the reference's recurrences (als.cu:45-109) with the product A_u p evaluated from the explicit matrix;
 //     256 threads, 256/f threads per matrix row.
 //
-// Cost model (f = 128, per 64 nonzeros and CU): 4 x 30 MFMA of 32 cycles on 4 SIMDs = 960 cycles of matrix pipe, ~220 VALU
-// instructions per wavefront for the splits; 32 KB gathered.  IMP_NM=0 restores the cluster + streamed kernels (A/B, parity).
+// Measured (configs[2], per iteration): long-row class 0.89 -> 0.54 ms, 0.27 -> 0.46 of the HBM roofline; the rounds are bounded
+// by the alternation of their two phases (conversion on the VALU, products on the matrix pipe: two workgroups per CU do not stay
+// in antiphase), not by memory: knock-outs and counters in DESIGN.md section 4.2.  IMP_NM=0 restores the cluster + streamed
+// kernels (A/B, parity).
 #include "als_qf_common.h"
 #include "common.h"
 #include "wave_ops.h"
@@ -185,43 +187,68 @@ __device__ __forceinline__ void nm_build(const int32_t *__restrict__ indices, co
     e0 = load_entry(0), e1 = load_entry(1);  // beyond the segment: the last entry with weight 0
     gather(e0, yb);
   }
-  struct Operands {
-    half8 uh, ul, yh, yl;
+  // ---- consume: the sequence of one wavefront per step, written out per wavefront so that a block's operands are read ONCE for
+  // all the tiles that use them (28 quads per step and workgroup instead of 40: the exchange through the LDS is what bounds the
+  // round), and the operands of the next tile / the next step are on their way while the three products of the current tile run
+  //   wave 0: (0,0) (1,0) (1,1)   wave 1: (2,0) (2,1) (2,2)   wave 2: (3,0) (3,1)   wave 3: (3,2) (3,3)
+  struct Pair {
+    half8 h, l;
   };
-  const float *op_i[L::kSlots], *op_j[L::kSlots];  // this lane's quads of block I (uh; ul one kind further) and J (yh; yl)
-#pragma unroll
-  for (int k = 0; k < L::kSlots; ++k) {
-    op_i[k] = ops + (0 * 4 + tI[k]) * L::QUAD + 4 * lane;
-    op_j[k] = ops + (2 * 4 + tJ[k]) * L::QUAD + 4 * lane;
-  }
-  auto fetch_ops = [&](int st, int k) {
-    Operands o;
-    o.uh = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4 *>(op_i[k] + st * 16 * L::QUAD));
-    o.ul = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4 *>(op_i[k] + st * 16 * L::QUAD + 4 * L::QUAD));
-    o.yh = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4 *>(op_j[k] + st * 16 * L::QUAD));
-    if constexpr (!kHalf) o.yl = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4 *>(op_j[k] + st * 16 * L::QUAD + 4 * L::QUAD));
-    return o;
+  const float *lane_ops = ops + 4 * lane;
+  auto ld_u = [&](int st, int I) {  // uh, ul of block I
+    Pair p;
+    p.h = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4 *>(lane_ops + (st * 16 + 0 * 4 + I) * L::QUAD));
+    p.l = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4 *>(lane_ops + (st * 16 + 1 * 4 + I) * L::QUAD));
+    return p;
   };
-  auto products = [&](auto k, const Operands &o) {
-    acc[k.value] = S::mfma(o.uh, o.yh, acc[k.value]);
-    acc[k.value] = S::mfma(o.ul, o.yh, acc[k.value]);
-    if constexpr (!kHalf) acc[k.value] = S::mfma(o.uh, o.yl, acc[k.value]);  // fp16 factors: 2^e y is an fp16 number too, no low half
+  auto ld_y = [&](int st, int J) {  // yh, yl of block J (fp16 factors: 2^e y is an fp16 number too, no low half)
+    Pair p;
+    p.h = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4 *>(lane_ops + (st * 16 + 2 * 4 + J) * L::QUAD));
+    if constexpr (!kHalf) p.l = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4 *>(lane_ops + (st * 16 + 3 * 4 + J) * L::QUAD));
+    else p.l = p.h;
+    return p;
   };
-  auto consume = [&](auto ns) {
-    constexpr int NS = ns.value;
-    Operands o0 = fetch_ops(0, 0);
+  auto products = [&](auto k, const Pair &u, const Pair &y) {
+    acc[k.value] = S::mfma(u.h, y.h, acc[k.value]);
+    acc[k.value] = S::mfma(u.l, y.h, acc[k.value]);
+    if constexpr (!kHalf) acc[k.value] = S::mfma(u.h, y.l, acc[k.value]);
+  };
+  auto consume = [&]() {
+    if (wave == 0) {
+      Pair u0 = ld_u(0, 0), y0 = ld_y(0, 0);
 #pragma unroll 1
-    for (int st = 0; st < 4; ++st) {
-      const Operands o1 = fetch_ops(st, 1);
-      products(idx_t<0>{}, o0);
-      if constexpr (NS == 3) {
-        const Operands o2 = fetch_ops(st, 2);
-        products(idx_t<1>{}, o1);
-        o0 = fetch_ops(min(st + 1, 3), 0);  // after the last step: a re-read nobody uses
-        products(idx_t<2>{}, o2);
-      } else {
-        o0 = fetch_ops(min(st + 1, 3), 0);
-        products(idx_t<1>{}, o1);
+      for (int st = 0; st < 4; ++st) {
+        const Pair u1 = ld_u(st, 1);
+        products(idx_t<0>{}, u0, y0);
+        const Pair y1 = ld_y(st, 1);
+        products(idx_t<1>{}, u1, y0);
+        u0 = ld_u(min(st + 1, 3), 0), y0 = ld_y(min(st + 1, 3), 0);  // after the last step: a re-read nobody uses
+        products(idx_t<2>{}, u1, y1);
+      }
+    } else if (wave == 1) {
+      Pair u2 = ld_u(0, 2), y0 = ld_y(0, 0);
+#pragma unroll 1
+      for (int st = 0; st < 4; ++st) {
+        const Pair y1 = ld_y(st, 1);
+        products(idx_t<0>{}, u2, y0);
+        const Pair y2 = ld_y(st, 2);
+        products(idx_t<1>{}, u2, y1);
+        const Pair un = ld_u(min(st + 1, 3), 2);
+        y0 = ld_y(min(st + 1, 3), 0);
+        products(idx_t<2>{}, u2, y2);
+        u2 = un;
+      }
+    } else {
+      const int J0 = wave == 2 ? 0 : 2;  // wave 2: (3,0) (3,1); wave 3: (3,2) (3,3)
+      Pair u3 = ld_u(0, 3), ya = ld_y(0, J0);
+#pragma unroll 1
+      for (int st = 0; st < 4; ++st) {
+        const Pair yb2 = ld_y(st, J0 + 1);
+        products(idx_t<0>{}, u3, ya);
+        const Pair un = ld_u(min(st + 1, 3), 3);
+        ya = ld_y(min(st + 1, 3), J0);
+        products(idx_t<1>{}, u3, yb2);
+        u3 = un;
       }
     }
   };
@@ -272,12 +299,8 @@ __device__ __forceinline__ void nm_build(const int32_t *__restrict__ indices, co
     }
     gather(e1, y);  // the landing registers are free again (beyond the last round: the segment's last row, unused)
     lds_barrier();
-    // ---- consume the four steps for the tiles of this wavefront: the operands of the next (step, tile) are on their way from
-    // the LDS while the three products of the current one run (one tile-step at a time left ~250 cycles of LDS + dependent
-    // matrix-instruction latency exposed per tile-step: 7.8 K cycles per round; all of a step's operands at once cost 32 more
-    // registers than this kernel has)
-    if (n_slots == 3) consume(std::integral_constant<int, 3>{});
-    else consume(std::integral_constant<int, 2>{});
+    // ---- consume the four steps for the tiles of this wavefront
+    consume();  // (raising the wave priority here changes nothing: 0.556 against 0.560 ms)
     lds_barrier();  // the exchange buffer is free again (and, after the last round, free for the image)
   };
 #pragma unroll 1

@@ -825,7 +825,12 @@ int64_t least_squares_cholesky(const imp_csr *C, imp_matrix *X, const imp_matrix
   const int f = (int)X->cols;
   if (f > 256) throw std::invalid_argument("least_squares_cholesky: factors must be <= 256 in this build");
   int lda = (f + 1) | 1;  // odd
-  const bool packed = f > 160;  // the square image of the augmented triangle no longer fits the LDS: packed rows
+  // Packed rows of the augmented triangle (i (i + 1) / 2 + j): a must beyond f = 160, where the square image no longer fits the
+  // LDS, and a gain well below that -- at f = 128 the packed image lets THREE workgroups share a CU instead of two (measured
+  // 248 -> 174 ms per configs[2]-shaped iteration for one multiplication more per address).  IMP_CHOL_PACKED=<f0> moves the
+  // switch-over (A/B; 1000: never below the LDS limit)
+  static const int packed_from = getenv("IMP_CHOL_PACKED") ? atoi(getenv("IMP_CHOL_PACKED")) : 96;
+  const bool packed = f > 160 || f >= packed_from;
   size_t lds = ((packed ? (size_t)(f + 1) * (f + 2) / 2 : (size_t)(f + 1) * lda) + (size_t)kCholTile * f + (size_t)kCholTile * (f + 1)) *
                sizeof(float);
   auto &failb = ctx().chol_failed;
