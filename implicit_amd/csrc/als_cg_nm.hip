@@ -79,7 +79,7 @@ template <int F> struct NmLayout {
   static constexpr int OPS = 4 * 16 * QUAD;    // floats of the exchange buffer (64 KB); the image re-uses the space afterwards
   static constexpr int NP = 256 / F;           // thread groups sharing a matrix row in the CG phase
   static constexpr int kVec = IMG > OPS ? IMG : OPS;  // offset of the vectors behind the image / exchange buffer
-  static constexpr size_t lds_floats = (size_t)kVec + 2 * F + NP * F + 64;  // image / operands | b | p | partial products | reduction slots
+  static constexpr size_t lds_floats = (size_t)kVec + 2 * F + NP * F + 64 + 4 * F;  // image / operands | b | p | partial products | reduction slots | b per wavefront
   __host__ __device__ static constexpr int at(int I, int J, int m, int n) { return ((I * 4 + J) * M + m) * TS + n; }
 };
 __device__ constexpr int nm_tile_i(int t) { return t < 1 ? 0 : t < 3 ? 1 : t < 6 ? 2 : 3; }
@@ -307,8 +307,16 @@ __device__ __forceinline__ void nm_build(const int32_t *__restrict__ indices, co
   for (int r = 0; r < n_rounds; ++r) round(r, yb);
   // b: lane (a, g) holds its nonzeros' share of factors 4a .. 4a+3 = positions c M + a
   if (!(ko & 2)) {
+    // (summed in a FIXED order: across the lane groups here, across the wavefronts by the caller -- ds_add_f32 would add in
+    // whatever order the wavefronts arrive, and the same sweep would differ in the last bit from run to run)
+    float *bstage = bvec + 2 * F + L::NP * F + 64;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) __hip_atomic_fetch_add(bvec + c * L::M + a, b4[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (int c = 0; c < 4; ++c) {
+      float v = b4[c];
+      if constexpr (S::KG == 4) v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (g == 0) bstage[wave * F + c * L::M + a] = v;
+    }
     // the image: every tile (and its mirror) is written by its one owner, gramian added on the way
     float *img = smem;
     const int n = S::col(lane);
@@ -415,8 +423,12 @@ __global__ __launch_bounds__(256, 2) void als_cg_nm_kernel(const LongPlanDev pla
     const int begin = plan.seg_begin[s], end = plan.seg_end[s];
     const bool whole = plan.row_seg[li + 1] - plan.row_seg[li] == 1;
     __syncthreads();  // the previous item's CG has read the image and b
-    if (tid < F) bvec[tid] = 0.f;
     nm_build<F, T>(indices, data, Y, gram_img, whole, begin, end, smem, bvec, tid, ko);
+    if (tid < F) {
+      const float *bstage = bvec + 2 * F + L::NP * F + 64;
+      bvec[tid] = (bstage[tid] + bstage[F + tid]) + (bstage[2 * F + tid] + bstage[3 * F + tid]);
+    }
+    __syncthreads();
     // the next ticket is drawn here: its round trip hides behind the CG / the store of the partial image
     int drawn = 0;
     if (tid == 0) drawn = (int)gridDim.x + atomicAdd(ticket, 1);
