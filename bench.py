@@ -95,7 +95,7 @@ PMC_KERNELS = {"als_cg_group_kernel": ("short", lambda s: 1), "als_cg_team_kerne
                "als_cg_qfgroup_kernel": ("short", lambda s: 1), "als_cg_qfteam_kernel": ("mid", lambda s: 1),
                "cg_long_partial": ("long", lambda s: 1 + s), "cg_long_combine_kernel": ("long", lambda s: 1 + s),
                "als_cg_cluster_kernel": ("long", lambda s: 1), "als_cg_nm_kernel": ("long", lambda s: 1),
-               "als_cg_nm_finish_kernel": ("long", lambda s: 1)}
+               "als_cg_nm_finish_kernel": ("long", lambda s: 1), "als_cg_nm_reduce_kernel": ("long", lambda s: 1)}
 
 
 def pmc_traffic_per_half_sweep(cg_steps):

@@ -16,7 +16,7 @@ here = os.path.dirname(os.path.abspath(__file__))
 
 
 def short(name):
-    return name.split("(")[0].replace("void ", "").replace("imp::", "")
+    return name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("imp::", "")
 
 
 stats = glob.glob(os.path.join(out_dir, "stats", "*", "*kernel_stats.csv"))
