@@ -213,46 +213,46 @@ __device__ __forceinline__ void nm_build(const int32_t *__restrict__ indices, co
     acc[k.value] = S::mfma(u.l, y.h, acc[k.value]);
     if constexpr (!kHalf) acc[k.value] = S::mfma(u.h, y.l, acc[k.value]);
   };
-  auto consume = [&]() {
+  auto consume = [&](int s0, int s1) {  // steps s0 .. s1 - 1 of the exchange buffer
     if (wave == 0) {
-      Pair u0 = ld_u(0, 0), y0 = ld_y(0, 0);
+      Pair u0 = ld_u(s0, 0), y0 = ld_y(s0, 0);
 #pragma unroll 1
-      for (int st = 0; st < 4; ++st) {
+      for (int st = s0; st < s1; ++st) {
         const Pair u1 = ld_u(st, 1);
         products(idx_t<0>{}, u0, y0);
         const Pair y1 = ld_y(st, 1);
         products(idx_t<1>{}, u1, y0);
-        u0 = ld_u(min(st + 1, 3), 0), y0 = ld_y(min(st + 1, 3), 0);  // after the last step: a re-read nobody uses
+        u0 = ld_u(min(st + 1, s1 - 1), 0), y0 = ld_y(min(st + 1, s1 - 1), 0);  // after the last step: a re-read nobody uses
         products(idx_t<2>{}, u1, y1);
       }
     } else if (wave == 1) {
-      Pair u2 = ld_u(0, 2), y0 = ld_y(0, 0);
+      Pair u2 = ld_u(s0, 2), y0 = ld_y(s0, 0);
 #pragma unroll 1
-      for (int st = 0; st < 4; ++st) {
+      for (int st = s0; st < s1; ++st) {
         const Pair y1 = ld_y(st, 1);
         products(idx_t<0>{}, u2, y0);
         const Pair y2 = ld_y(st, 2);
         products(idx_t<1>{}, u2, y1);
-        const Pair un = ld_u(min(st + 1, 3), 2);
-        y0 = ld_y(min(st + 1, 3), 0);
+        const Pair un = ld_u(min(st + 1, s1 - 1), 2);
+        y0 = ld_y(min(st + 1, s1 - 1), 0);
         products(idx_t<2>{}, u2, y2);
         u2 = un;
       }
     } else {
       const int J0 = wave == 2 ? 0 : 2;  // wave 2: (3,0) (3,1); wave 3: (3,2) (3,3)
-      Pair u3 = ld_u(0, 3), ya = ld_y(0, J0);
+      Pair u3 = ld_u(s0, 3), ya = ld_y(s0, J0);
 #pragma unroll 1
-      for (int st = 0; st < 4; ++st) {
+      for (int st = s0; st < s1; ++st) {
         const Pair yb2 = ld_y(st, J0 + 1);
         products(idx_t<0>{}, u3, ya);
-        const Pair un = ld_u(min(st + 1, 3), 3);
-        ya = ld_y(min(st + 1, 3), J0);
+        const Pair un = ld_u(min(st + 1, s1 - 1), 3);
+        ya = ld_y(min(st + 1, s1 - 1), J0);
         products(idx_t<1>{}, u3, yb2);
         u3 = un;
       }
     }
   };
-  auto round = [&](int r, float4 (&y)[8]) {
+  auto produce = [&](int r, float4 (&y)[8]) {
     // The entries rotate HERE, not where e2 is loaded: a register move of a value still in flight makes the compiler wait for
     // its load, and -- the queue being in order -- at the end of the produce phase that wait would also cover the gathers just
     // issued.  Here it covers the loads older than e2: the rows of THIS round, which are due anyway.
@@ -298,13 +298,17 @@ __device__ __forceinline__ void nm_build(const int32_t *__restrict__ indices, co
       }                                     // vector-memory load -- waiting for it (vmcnt 0) drains the gathers in flight
     }
     gather(e1, y);  // the landing registers are free again (beyond the last round: the segment's last row, unused)
-    lds_barrier();
-    // ---- consume the four steps for the tiles of this wavefront
-    consume();  // (raising the wave priority here changes nothing: 0.556 against 0.560 ms)
-    lds_barrier();  // the exchange buffer is free again (and, after the last round, free for the image)
   };
+  // (A staggered schedule -- wavefronts 0, 1 convert in the first half of a trip, 2, 3 in the second, everybody multiplying the
+  // other pair's steps meanwhile, so that each workgroup keeps both pipes busy by itself -- measured 0.67 against 0.52 ms: the
+  // converting pair's conversion + two steps of products is a longer critical path per 32 nonzeros than the two-phase round's per 64.)
 #pragma unroll 1
-  for (int r = 0; r < n_rounds; ++r) round(r, yb);
+  for (int r = 0; r < n_rounds; ++r) {
+    produce(r, yb);
+    lds_barrier();
+    consume(0, 4);  // (raising the wave priority here changes nothing: 0.556 against 0.560 ms)
+    lds_barrier();  // the exchange buffer is free again (and, after the last round, free for the image)
+  }
   // b: lane (a, g) holds its nonzeros' share of factors 4a .. 4a+3 = positions c M + a
   if (!(ko & 2)) {
     // (summed in a FIXED order: across the lane groups here, across the wavefronts by the caller -- ds_add_f32 would add in
