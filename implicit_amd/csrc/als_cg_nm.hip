@@ -16,10 +16,13 @@
 //     positions 8g .. 8g+7) if the factor index is READ AS i = 4 m + I: the f factors split into 4 interleaved blocks I = i % 4 of
 //     M = f/4 rows m = i / 4.  A_u then consists of 4 x 4 tiles T(I,J)[m][n] = A_u[4m+I][4n+J]; the 10 tiles with I >= J cover
 //     every unordered pair.  f = 64: the same with v_mfma_f32_16x16x32_f16 (M = 16, 4 lane groups, 32 nonzeros per step).
-//   * Precision: fp32 operands are split into two fp16 halves x = h + l (h = rn16(x), l = rn16(x - h): 22 significant bits) and
-//     the tile takes three products  u_h y_h + u_l y_h + u_h y_l  (u and y carry the weight w = |c| - 1 between them, see
-//     nm_build); the dropped u_l y_l is 2^-22 of the term, fp32 accumulation.  fp16 factor storage: y IS an fp16 number, two
-//     products.  Factors beyond +-16 would overflow the operands of a 10^7 confidence (no ALS factor is that large).
+//   * Precision: fp32 operands are split into two fp16 halves x = h + l (h = rn16(x), l = rn16(x - h)) and the tile takes three
+//     products  u_h y_h + u_l y_h + u_h y_l  (u and y carry the weight w = |c| - 1 between them, see nm_build), fp32
+//     accumulation.  |x - (h + l)| <= max(2^-23 |x|, 2^-25): the low half is an fp16 subnormal below |x| = 1/8, so factors of
+//     0.01 .. 0.1 carry 18 .. 21 significant bits per operand and a product is good to ~1e-6 of itself, unbiased
+//     (tests/test_nm_split_model.py restates this arithmetic in numpy); a row's sum comes out CLOSER to the float64 answer than
+//     the fp32 reference's dot-product chain (PARITY.md).  fp16 factor storage: y IS an fp16 number, two products.  Factors
+//     beyond +-13 would overflow the operands of a 10^7 confidence (no ALS factor is that large).
 //   * Inside the workgroup the TILES are dealt to the four wavefronts (3, 3, 2, 2) and the converted operands travel through the
 //     LDS: every nonzero is converted once, every tile's sum lives in one wavefront's accumulators from the first nonzero to
 //     the last, and the image of A_u is written by the tiles' owners with plain stores (nm_build).
