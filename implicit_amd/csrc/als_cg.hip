@@ -642,6 +642,9 @@ static void launch_all(const imp_csr *C, T *X, const T *Y, const float *A0, int 
     // f = 64 / 128: rows of 513 .. kClusterRow nonzeros are resident across a cluster of workgroups (als_cg_cluster.hip);
     // only the rows beyond that are streamed.  IMP_NO_CLUSTER=1: every long row streamed (A/B, parity)
     static const bool no_cluster = getenv("IMP_NO_CLUSTER") != nullptr;
+    // IMP_CLASS_STREAMS=1: the row classes' kernels on four streams, joined before the call returns (common.h ClassStreams)
+    static const bool class_streams = getenv("IMP_CLASS_STREAMS") && atoi(getenv("IMP_CLASS_STREAMS")) != 0;
+    ClassStreams streams(class_streams);
     if (nm_enabled() && !no_cluster && !team16_as_cluster()) {
       least_squares_cg_nm<T>(C, X, Y, A0, f, cg_steps);  // round 4: the row's normal matrix on the matrix cores, CG on the LDS image
     } else {

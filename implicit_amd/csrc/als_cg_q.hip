@@ -421,6 +421,7 @@ template <int F, typename T> static void run_classes_q(const imp_csr *C, T *X, c
     const int mask = std::is_same<T, __half>::value ? (half64 ? 15 : 0) : float64;
     if (mask) {
       auto cls = [&](int bit, int width64, int width32, int lo, int hi, const char *name) {
+        class_stream_next();
         if (mask & bit) launch_team_tile64<T>(C, F, width64, lo, hi - lo, X, Y, A0, cg_steps, name);
         else launch_team_fused<T>(C, F, width32, lo, hi - lo, X, Y, A0, cg_steps, name);
       };
@@ -428,6 +429,7 @@ template <int F, typename T> static void run_classes_q(const imp_csr *C, T *X, c
       cls(2, 4, 8, b[2], b[3], "als_cg_team8_rows");
       cls(4, 2, 4, b[3], b[4], "als_cg_team4_rows");
       cls(8, 1, 2, b[4], b[5], "als_cg_team2_rows");
+      class_stream_next();
       if constexpr (F == 64) launch_team_fused<T>(C, F, 1, b[5], b[7] - b[5], X, Y, A0, cg_steps, "als_cg_short_rows");
       else launch_group_fused<T>(C, F, b[5], b[7] - b[5], X, Y, A0, cg_steps, "als_cg_short_rows");
       return;
@@ -438,6 +440,7 @@ template <int F, typename T> static void run_classes_q(const imp_csr *C, T *X, c
   static const int fused = getenv("IMP_TEAM_FUSED") ? atoi(getenv("IMP_TEAM_FUSED")) : 63;
   static const bool want_stats = getenv("IMP_CG_STATS") != nullptr;
   auto team = [&](int bit, int width, int first, int count, const char *name, auto old) {
+    class_stream_next();
     if (fused & bit) launch_team_fused<T>(C, F, width, first, count, X, Y, A0, cg_steps, name);  // IMP_CG_STATS: its own instrumented form
     else old(first, count, name);
   };
@@ -456,6 +459,7 @@ template <int F, typename T> static void run_classes_q(const imp_csr *C, T *X, c
   // and the lock step costs more than the matrix pipe saves.  IMP_SHORT_TEAM1=0/1 forces one or the other (A/B).
   static const int short_team1 = getenv("IMP_SHORT_TEAM1") ? atoi(getenv("IMP_SHORT_TEAM1")) : -1;
   const bool team1 = short_team1 >= 0 ? short_team1 != 0 : F == 64;
+  if (!team1 || F != 64) class_stream_next();  // (the f = 64 team form of the short rows goes through `team`, which moves on itself)
   if (team1) {
     if constexpr (F == 64)
       team(16, 1, b[5], b[7] - b[5], "als_cg_short_rows",

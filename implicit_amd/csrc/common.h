@@ -152,6 +152,13 @@ struct Context {
   // iteration -- K solve chunks, their exchanges, two all-reduces -- and waits once)
   bool deferred = false;
   hipStream_t occupy_stream = nullptr;  // imp_debug_occupy
+  // Row-class streams (als_cg.hip launch_all, IMP_CLASS_STREAMS): the row classes of a half sweep solve disjoint rows, so their
+  // kernels may run side by side -- each persistent kernel's tail (workgroups finishing at different times) is then filled by
+  // the next class's workgroups instead of idling until the launch ends.  `cur` is what stream() hands out: the library stream
+  // except between ClassStreams::next() and ClassStreams::join().
+  hipStream_t side[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t fork_event = nullptr, join_event[3] = {nullptr, nullptr, nullptr};
+  hipStream_t cur = nullptr;
   std::recursive_mutex mutex;
   std::mutex small_mutex;                  // the free lists below (a Storage may die on a thread that holds another device's lock)
   std::vector<void *> small_free[24];      // [log2 size]: recycled device blocks of 256 B .. 4 MB (Storage)
@@ -172,7 +179,21 @@ struct Context {
   DeviceArray<int> nm_ticket;                    // work counter of the normal-matrix kernel (als_cg_nm.hip), reset by every launch
   DeviceArray<unsigned> cluster_fault_rows;      // rows a faulted cluster left to the fix-up kernel; their count sits behind the exchange slots (als_cg_cluster.hip)
 };
-inline hipStream_t stream() { return ctx().stream; }
+inline hipStream_t stream() {
+  auto &c = ctx();
+  return c.cur ? c.cur : c.stream;
+}
+void class_stream_next();  // next() of the ClassStreams object alive on this thread, if any
+bool prof_per_kernel();  // the profiler records every kernel scope (no name filter): launches stay on one stream, one after the other
+// Deals the launches of one half sweep to the library stream and three side streams, and joins them again (RAII).
+struct ClassStreams {
+  explicit ClassStreams(bool enable);
+  ~ClassStreams();
+  void next();  // the launches that follow go to the next stream of the rotation (class_stream_next() for code further down the call chain)
+  bool on = false;
+  int turn = 0;
+  bool used[3] = {false, false, false};
+};
 // a C-ABI entry point is about to write `bytes` at `dst` through the library: a padded copy of Y made from memory it overlaps
 // (least_squares_cg_padded) is no longer to be trusted
 inline void note_device_write(const void *dst, size_t bytes) {

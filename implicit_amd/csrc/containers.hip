@@ -72,6 +72,52 @@ static std::vector<ProfPending> g_prof_pending;
 static std::vector<hipEvent_t> g_event_pool;
 
 bool prof_enabled() { return g_prof_on; }
+bool prof_per_kernel() { return g_prof_on && g_prof_filter.empty(); }
+
+static thread_local ClassStreams *t_class_streams = nullptr;
+void class_stream_next() {
+  if (t_class_streams) t_class_streams->next();
+}
+ClassStreams::ClassStreams(bool enable) {
+  auto &c = ctx();
+  on = enable && !c.cur && !prof_per_kernel() && !t_class_streams;
+  if (!on) return;
+  t_class_streams = this;
+  if (!c.fork_event) {
+    IMP_CHECK_HIP(hipEventCreateWithFlags(&c.fork_event, hipEventDisableTiming));
+    for (int i = 0; i < 3; ++i) {
+      IMP_CHECK_HIP(hipStreamCreateWithFlags(&c.side[i], hipStreamNonBlocking));
+      IMP_CHECK_HIP(hipEventCreateWithFlags(&c.join_event[i], hipEventDisableTiming));
+    }
+  }
+  IMP_CHECK_HIP(hipEventRecord(c.fork_event, c.stream));  // everything queued so far (gramian, exchanges) is ordered before the classes
+}
+void ClassStreams::next() {
+  if (!on) return;
+  auto &c = ctx();
+  turn = (turn + 1) & 3;
+  if (turn == 0) {
+    c.cur = nullptr;
+    return;
+  }
+  const int i = turn - 1;
+  if (!used[i]) {
+    (void)hipStreamWaitEvent(c.side[i], c.fork_event, 0);
+    used[i] = true;
+  }
+  c.cur = c.side[i];
+}
+ClassStreams::~ClassStreams() {
+  if (!on) return;
+  t_class_streams = nullptr;
+  auto &c = ctx();
+  c.cur = nullptr;
+  for (int i = 0; i < 3; ++i)
+    if (used[i]) {
+      (void)hipEventRecord(c.join_event[i], c.side[i]);
+      (void)hipStreamWaitEvent(c.stream, c.join_event[i], 0);
+    }
+}
 
 static hipEvent_t get_event() {
   if (!g_event_pool.empty()) {
