@@ -32,7 +32,7 @@ namespace imp {
 
 template <typename T> void least_squares_cg_q(const imp_csr *C, T *X, const T *Y, const float *A0, int f, int cg_steps);  // als_cg_q.hip
 template <typename T> void least_squares_cg_cluster(const imp_csr *C, T *X, const T *Y, const float *A0, int f, int cg_steps);  // als_cg_cluster.hip
-template <typename T> void least_squares_cg_nm(const imp_csr *C, T *X, const T *Y, const float *A0, int f, int cg_steps);  // als_cg_nm.hip
+template <typename T> void least_squares_cg_nm(const imp_csr *C, T *X, const T *Y, size_t y_rows, const float *A0, int f, int cg_steps);  // als_cg_nm.hip
 
 // ---- generic per-nnz pass (any f): 4 gathers in flight, one DPP all-reduce per dot -------------------
 template <int VPL, bool VEC, bool FIRST>
@@ -635,7 +635,7 @@ static void launch_long(const imp_csr *C, const LongPlan &lp, T *X, const T *Y, 
 }
 
 template <int VPL, bool VEC, bool A_LDS, typename T>
-static void launch_all(const imp_csr *C, T *X, const T *Y, const float *A0, int f, int cg_steps) {
+static void launch_all(const imp_csr *C, T *X, const T *Y, size_t y_rows, const float *A0, int f, int cg_steps) {
   // schedule classes (imp_csr): 0 long (segment-split), 1..4 mid, 5..6 short, 7 empty
   const int32_t *b = C->bin_start;
   if constexpr (VEC && A_LDS && (VPL == 1 || VPL == 2)) {
@@ -646,7 +646,7 @@ static void launch_all(const imp_csr *C, T *X, const T *Y, const float *A0, int 
     static const bool class_streams = getenv("IMP_CLASS_STREAMS") && atoi(getenv("IMP_CLASS_STREAMS")) != 0;
     ClassStreams streams(class_streams);
     if (nm_enabled() && !no_cluster && !team16_as_cluster()) {
-      least_squares_cg_nm<T>(C, X, Y, A0, f, cg_steps);  // round 4: the row's normal matrix on the matrix cores, CG on the LDS image
+      least_squares_cg_nm<T>(C, X, Y, y_rows, A0, f, cg_steps);  // round 4: the row's normal matrix on the matrix cores, CG on the LDS image
     } else {
       launch_long<VPL, VEC, A_LDS, T>(C, no_cluster ? C->plan_all : C->plan_xl, X, Y, A0, f, cg_steps);
       if (!no_cluster) least_squares_cg_cluster<T>(C, X, Y, A0, f, cg_steps);
@@ -751,9 +751,9 @@ static void least_squares_cg_padded(const imp_csr *C, imp_matrix *X, const imp_m
     pad_gram_kernel<<<grid((size_t)F * F), 256, 0, stream()>>>(YtY->f32(), c.pad_gram.data(), f, F);
     IMP_CHECK_HIP(hipGetLastError());
   }
-  if (F == 64) launch_all<1, true, true, float>(C, c.pad_x.data(), c.pad_y.data(), c.pad_gram.data(), F, cg_steps);
-  else if (F == 128) launch_all<2, true, true, float>(C, c.pad_x.data(), c.pad_y.data(), c.pad_gram.data(), F, cg_steps);
-  else launch_all<4, true, false, float>(C, c.pad_x.data(), c.pad_y.data(), c.pad_gram.data(), F, cg_steps);
+  if (F == 64) launch_all<1, true, true, float>(C, c.pad_x.data(), c.pad_y.data(), ry, c.pad_gram.data(), F, cg_steps);
+  else if (F == 128) launch_all<2, true, true, float>(C, c.pad_x.data(), c.pad_y.data(), ry, c.pad_gram.data(), F, cg_steps);
+  else launch_all<4, true, false, float>(C, c.pad_x.data(), c.pad_y.data(), ry, c.pad_gram.data(), F, cg_steps);
   {
     IMP_PROF("unpad_factors");
     if (rx) unpad_rows_kernel<<<grid(rx * f), 256, 0, stream()>>>(c.pad_x.data(), X->f32(), rx, f, F);
@@ -771,8 +771,8 @@ void least_squares_cg(const imp_csr *C, imp_matrix *X, const imp_matrix *YtY, co
     if (!cg_native_half(f)) throw std::invalid_argument("least_squares: fp16 factors with this factor count are converted by the caller");
     __half *x = reinterpret_cast<__half *>(X->data);
     const __half *y = reinterpret_cast<const __half *>(Y->data);
-    if (f == 64) launch_all<1, true, true, __half>(C, x, y, a0, f, cg_steps);
-    else launch_all<2, true, true, __half>(C, x, y, a0, f, cg_steps);
+    if (f == 64) launch_all<1, true, true, __half>(C, x, y, Y->rows, a0, f, cg_steps);
+    else launch_all<2, true, true, __half>(C, x, y, Y->rows, a0, f, cg_steps);
     return;
   }
   float *x = X->f32();
@@ -783,17 +783,17 @@ void least_squares_cg(const imp_csr *C, imp_matrix *X, const imp_matrix *YtY, co
     least_squares_cg_padded(C, X, YtY, Y, cg_steps, f < 64 ? 64 : (f < 128 ? 128 : 256));
     return;
   }
-  if (f == 64) launch_all<1, true, true, float>(C, x, y, a0, f, cg_steps);
-  else if (f == 128) launch_all<2, true, true, float>(C, x, y, a0, f, cg_steps);
-  else if (f == 256) launch_all<4, true, false, float>(C, x, y, a0, f, cg_steps);
-  else if (f < 64) launch_all<1, false, true, float>(C, x, y, a0, f, cg_steps);
-  else if (f < 128) launch_all<2, false, true, float>(C, x, y, a0, f, cg_steps);
-  else if (f < 192) launch_all<3, false, true, float>(C, x, y, a0, f, cg_steps);
-  else if (f < 256) launch_all<4, false, false, float>(C, x, y, a0, f, cg_steps);
-  else if (f <= 384) launch_all<6, false, false, float>(C, x, y, a0, f, cg_steps);
-  else if (f <= 512) launch_all<8, false, false, float>(C, x, y, a0, f, cg_steps);
-  else if (f <= 768) launch_all<12, false, false, float>(C, x, y, a0, f, cg_steps);
-  else if (f <= 1024) launch_all<16, false, false, float>(C, x, y, a0, f, cg_steps);  // the reference's limit: one thread per factor, als.cu:177-179
+  if (f == 64) launch_all<1, true, true, float>(C, x, y, Y->rows, a0, f, cg_steps);
+  else if (f == 128) launch_all<2, true, true, float>(C, x, y, Y->rows, a0, f, cg_steps);
+  else if (f == 256) launch_all<4, true, false, float>(C, x, y, Y->rows, a0, f, cg_steps);
+  else if (f < 64) launch_all<1, false, true, float>(C, x, y, Y->rows, a0, f, cg_steps);
+  else if (f < 128) launch_all<2, false, true, float>(C, x, y, Y->rows, a0, f, cg_steps);
+  else if (f < 192) launch_all<3, false, true, float>(C, x, y, Y->rows, a0, f, cg_steps);
+  else if (f < 256) launch_all<4, false, false, float>(C, x, y, Y->rows, a0, f, cg_steps);
+  else if (f <= 384) launch_all<6, false, false, float>(C, x, y, Y->rows, a0, f, cg_steps);
+  else if (f <= 512) launch_all<8, false, false, float>(C, x, y, Y->rows, a0, f, cg_steps);
+  else if (f <= 768) launch_all<12, false, false, float>(C, x, y, Y->rows, a0, f, cg_steps);
+  else if (f <= 1024) launch_all<16, false, false, float>(C, x, y, Y->rows, a0, f, cg_steps);  // the reference's limit: one thread per factor, als.cu:177-179
   else throw std::invalid_argument("least_squares: factors must be <= 1024 (as the reference, implicit/gpu/als.cu:177-182)");
 }
 

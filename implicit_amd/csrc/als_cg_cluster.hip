@@ -307,22 +307,26 @@ __global__ __launch_bounds__(64 * kClusterWaves, 4) void als_cg_cluster_kernel(
   }
 }
 
-// ---- fix-up of the rows a faulted cluster left unsolved -----------------------------------------------------------------
-// One wavefront per listed row, everything streamed: lane l owns the FC = F / 64 consecutive factors FC l ..; a nonzero is one
-// coalesced row read, one wave-wide dot product, one axpy; the gramian comes from global memory (L2) row by row with the
-// operand broadcast from a wave-private LDS copy.  The oracle's CG step by step (_als.pyx:179-244); only the summation order
-// differs from the cluster kernel's.  Slow (milliseconds for a 4096-nonzero row) and never expected to have work.
+// ---- fix-up of the rows another kernel left unsolved ---------------------------------------------------------------------
+// Two producers: a faulted cluster (above) and the normal-matrix kernels (als_cg_nm.hip: a row whose fp16-split operands left the
+// fp16 range).  One wavefront per listed row, everything streamed in fp32: lane l owns the FC = F / 64 consecutive factors FC l ..;
+// a nonzero is one coalesced row read, one wave-wide dot product, one axpy (four nonzeros' reads in flight); the gramian comes
+// from global memory (L2) row by row with the operand broadcast from a wave-private LDS copy.  The oracle's CG step by step
+// (_als.pyx:179-244); only the summation order differs from the producers'.  Slow (a millisecond for a 4096-nonzero row) and
+// never expected to have work; `total` (host-mapped, imp_solver_fixup_rows) counts the rows it has re-solved.
 template <int F, typename ST>
 __global__ __launch_bounds__(256) void als_cg_fault_fixup_kernel(const unsigned *__restrict__ fault_count,
                                                                  const unsigned *__restrict__ fault_rows, int capacity,
                                                                  const int32_t *__restrict__ indptr,
                                                                  const int32_t *__restrict__ indices,
                                                                  const float *__restrict__ data, ST *__restrict__ X,
-                                                                 const ST *__restrict__ Y, const float *__restrict__ A0, int cg_steps) {
-  constexpr int FC = F / 64, WAVES = 4;
+                                                                 const ST *__restrict__ Y, const float *__restrict__ A0, int cg_steps,
+                                                                 unsigned long long *total) {
+  constexpr int FC = F / 64, WAVES = 4, U = 4;
   __shared__ float vecs[WAVES][F];
   const int n = min((int)fault_count[0], capacity);
   if (n == 0) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(total, (unsigned long long)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float *vec = vecs[wave];
   auto load_vec = [&](const ST *row, float (&v)[FC]) {
@@ -344,15 +348,24 @@ __global__ __launch_bounds__(256) void als_cg_fault_fixup_kernel(const unsigned 
 #pragma unroll
       for (int c = 0; c < FC; ++c) acc[c] = -acc[c];
     }
-    for (int k = rb; k < re; ++k) {
-      const float conf = data[k];
-      float y[FC];
-      load_vec(Y + (size_t)indices[k] * F, y);
-      const float d = wave_allsum(dot_local<FC>(y, v));
-      const float cm1 = fabsf(conf) - 1.f;
-      const float w = first ? fmaxf(conf, 0.f) - cm1 * d : cm1 * d;
+    for (int k0 = rb; k0 < re; k0 += U) {
+      float conf[U], y[U][FC];
 #pragma unroll
-      for (int c = 0; c < FC; ++c) acc[c] = fmaf(w, y[c], acc[c]);
+      for (int q = 0; q < U; ++q) {
+        const int k = min(k0 + q, re - 1);
+        conf[q] = data[k];
+        load_vec(Y + (size_t)indices[k] * F, y[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        if (k0 + q < re) {  // wave-uniform
+          const float d = wave_allsum(dot_local<FC>(y[q], v));
+          const float cm1 = fabsf(conf[q]) - 1.f;
+          const float w = first ? fmaxf(conf[q], 0.f) - cm1 * d : cm1 * d;
+#pragma unroll
+          for (int c = 0; c < FC; ++c) acc[c] = fmaf(w, y[q][c], acc[c]);
+        }
+      }
     }
   };
   for (int i = blockIdx.x * WAVES + wave; i < n; i += gridDim.x * WAVES) {
@@ -385,6 +398,31 @@ __global__ __launch_bounds__(256) void als_cg_fault_fixup_kernel(const unsigned 
     for (int c = 0; c < FC; ++c) store1(xrow + FC * lane + c, x[c]);
   }
 }
+
+// host-mapped counter of the rows the fix-up kernel has re-solved on this device (imp_solver_fixup_rows)
+unsigned long long *fixup_total() {
+  auto &c = ctx();
+  if (!c.fixup_total) {
+    IMP_CHECK_HIP(hipHostMalloc(reinterpret_cast<void **>(&c.fixup_total), sizeof(unsigned long long), hipHostMallocMapped));
+    *c.fixup_total = 0ull;
+  }
+  return c.fixup_total;
+}
+
+// queued behind the kernels that fill the list; normally reads a zero and exits
+template <int F, typename T>
+void launch_cg_fixup(const unsigned *count, const unsigned *rows, int capacity, const imp_csr *C, T *X, const T *Y, const float *A0,
+                     int cg_steps) {
+  if (capacity <= 0) return;
+  IMP_PROF("als_cg_fixup");
+  als_cg_fault_fixup_kernel<F, T><<<std::min((capacity + 3) / 4, ctx().num_cus * 2), 256, 0, stream()>>>(
+      count, rows, capacity, C->indptr.data(), C->indices.data(), C->data.data(), X, Y, A0, cg_steps, fixup_total());
+  IMP_CHECK_HIP(hipGetLastError());
+}
+template void launch_cg_fixup<64, float>(const unsigned *, const unsigned *, int, const imp_csr *, float *, const float *, const float *, int);
+template void launch_cg_fixup<128, float>(const unsigned *, const unsigned *, int, const imp_csr *, float *, const float *, const float *, int);
+template void launch_cg_fixup<64, __half>(const unsigned *, const unsigned *, int, const imp_csr *, __half *, const __half *, const float *, int);
+template void launch_cg_fixup<128, __half>(const unsigned *, const unsigned *, int, const imp_csr *, __half *, const __half *, const float *, int);
 
 template <int F, int CL, typename T>
 static void launch_cluster(const imp_csr *C, int first, int count, T *X, const T *Y, const float *A0, int cg_steps,
@@ -470,13 +508,8 @@ template <int F, typename T> static void run_clusters(const imp_csr *C, T *X, co
   launch_cluster<F, 4, T>(C, cut[2], cut[3] - cut[2], X, Y, A0, cg_steps, xchg + 2 * per_class, fault_count, fault_rows, capacity, "als_cg_cluster4_rows");
   if (with16)
     launch_cluster<F, 2, T>(C, b[1], b[2] - b[1], X, Y, A0, cg_steps, xchg + 3 * per_class, fault_count, fault_rows, capacity, "als_cg_team16_rows");
-  {
-    // normally reads a zero and exits; after a lost exchange it re-solves the rows the faulted clusters left untouched
-    IMP_PROF("als_cg_cluster_fixup");
-    als_cg_fault_fixup_kernel<F, T><<<std::min(capacity, c.num_cus * 2), 256, 0, stream()>>>(
-        fault_count, fault_rows, capacity, C->indptr.data(), C->indices.data(), C->data.data(), X, Y, A0, cg_steps);
-    IMP_CHECK_HIP(hipGetLastError());
-  }
+  // after a lost exchange: re-solves the rows the faulted clusters left untouched
+  launch_cg_fixup<F, T>(fault_count, fault_rows, capacity, C, X, Y, A0, cg_steps);
 }
 
 // true if a cluster kernel of an earlier launch on this device gave up on an exchange (looked at after a stream

@@ -103,10 +103,28 @@ __device__ __forceinline__ unsigned pack_pair(float x0, float x1) {
 }
 __device__ __forceinline__ float comp(const float4 &v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
 
-// The regularised gramian in image order (once per launch; the workgroups copy it linearly)
-template <int F> __global__ void nm_gram_image_kernel(const float *__restrict__ A0, float *__restrict__ img, int *__restrict__ ticket) {
+// The regularised gramian in image order (once per launch; the workgroups copy it linearly).  Block 0 also resets the ticket and
+// picks the launch's OPERAND SCALE 2^k (ctl[1]): the fp16 split keeps 22 bits of an operand only while its low half is a normal
+// fp16 number, i.e. while |operand| >= 1/8 -- cold-start factors of 0.005 would sit ten binades below that.  k brings the
+// root-mean-square of the largest factor column (from the gramian's diagonal: sqrt(max_j A0[j][j] / rows of Y), an upper bound
+// because the diagonal carries the regularisation) to about 8; it never scales down (k >= 0), and a row whose scaled operands
+// leave the fp16 range is caught by nm_cg's finiteness check and re-solved in fp32 (the fix-up list).  ctl[2] counts those rows.
+template <int F> __global__ void nm_gram_image_kernel(const float *__restrict__ A0, float *__restrict__ img, int *__restrict__ ctl,
+                                                      float y_rows, int forced_k) {
   using L = NmLayout<F>;
-  if (blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0;
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    float d = 0.f;
+    for (int j = threadIdx.x; j < F; j += 64) d = fmaxf(d, A0[(size_t)j * F + j]);
+    d = wave_allmax(d);
+    if (threadIdx.x == 0) {
+      int k = 0;
+      const float rms = sqrtf(d / fmaxf(y_rows, 1.f));
+      if (rms > 0.f && rms < 8.f) k = min((int)floorf(log2f(8.f / rms)), 16);  // NaN / inf / zero diagonal: k = 0
+      ctl[0] = 0;
+      ctl[1] = forced_k >= 0 ? forced_k : k;
+      ctl[2] = 0;
+    }
+  }
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < L::IMG; e += gridDim.x * blockDim.x) {
     const int n = e % L::TS, m = (e / L::TS) % L::M, t = e / (L::TS * L::M);
     img[e] = n < L::M ? A0[(size_t)(4 * m + t / 4) * F + 4 * n + t % 4] : 0.f;
@@ -126,13 +144,15 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // add the four copies up).  Registers: 48 accumulators + 32 landing + the operands in transit; two workgroups per CU.
 //
 // Weights without a pre-pass: w = |c| - 1 is dealt to the two operands as w 2^-e and 2^e with e = floor(log2|w| / 2) clamped to
-// +-12 -- exact scalings; both operands stay within sqrt(2 |w|) |y| of the fp16 range for confidences up to 10^7.
+// [-12, 24] -- exact scalings; both operands stay within 2^k sqrt(2 |w|) |y| (k: the launch's operand scale).  Nothing bounds
+// |y| here: operands beyond the fp16 range turn into infinities, the image and the CG scalars stop being finite, and nm_cg hands
+// the row to the fp32 fix-up kernel instead of storing it.
 //
 // Returns with the image complete in the LDS (gramian added when `whole`), behind a barrier.
 template <int F, typename T>
 __device__ __forceinline__ void nm_build(const int32_t *__restrict__ indices, const float *__restrict__ data, const T *__restrict__ Y,
                                          const float *__restrict__ gram_img, bool whole, int begin, int end, float *smem, float *bvec,
-                                         int tid, int ko) {
+                                         int tid, int ko, int scale_k) {
   using S = NmShape<F>;
   using L = NmLayout<F>;
   constexpr bool kHalf = !std::is_same<T, float>::value;
@@ -154,6 +174,7 @@ __device__ __forceinline__ void nm_build(const int32_t *__restrict__ indices, co
 #pragma unroll
     for (int e = 0; e < S::NACC; ++e) acc[k][e] = 0.f;
   float b4[4] = {0.f, 0.f, 0.f, 0.f};
+  const float scale2 = __uint_as_float((unsigned)(127 + 2 * scale_k) << 23), unscale2 = __uint_as_float((unsigned)(127 - 2 * scale_k) << 23);
 
   // Every round issues the same loads whether they are needed or not: s_waitcnt counts loads statically, and one conditional
   // gather makes the compiler assume the worst path -- the counts it then emits (vmcnt 7 .. 0) drain the whole queue at every
@@ -264,9 +285,11 @@ __device__ __forceinline__ void nm_build(const int32_t *__restrict__ indices, co
     // ---- produce step `wave` of this round
     {
       // this lane's entry: w = |c| - 1 dealt as wa = w 2^-e and sb = 2^e, e = floor((exponent of |w|) / 2) clamped to [-12, 12]
-      const float w_mine = fabsf(e0.c) - 1.f;
+      // (times the launch's operand scale 4^k, nm_gram_image_kernel: the image comes out scaled by 4^k and is scaled back,
+      // exactly, where it is written)
+      const float w_mine = (fabsf(e0.c) - 1.f) * scale2;
       unsigned hb = (((__float_as_uint(w_mine) & 0x7f800000u) + (127u << 23)) >> 1) & 0x7f800000u;
-      hb = min(max(hb, (127u - 12u) << 23), (127u + 12u) << 23);
+      hb = min(max(hb, (127u - 12u) << 23), (127u + 24u) << 23);
       const float sb_mine = __uint_as_float(hb), wa_mine = w_mine * __uint_as_float((254u << 23) - hb);
       const float cp_mine = e0.c > 0.f ? e0.c : 0.f;
       float wa[8], sb[8];
@@ -341,7 +364,7 @@ __device__ __forceinline__ void nm_build(const int32_t *__restrict__ indices, co
 #pragma unroll
         for (int e = 0; e < S::NACC; ++e) {
           const int m = S::row(lane, e);
-          const float v = acc[k][e] + gv[e];
+          const float v = fmaf(acc[k][e], unscale2, gv[e]);
           img[L::at(I, J, m, n)] = v;
           if (I != J) img[L::at(J, I, n, m)] = v;
         }
@@ -355,7 +378,7 @@ __device__ __forceinline__ void nm_build(const int32_t *__restrict__ indices, co
 // Vectors live in image order: position r = I M + m is factor 4m + I.  Thread (r = tid % F, grp = tid / F) forms the products of
 // row r with the column blocks J of its group: lanes walk m, i.e. consecutive tile rows of stride M + 1 -- conflict-free.
 template <int F, typename T>
-__device__ __forceinline__ void nm_cg(const float *img, const float *bvec, float *pv, float *parts, float *red, T *xrow, int cg_steps, int tid) {
+__device__ __forceinline__ bool nm_cg(const float *img, const float *bvec, float *pv, float *parts, float *red, T *xrow, int cg_steps, int tid) {
   using L = NmLayout<F>;
   constexpr int M = L::M, NP = L::NP, JPG = 4 / NP;
   const int r = tid % F, grp = tid / F, lane = tid & 63, wave = tid >> 6;
@@ -389,26 +412,35 @@ __device__ __forceinline__ void nm_cg(const float *img, const float *bvec, float
     slot = (slot + 1) & 7;
     return s;
   };
+  // Operands beyond the fp16 range leave infinities in the image; whatever they touch stops being finite.  The squared norms
+  // below see every component of every residual and of every A p (through p.Ap) -- one non-finite value in them and the row is
+  // NOT stored: the caller lists it for the fp32 fix-up kernel.  (A row whose inputs are not finite to begin with takes the same
+  // way and gets the reference's own non-finite answer there.)
+  auto finite = [](float v) { return fabsf(v) <= 3.0e38f; };
   float x = load1(xrow + 4 * m + I);
   if (grp == 0) pv[r] = x;
   __syncthreads();
   float res = bvec[r] - matvec();
   float p = res;
   float rsold = block_sum(res * res);
-  if (rsold < 1e-20f) return;
+  if (!finite(rsold)) return true;
+  if (rsold < 1e-20f) return false;
   for (int it = 0; it < cg_steps; ++it) {
     if (grp == 0) pv[r] = p;
     __syncthreads();
     const float Ap = matvec();
-    const float alpha = rsold / block_sum(p * Ap);
+    const float pAp = block_sum(p * Ap);
+    const float alpha = rsold / pAp;
     x = fmaf(alpha, p, x);
     res = fmaf(-alpha, Ap, res);
     const float rsnew = block_sum(res * res);
+    if (!finite(pAp) || !finite(rsnew) || !finite(alpha)) return true;
     if (rsnew < 1e-20f) break;
     p = fmaf(rsnew / rsold, p, res);
     rsold = rsnew;
   }
   if (grp == 0) store1(xrow + 4 * m + I, x);
+  return false;
 }
 
 // One workgroup per segment of plan_nm at a time; a row that is ONE segment is solved here, the others leave partial[seg] =
@@ -418,19 +450,21 @@ template <int F, typename T>
 __global__ __launch_bounds__(256, 2) void als_cg_nm_kernel(const LongPlanDev plan, const int32_t *__restrict__ indices,
                                                            const float *__restrict__ data, T *__restrict__ X, const T *__restrict__ Y,
                                                            const float *__restrict__ gram_img, int cg_steps, float *__restrict__ partial,
-                                                           int *__restrict__ ticket,
+                                                           int *__restrict__ ticket,  // [0] ticket [1] operand scale k [2] rows left to the fix-up
+                                                           unsigned *__restrict__ fix_rows,
                                                            int ko) {  // ko: timing-only knock-outs (IMP_NM_KO), 0 in production
   using L = NmLayout<F>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int next_item;
   float *img = smem, *bvec = img + L::kVec, *pv = bvec + F, *parts = pv + F, *red = parts + L::NP * F;
   const int tid = threadIdx.x;
+  const int scale_k = __builtin_amdgcn_readfirstlane(ticket[1]);
   for (int s = blockIdx.x; s < plan.n_seg;) {
     const int li = plan.seg_row[s];
     const int begin = plan.seg_begin[s], end = plan.seg_end[s];
     const bool whole = plan.row_seg[li + 1] - plan.row_seg[li] == 1;
     __syncthreads();  // the previous item's CG has read the image and b
-    nm_build<F, T>(indices, data, Y, gram_img, whole, begin, end, smem, bvec, tid, ko);
+    nm_build<F, T>(indices, data, Y, gram_img, whole, begin, end, smem, bvec, tid, ko, scale_k);
     if (tid < F) {
       const float *bstage = bvec + 2 * F + L::NP * F + 64;
       bvec[tid] = (bstage[tid] + bstage[F + tid]) + (bstage[2 * F + tid] + bstage[3 * F + tid]);
@@ -441,7 +475,8 @@ __global__ __launch_bounds__(256, 2) void als_cg_nm_kernel(const LongPlanDev pla
     if (tid == 0) drawn = (int)gridDim.x + atomicAdd(ticket, 1);
     if (!(ko & 4)) {
       if (whole) {
-        nm_cg<F, T>(img, bvec, pv, parts, red, X + (size_t)plan.rows[li] * F, cg_steps, tid);
+        const bool bad = nm_cg<F, T>(img, bvec, pv, parts, red, X + (size_t)plan.rows[li] * F, cg_steps, tid);
+        if (bad && tid == 0) fix_rows[atomicAdd(ticket + 2, 1)] = (unsigned)plan.rows[li];
       } else {
         float *out = partial + (size_t)s * (L::IMG + F);
         for (int e = tid; e < L::IMG / 4; e += 256) reinterpret_cast<float4 *>(out)[e] = reinterpret_cast<const float4 *>(img)[e];
@@ -493,7 +528,8 @@ __global__ __launch_bounds__(256) void als_cg_nm_reduce_kernel(const LongPlanDev
 // step 2: the CG of those rows on the summed image
 template <int F, typename T>
 __global__ __launch_bounds__(256) void als_cg_nm_finish_kernel(const LongPlanDev plan, int n_multi, T *__restrict__ X, int cg_steps,
-                                                               const float *__restrict__ partial) {
+                                                               const float *__restrict__ partial, int *__restrict__ ctl,
+                                                               unsigned *__restrict__ fix_rows) {
   using L = NmLayout<F>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *img = smem, *bvec = img + L::kVec, *pv = bvec + F, *parts = pv + F, *red = parts + L::NP * F;
@@ -504,11 +540,12 @@ __global__ __launch_bounds__(256) void als_cg_nm_finish_kernel(const LongPlanDev
     for (int e = tid; e < L::IMG / 4; e += 256) reinterpret_cast<float4 *>(img)[e] = reinterpret_cast<const float4 *>(in)[e];
     if (tid < F) bvec[tid] = in[L::IMG + tid];
     __syncthreads();
-    nm_cg<F, T>(img, bvec, pv, parts, red, X + (size_t)plan.rows[li] * F, cg_steps, tid);
+    const bool bad = nm_cg<F, T>(img, bvec, pv, parts, red, X + (size_t)plan.rows[li] * F, cg_steps, tid);
+    if (bad && tid == 0) fix_rows[atomicAdd(ctl + 2, 1)] = (unsigned)plan.rows[li];
   }
 }
 
-template <int F, typename T> void launch_nm(const imp_csr *C, T *X, const T *Y, const float *A0, int cg_steps) {
+template <int F, typename T> void launch_nm(const imp_csr *C, T *X, const T *Y, size_t y_rows, const float *A0, int cg_steps) {
   const LongPlan &lp = C->plan_nm;
   if (lp.n_seg <= 0) return;
   using L = NmLayout<F>;
@@ -519,8 +556,10 @@ template <int F, typename T> void launch_nm(const imp_csr *C, T *X, const T *Y, 
   const size_t need = (size_t)L::IMG + (size_t)n_multi_seg * (L::IMG + F);  // gramian image | partial images
   if (ws.size < need) ws.alloc(need);
   float *gram_img = ws.data(), *partial = gram_img + L::IMG;
-  auto &tk = ctx().nm_ticket;
-  if (tk.size < 1) tk.alloc(1, true);
+  auto &tk = ctx().nm_ticket;  // [0] ticket, [1] operand scale, [2] number of rows left to the fix-up kernel
+  if (tk.size < 4) tk.alloc(4, true);
+  auto &fix = ctx().nm_fix_rows;
+  if (fix.size < (size_t)lp.n_long) fix.alloc((size_t)lp.n_long);
   LongPlanDev plan = lp.dev(C->order.data());
   auto kern = als_cg_nm_kernel<F, T>;
   auto fin = als_cg_nm_finish_kernel<F, T>;
@@ -528,18 +567,21 @@ template <int F, typename T> void launch_nm(const imp_csr *C, T *X, const T *Y, 
   IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   {
     IMP_PROF("als_cg_nm_rows");
-    nm_gram_image_kernel<F><<<(L::IMG + 255) / 256, 256, 0, stream()>>>(A0, gram_img, tk.data());
+    static const int forced_k = getenv("IMP_NM_SCALE") ? atoi(getenv("IMP_NM_SCALE")) : -1;  // A/B and tests: fixed operand scale 2^k
+    nm_gram_image_kernel<F><<<(L::IMG + 255) / 256, 256, 0, stream()>>>(A0, gram_img, tk.data(), (float)y_rows, std::min(forced_k, 16));
     const int grid = std::min(lp.n_seg, ctx().num_cus * 2);  // two resident workgroups per CU; the ticket counter balances them
     static const int ko = getenv("IMP_NM_KO") ? atoi(getenv("IMP_NM_KO")) : 0;
-    kern<<<grid, 256, lds, stream()>>>(plan, C->indices.data(), C->data.data(), X, Y, gram_img, cg_steps, partial, tk.data(), ko);
+    kern<<<grid, 256, lds, stream()>>>(plan, C->indices.data(), C->data.data(), X, Y, gram_img, cg_steps, partial, tk.data(), fix.data(), ko);
     IMP_CHECK_HIP(hipGetLastError());
   }
   if (n_multi > 0) {
     IMP_PROF("als_cg_nm_finish");
     als_cg_nm_reduce_kernel<F><<<std::min(n_multi * 16, ctx().num_cus * 16), 256, 0, stream()>>>(plan, n_multi, gram_img, partial);
-    fin<<<std::min(n_multi, ctx().num_cus * 2), 256, lds, stream()>>>(plan, n_multi, X, cg_steps, partial);
+    fin<<<std::min(n_multi, ctx().num_cus * 2), 256, lds, stream()>>>(plan, n_multi, X, cg_steps, partial, tk.data(), fix.data());
     IMP_CHECK_HIP(hipGetLastError());
   }
+  // rows whose operands left the fp16 range (normally none: the kernel reads a zero and exits)
+  launch_cg_fixup<F, T>(reinterpret_cast<const unsigned *>(tk.data() + 2), fix.data(), lp.n_long, C, X, Y, A0, cg_steps);
 }
 
 }  // namespace
@@ -549,12 +591,12 @@ bool nm_enabled() {
   return on;
 }
 
-template <typename T> void least_squares_cg_nm(const imp_csr *C, T *X, const T *Y, const float *A0, int f, int cg_steps) {
-  if (f == 128) launch_nm<128, T>(C, X, Y, A0, cg_steps);
-  else if (f == 64) launch_nm<64, T>(C, X, Y, A0, cg_steps);
+template <typename T> void least_squares_cg_nm(const imp_csr *C, T *X, const T *Y, size_t y_rows, const float *A0, int f, int cg_steps) {
+  if (f == 128) launch_nm<128, T>(C, X, Y, y_rows, A0, cg_steps);
+  else if (f == 64) launch_nm<64, T>(C, X, Y, y_rows, A0, cg_steps);
   else throw std::invalid_argument("least_squares_cg_nm: f must be 64 or 128");
 }
-template void least_squares_cg_nm<float>(const imp_csr *, float *, const float *, const float *, int, int);
-template void least_squares_cg_nm<__half>(const imp_csr *, __half *, const __half *, const float *, int, int);
+template void least_squares_cg_nm<float>(const imp_csr *, float *, const float *, size_t, const float *, int, int);
+template void least_squares_cg_nm<__half>(const imp_csr *, __half *, const __half *, size_t, const float *, int, int);
 
 }  // namespace imp

@@ -90,6 +90,7 @@ void sync();  // hipStreamSynchronize on the library stream
 // deferred mode (imp_set_deferred_sync), where the caller orders a whole iteration with ONE imp_device_synchronize
 void sync_call();
 bool team16_as_cluster();    // als_cg_cluster.hip: rows of (256,512] nnz on clusters of two workgroups instead of team16
+unsigned long long *fixup_total();  // als_cg_cluster.hip: host-mapped count of the rows the fix-up kernel re-solved on this device
 bool cluster_fault_pending();  // als_cg_cluster.hip: a cluster exchange timed out since the last check (clears the flag)
 bool nm_enabled();           // als_cg_nm.hip: long rows of the f = 64 / 128 path through their explicit normal matrix (IMP_NM=0: clusters + streamed)
 
@@ -111,8 +112,9 @@ struct Storage {
   bool owned = true;
   // small blocks (<= kSmallMax) come from, and return to, their device's free lists instead of hipMalloc / hipFree: a
   // recommend() batch creates and destroys an IntVector and a COO filter (20-50 us of allocator time per object, hipFree
-  // synchronises).  Safe without a synchronisation: everything that touches such a block runs on the ONE library stream of
-  // its device, so a recycled block's next use is ordered behind its last.
+  // synchronises).  Safe without a synchronisation: every side stream (row-class streams, exchange stream) is joined to the
+  // library stream of its device before the entry point that used it returns, so a recycled block's next use -- queued on that
+  // stream -- is ordered behind its last.  The lists are a cache: an allocation that fails empties them and retries.
   Context *home = nullptr;
   int size_class = -1;
   static constexpr size_t kSmallMax = (size_t)4 << 20;
@@ -176,6 +178,8 @@ struct Context {
   DeviceArray<float> barrier_word;              // operand of the RCCL barrier (comm.hip)
   DeviceArray<unsigned long long> cluster_xchg;  // partial-vector exchange slots of the cluster kernels (als_cg_cluster.hip)
   unsigned *cluster_fault = nullptr;             // host-mapped word: set by a cluster kernel whose exchange timed out
+  unsigned long long *fixup_total = nullptr;     // host-mapped: rows re-solved by the fp32 fix-up kernel since the last imp_solver_fixup_rows(reset)
+  DeviceArray<unsigned> nm_fix_rows;             // rows the normal-matrix kernels left to the fix-up kernel (operands beyond the fp16 range)
   DeviceArray<int> nm_ticket;                    // work counter of the normal-matrix kernel (als_cg_nm.hip), reset by every launch
   DeviceArray<unsigned> cluster_fault_rows;      // rows a faulted cluster left to the fix-up kernel; their count sits behind the exchange slots (als_cg_cluster.hip)
 };
@@ -194,15 +198,11 @@ struct ClassStreams {
   int turn = 0;
   bool used[3] = {false, false, false};
 };
-// a C-ABI entry point is about to write `bytes` at `dst` through the library: a padded copy of Y made from memory it overlaps
-// (least_squares_cg_padded) is no longer to be trusted
-inline void note_device_write(const void *dst, size_t bytes) {
-  auto &c = ctx();
-  if (!c.pad_y_src) return;
-  const char *a = static_cast<const char *>(dst), *b = static_cast<const char *>(c.pad_y_src);
-  const size_t b_bytes = c.pad_y_rows * (size_t)c.pad_y_f * sizeof(float);
-  if (a < b + b_bytes && b < a + bytes) c.pad_y_src = nullptr;
-}
+// a C-ABI entry point is about to write `bytes` at `dst` through the library (or the memory is being freed): a padded copy of Y
+// made from memory it overlaps (least_squares_cg_padded) is no longer to be trusted -- on WHICHEVER device's context the copy
+// lives (device addresses are unique across the devices of a process; a Storage may die on a thread whose current device is
+// not the one that made the copy).  containers.hip.
+void note_device_write(const void *dst, size_t bytes);
 
 }  // namespace imp
 
@@ -305,5 +305,12 @@ struct imp_coo {
   imp::DeviceArray<int32_t> row, col;
   imp::DeviceArray<float> data;
 };
+
+namespace imp {
+// als_cg_cluster.hip: the fp32 one-wavefront-per-row solver for the rows listed in rows[0 .. *count) (F = 64 / 128, float / __half)
+template <int F, typename T>
+void launch_cg_fixup(const unsigned *count, const unsigned *rows, int capacity, const imp_csr *C, T *X, const T *Y, const float *A0,
+                     int cg_steps);
+}  // namespace imp
 
 #endif  // IMPLICIT_AMD_CSRC_COMMON_H_

@@ -42,6 +42,18 @@ Context &ctx() {
   return *it->second;
 }
 
+void note_device_write(const void *dst, size_t bytes) {
+  const char *a = static_cast<const char *>(dst);
+  std::lock_guard<std::mutex> lock(g_ctx_mutex);
+  for (auto &kv : g_contexts) {
+    Context &c = *kv.second;
+    if (!c.pad_y_src) continue;
+    const char *b = static_cast<const char *>(c.pad_y_src);
+    const size_t b_bytes = c.pad_y_rows * (size_t)c.pad_y_f * sizeof(float);
+    if (a < b + b_bytes && b < a + bytes) c.pad_y_src = nullptr;
+  }
+}
+
 std::unique_lock<std::recursive_mutex> lock_device() {
   try {
     return std::unique_lock<std::recursive_mutex>(ctx().mutex);
@@ -175,6 +187,35 @@ static void prof_flush() {
 }
 
 // ---- storage ------------------------------------------------------------------------------------
+// Recycled small blocks (<= 4 MB, at most 32 per size class and device: a worst case of ~250 MB) are only a cache: an allocation
+// that fails gives them all back to the runtime and tries once more.  Safe to hand out without a fence because every library
+// stream is joined to the ONE library stream before an entry point returns (class streams, exchange stream, occupy stream),
+// and the next user of a block queues its work behind that stream.
+static void flush_small_blocks() {
+  std::vector<void *> blocks;
+  {
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    for (auto &kv : g_contexts) {
+      std::lock_guard<std::mutex> g(kv.second->small_mutex);
+      for (auto &list : kv.second->small_free) {
+        blocks.insert(blocks.end(), list.begin(), list.end());
+        list.clear();
+      }
+    }
+  }
+  if (!blocks.empty()) (void)hipDeviceSynchronize();
+  for (void *b : blocks) (void)hipFree(b);
+}
+static void device_malloc(void **out, size_t bytes) {
+  hipError_t e = hipMalloc(out, bytes);
+  if (e == hipErrorOutOfMemory) {
+    (void)hipGetLastError();
+    flush_small_blocks();
+    e = hipMalloc(out, bytes);
+  }
+  IMP_CHECK_HIP(e);
+}
+
 Storage::Storage(size_t bytes_, bool zero) : bytes(bytes_) {
   if (bytes) {
     if (bytes <= kSmallMax) {
@@ -189,19 +230,16 @@ Storage::Storage(size_t bytes_, bool zero) : bytes(bytes_) {
           list.pop_back();
         }
       }
-      if (!ptr) IMP_CHECK_HIP(hipMalloc(&ptr, (size_t)1 << size_class));
+      if (!ptr) device_malloc(&ptr, (size_t)1 << size_class);
     } else {
-      IMP_CHECK_HIP(hipMalloc(&ptr, bytes));
+      device_malloc(&ptr, bytes);
     }
     if (zero) IMP_CHECK_HIP(hipMemsetAsync(ptr, 0, bytes, stream()));
   }
 }
 Storage::~Storage() {
   if (!owned || !ptr) return;
-  try {
-    note_device_write(ptr, bytes);  // the memory is about to be re-used for something else
-  } catch (...) {
-  }
+  note_device_write(ptr, bytes);  // the memory is about to be re-used for something else
   if (home) {
     std::lock_guard<std::mutex> g(home->small_mutex);
     auto &list = home->small_free[size_class];
@@ -358,6 +396,14 @@ int imp_debug_occupy(int workgroups, int microseconds) {
 int imp_get_device(int *device) {
   return guarded([&] { IMP_CHECK_HIP(hipGetDevice(device)); });
 }
+int imp_solver_fixup_rows(unsigned long long *count, int reset) {
+  return guarded([&] {
+    sync();  // the counter is written by kernels on the library stream
+    unsigned long long *total = fixup_total();
+    if (count) *count = *total;
+    if (reset) *total = 0ull;
+  });
+}
 int imp_device_synchronize(void) {
   return guarded([&] {
     sync();
@@ -380,6 +426,7 @@ int imp_release_workspaces(void) {
     c.pad_gram = {};
     c.cluster_xchg = {};
     c.cluster_fault_rows = {};
+    c.nm_fix_rows = {};
     std::lock_guard<std::mutex> g(c.small_mutex);
     for (auto &list : c.small_free) {
       for (void *p : list) (void)hipFree(p);

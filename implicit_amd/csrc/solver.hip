@@ -235,6 +235,7 @@ int imp_solver_least_squares_cholesky(imp_solver *, const imp_csr *cui, imp_matr
                                       const imp_matrix *Y, double regularization, int64_t *failed_row) {
   return guarded([&] {
     check_solver_args(cui, X, YtY, Y);
+    note_device_write(X->data, X->bytes());  // the rows this call solves
     int64_t failed = -1;
     run_with_f32(cui, X, Y, [&](imp_matrix *x, const imp_matrix *y) {
       size_t block = 0;

@@ -25,6 +25,19 @@ __device__ __forceinline__ float wave_allsum(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// Maximum over the 64 lanes, in every lane (NaN inputs are dropped by fmaxf).
+__device__ __forceinline__ float wave_allmax(float v) {
+  v = fmaxf(v, dpp_mov<0x128>(v));
+  v = fmaxf(v, dpp_mov<0x124>(v));
+  v = fmaxf(v, dpp_mov<0x122>(v));
+  v = fmaxf(v, dpp_mov<0x121>(v));  // every lane: the maximum of its 16-lane row
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
 __device__ __forceinline__ float lane_bcast(float v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }

@@ -470,6 +470,15 @@ def synchronize():
     check(lib().imp_device_synchronize())
 
 
+def fixup_rows(reset=True):
+    """Rows of CG sweeps on the current device that a fast kernel handed to the fp32 fix-up kernel since the last reset (a lost
+    cluster exchange, or long rows whose matrix-core operands left the fp16 range): results are correct either way, a non-zero
+    count is a performance signal."""
+    n = ctypes.c_ulonglong(0)
+    check(lib().imp_solver_fixup_rows(ctypes.byref(n), 1 if reset else 0))
+    return int(n.value)
+
+
 class Profiler:
     """Per-kernel HIP-event timing on the library stream (imp_prof_*), for bench.py's roofline leg."""
 

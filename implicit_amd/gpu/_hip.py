@@ -25,6 +25,7 @@ _SIGNATURES = {
     "imp_set_deferred_sync": [ctypes.c_int],
     "imp_debug_occupy": [ctypes.c_int, ctypes.c_int],
     "imp_device_synchronize": [],
+    "imp_solver_fixup_rows": [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int],
     "imp_mem_get_info": [ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)],
     "imp_release_workspaces": [],
     "imp_host_csr_transpose": [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,

@@ -67,6 +67,11 @@ int imp_set_deferred_sync(int on);
 /* Measurement aid: occupies `workgroups` x (256 threads, 32 KB LDS) for about `microseconds` on a stream of its own. */
 int imp_debug_occupy(int workgroups, int microseconds);
 int imp_device_synchronize(void);
+/* NEW.  Rows of CG sweeps on the CURRENT device that a fast kernel declined to store and the fp32 one-wavefront-per-row fix-up
+ * kernel re-solved instead, since the last reset: rows of a cluster whose exchange through memory was lost, and long rows whose
+ * fp16-split matrix-core operands left the fp16 range (factors or confidences far outside anything ALS produces).  Results are
+ * correct either way; a non-zero count says the sweep ran slower than it should.  Waits for the library stream. */
+int imp_solver_fixup_rows(unsigned long long *count, int reset);
 int imp_mem_get_info(size_t *free_bytes, size_t *total_bytes);
 /* NEW: frees the per-device scratch buffers the solver paths grow on demand (split-K gramian partials, long-row CG state, the
  * zero-padded copies other factor counts ride the f = 64 / 128 / 256 kernels on, cluster exchange slots); the next call that

@@ -129,6 +129,91 @@ def test_tiny_and_mixed_magnitudes(gpu, oracle):
     assert err.max() < TOL
 
 
+def test_operands_beyond_the_fp16_range_are_resolved_in_fp32(gpu, oracle):
+    """confidences of 1e6 on factors of +-40 put the fp16-split operands (~ sqrt(2 w) |y| 2^k) past 65504.  The
+    kernel must notice (the CG scalars stop being finite), store nothing, and leave the row to the fp32 fix-up kernel: finite
+    output, parity with the oracle at the oracle's own fp64 distance, and a non-zero imp_solver_fixup_rows.  The rows of the same
+    launch whose operands stay in range are solved by the matrix-core kernel as usual."""
+    f, items = 128, 6000
+
+    def conf(rng, n):
+        return 1 + 4 * rng.random(n)
+
+    C = _long_row_matrix([600, 900, 2500, 5000], items, seed=12, conf=conf).tolil()
+    rng = np.random.default_rng(7)
+    Y = (rng.standard_normal((items, f)) * 0.1).astype(np.float32)
+    C = C.tocsr()
+    # rows 1 and 3: a tenth of their entries with confidence 1e6 on item rows of magnitude 40
+    hot = np.arange(0, items, 10)
+    Y[hot] = (rng.standard_normal((len(hot), f)) * 40).astype(np.float32)
+    for r in (1, 3):
+        lo, hi = C.indptr[r], C.indptr[r + 1]
+        sel = np.isin(C.indices[lo:hi], hot)
+        C.data[lo:hi][sel] = 1e6
+    # rows 0 and 2 must not touch the hot items at all (their operands stay in range)
+    for r in (0, 2):
+        lo, hi = C.indptr[r], C.indptr[r + 1]
+        C.data[lo:hi][np.isin(C.indices[lo:hi], hot)] = 1.0   # weight 0
+    X = (rng.standard_normal((4, f)) * 0.1).astype(np.float32)
+    want = X.copy()
+    oracle.least_squares_cg(C, want, Y, 0.01)
+    exact = oracle.least_squares_cg_f64(C, X, Y, 0.01)
+    gpu.fixup_rows(reset=True)
+    got = _solve(gpu, C, X.copy(), Y, 0.01, 3)
+    n_fix = gpu.fixup_rows(reset=True)
+    e_gpu, e_oracle = _row_errors(got, exact), _row_errors(want, exact)
+    print("rows re-solved in fp32:", n_fix, "gpu vs fp64", e_gpu, "oracle vs fp64", e_oracle)
+    assert np.isfinite(got).all()
+    assert n_fix == 2
+    assert (e_gpu < np.maximum(TOL, 2.0 * e_oracle)).all()
+    # and an ordinary launch leaves the counter alone
+    _solve(gpu, _long_row_matrix([700, 3000], items, seed=1), X[:2].copy(), (Y * np.float32(0.01)), 0.01, 3)
+    assert gpu.fixup_rows(reset=True) == 0
+
+
+@pytest.mark.parametrize("scale", [0.01, 1e-3, 1e-4])
+def test_small_factors_keep_their_bits(gpu, oracle, scale):
+    """Factors of magnitude 0.01 and below (symmetric about zero: a well-conditioned system): the launch's operand scale
+    (nm_gram_image_kernel) keeps the low fp16 halves out of the subnormals; every row at least as close to the float64 answer as the
+    fp32 oracle (measured 2e-7 .. 4e-7 with the scale, 4e-7 .. 1.3e-6 without, oracle 7e-7 .. 2.9e-6; profiles/scripts/r5b_nm_coldstart.py)."""
+    f, items = 128, 9000
+    C = _long_row_matrix([600, 1300, 4000, 9000], items, seed=21)
+    rng = np.random.default_rng(4)
+    Y = ((rng.random((items, f)) - 0.5) * scale).astype(np.float32)
+    X = ((rng.random((4, f)) - 0.5) * scale).astype(np.float32)
+    want = X.copy()
+    oracle.least_squares_cg(C, want, Y, 0.01)
+    exact = oracle.least_squares_cg_f64(C, X, Y, 0.01)
+    got = _solve(gpu, C, X.copy(), Y, 0.01, 3)
+    e_gpu, e_oracle = _row_errors(got, exact), _row_errors(want, exact)
+    print("scale", scale, "gpu vs fp64", e_gpu, "oracle vs fp64", e_oracle)
+    assert gpu.fixup_rows(reset=True) == 0
+    assert (e_gpu < np.maximum(1e-6, 1.5 * e_oracle)).all()
+
+
+def test_all_positive_cold_start_factors(gpu, oracle):
+    """The first sweep of every fit starts from factors uniform in (0, 0.01) (implicit/gpu/als.py:98-101): A_u is then a rank-one
+    matrix plus a perturbation four orders of magnitude smaller, and three CG steps amplify fp32 rounding to 1e-4 .. 1e-2 of the
+    answer in EVERY implementation (the fp32 oracle itself: 8e-5 .. 1.3e-2 per row from float64).  The explicit normal matrix
+    rounds its entries once more than the reference's implicit product does; measured 3e-3 .. 4e-2 per row here against 9e-4 ..
+    1.2e-2 for the streamed fp32 kernels (IMP_NM=0) -- independent of the operand scale, i.e. conditioning, not the fp16 split.
+    The bar is the oracle's own distance over the sweep, within a factor that says "same regime"; from the second sweep on the
+    lock-step fit test holds every half sweep to 1e-4 (tests/test_gpu_als.py)."""
+    f, items = 128, 9000
+    C = _long_row_matrix([600, 1300, 4000, 9000], items, seed=21)
+    rng = np.random.default_rng(4)
+    Y = (rng.random((items, f)) * 0.01).astype(np.float32)
+    X = (rng.random((4, f)) * 0.01).astype(np.float32)
+    want = X.copy()
+    oracle.least_squares_cg(C, want, Y, 0.01)
+    exact = oracle.least_squares_cg_f64(C, X, Y, 0.01)
+    got = _solve(gpu, C, X.copy(), Y, 0.01, 3)
+    fro = lambda a: np.linalg.norm(a.astype(np.float64) - exact) / np.linalg.norm(exact)  # noqa: E731
+    print("per row: gpu vs fp64", _row_errors(got, exact), "oracle vs fp64", _row_errors(want, exact), "sweep: gpu %.2e oracle %.2e" % (fro(got), fro(want)))
+    assert np.isfinite(got).all() and gpu.fixup_rows(reset=True) == 0
+    assert fro(got) < 10.0 * fro(want)
+
+
 @pytest.mark.parametrize("f", [64, 128])
 def test_fp16_factor_storage(gpu, oracle, f):
     """fp16 factors: y is an fp16 number, the split needs one half; result = the fp32 solve of the rounded inputs, rounded once."""

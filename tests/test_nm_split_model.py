@@ -1,6 +1,6 @@
 """CPU model of the operand arithmetic of the normal-matrix kernels (implicit_amd/csrc/als_cg_nm.hip), so that its precision and
 range claims are checked where no GPU is: the weight w = |c| - 1 is dealt to the two matrix-core operands as w 2^-e and 2^e
-(e = floor(exponent(|w|) / 2), clamped to +-12), each operand is split into two fp16 halves (round to nearest), and a product
+(e = floor(exponent(|w|) / 2), clamped to [-12, 24]; w carries the launch's operand scale 4^k), each operand is split into two fp16 halves (round to nearest), and a product
 keeps the three terms  u_h y_h + u_l y_h + u_h y_l  with fp32 accumulation.  The numpy code below restates nm_build's produce
 phase bit for bit (same integer expression for the exponent, same conversions); the GPU parity of the whole kernel is
 tests/test_gpu_nm.py.
@@ -8,12 +8,20 @@ tests/test_gpu_nm.py.
 import numpy as np
 
 
-def deal_weight(w):
-    """(wa, sb) with wa * sb == w exactly: sb = 2^e, e = floor((exponent of |w|) / 2) clamped to [-12, 12]."""
-    w = np.asarray(w, np.float32)
+def operand_scale(max_diag, y_rows):
+    """k of nm_gram_image_kernel: brings the rms of the largest factor column (gramian diagonal / rows of Y) to about 8; 0 .. 16."""
+    rms = np.sqrt(np.float32(max_diag) / np.float32(max(y_rows, 1)))
+    if not (rms > 0 and rms < 8):
+        return 0
+    return int(min(np.floor(np.log2(np.float32(8.0) / rms)), 16))
+
+
+def deal_weight(w, k=0):
+    """(wa, sb) with wa * sb == 4^k w exactly: sb = 2^e, e = floor((exponent of |4^k w|) / 2) clamped to [-12, 24]."""
+    w = np.asarray(w, np.float32) * np.float32(4.0 ** k)
     bits = w.view(np.uint32)
     hb = ((((bits & np.uint32(0x7F800000)).astype(np.uint64) + (127 << 23)) >> 1) & 0x7F800000).astype(np.uint32)
-    hb = np.minimum(np.maximum(hb, np.uint32((127 - 12) << 23)), np.uint32((127 + 12) << 23))
+    hb = np.minimum(np.maximum(hb, np.uint32((127 - 12) << 23)), np.uint32((127 + 24) << 23))
     sb = hb.view(np.float32)
     wa = w * (np.uint32(254 << 23) - hb).view(np.float32)
     return wa, sb
@@ -85,3 +93,40 @@ def test_tiny_factors_lose_absolute_not_relative_accuracy():
     y = np.float32(3e-6)
     h, l = split(y)
     assert abs(float(h) + float(l) - float(y)) <= 2.0 ** -25
+
+
+def test_operand_scale_restores_the_bits_of_small_factors():
+    """Cold-start factors (0 .. 0.01, implicit/gpu/als.py:98-101) and trained factors of 1e-3: without the launch's scale the low
+    halves are fp16 subnormals and an operand keeps 14 .. 17 bits; with it (k from the gramian's diagonal) the products are good to
+    2^-20 of themselves again.  The scale is exact: the image is multiplied by 4^-k where it is written."""
+    rng = np.random.default_rng(3)
+    for scale in (0.01, 1e-3, 1e-4):
+        items = 50_000
+        y_i = (rng.random(items) * scale).astype(np.float32)
+        y_j = (rng.random(items) * scale).astype(np.float32)
+        k = operand_scale(float((y_i.astype(np.float64) ** 2).sum()) + 0.01, items)   # diagonal incl. the regularisation
+        assert 1 <= k <= 16
+        w = (rng.random(items) * 4).astype(np.float32)
+        exact = w.astype(np.float64) * y_i * y_j
+        rel = {}
+        for kk in (0, k):
+            wa, sb = deal_weight(w, kk)
+            u, v = wa * y_i, sb * y_j
+            assert np.isfinite(u.astype(np.float16)).all() and np.isfinite(v.astype(np.float16)).all()
+            got = three_products(u, v) * 4.0 ** -kk
+            big = np.abs(exact) > 1e-3 * np.abs(exact).max()
+            rel[kk] = (np.abs(got - exact)[big] / np.abs(exact)[big]).max()
+        print("scale %g: k = %d, worst product rel %.1e -> %.1e" % (scale, k, rel[0], rel[k]))
+        # (at 1e-4 the regularisation dominates the diagonal the scale is taken from -- and the matrix the products are added to)
+        assert rel[k] < (2.0 ** -17 if scale >= 1e-3 else 2.0 ** -13) and rel[k] < 1e-2 * rel[0]
+
+
+def test_operands_beyond_the_fp16_range_become_infinite_not_wrong():
+    """What the kernel's finiteness check relies on: an operand past 65504 converts to an fp16 infinity (never to a finite wrong
+    number), and its low half to the opposite infinity or NaN -- every product it takes part in is then non-finite."""
+    u = np.float32(70000.0)
+    with np.errstate(over="ignore", invalid="ignore"):
+        h, l = split(u)
+        assert np.isinf(h) and not np.isfinite(l)
+        assert not np.isfinite(three_products(u, np.float32(0.5)))
+        assert not np.isfinite(three_products(u, np.float32(0.0)))
