@@ -32,6 +32,7 @@ namespace imp {
 
 template <typename T> void least_squares_cg_q(const imp_csr *C, T *X, const T *Y, const float *A0, int f, int cg_steps);  // als_cg_q.hip
 template <typename T> void least_squares_cg_cluster(const imp_csr *C, T *X, const T *Y, const float *A0, int f, int cg_steps);  // als_cg_cluster.hip
+void least_squares_cg_w256(const imp_csr *C, float *X, const float *Y, const float *A0, int cg_steps);  // als_cg_w256.hip
 template <typename T> void least_squares_cg_nm(const imp_csr *C, T *X, const T *Y, size_t y_rows, const float *A0, int f, int cg_steps);  // als_cg_nm.hip
 
 // ---- generic per-nnz pass (any f): 4 gathers in flight, one DPP all-reduce per dot -------------------
@@ -657,7 +658,12 @@ static void launch_all(const imp_csr *C, T *X, const T *Y, size_t y_rows, const 
     if constexpr (VEC && VPL == 4 && !A_LDS) {  // f = 256: workgroup-shared gramian.  IMP_F256_GENERIC=1: the generic kernel (A/B)
       static const bool generic256 = getenv("IMP_F256_GENERIC") != nullptr;
       if (!generic256) {
-        launch_f256(C, b[1], b[7] - b[1], X, Y, A0, cg_steps, "als_cg_mid_rows");
+        if (w256_enabled()) {  // round 5: rows of <= 256 nonzeros resident, 16 / WPR rows per workgroup in lock step (als_cg_w256.hip)
+          launch_f256(C, b[1], b[2] - b[1], X, Y, A0, cg_steps, "als_cg_mid_rows");
+          least_squares_cg_w256(C, X, Y, A0, cg_steps);
+        } else {
+          launch_f256(C, b[1], b[7] - b[1], X, Y, A0, cg_steps, "als_cg_mid_rows");
+        }
         zero_rows_t<T>(C->order.data(), C->first_empty(), C->n_empty(), X, f);
         return;
       }

@@ -92,6 +92,7 @@ void sync_call();
 bool team16_as_cluster();    // als_cg_cluster.hip: rows of (256,512] nnz on clusters of two workgroups instead of team16
 unsigned long long *fixup_total();  // als_cg_cluster.hip: host-mapped count of the rows the fix-up kernel re-solved on this device
 bool cluster_fault_pending();  // als_cg_cluster.hip: a cluster exchange timed out since the last check (clears the flag)
+bool w256_enabled();         // als_cg_w256.hip: resident lock-step kernels for the rows of <= 256 nonzeros at f = 256 (IMP_F256_OLD=1: round-2 kernel)
 bool nm_enabled();           // als_cg_nm.hip: long rows of the f = 64 / 128 path through their explicit normal matrix (IMP_NM=0: clusters + streamed)
 
 // ---- launch-time profiler (HIP events on the library stream) ------------------------------------
@@ -179,6 +180,7 @@ struct Context {
   DeviceArray<unsigned long long> cluster_xchg;  // partial-vector exchange slots of the cluster kernels (als_cg_cluster.hip)
   unsigned *cluster_fault = nullptr;             // host-mapped word: set by a cluster kernel whose exchange timed out
   unsigned long long *fixup_total = nullptr;     // host-mapped: rows re-solved by the fp32 fix-up kernel since the last imp_solver_fixup_rows(reset)
+  DeviceArray<float> w256_ws;                    // fp16-split gramian in fragment order + header (als_cg_w256.hip)
   DeviceArray<unsigned> nm_fix_rows;             // rows the normal-matrix kernels left to the fix-up kernel (operands beyond the fp16 range)
   DeviceArray<int> nm_ticket;                    // work counter of the normal-matrix kernel (als_cg_nm.hip), reset by every launch
   DeviceArray<unsigned> cluster_fault_rows;      // rows a faulted cluster left to the fix-up kernel; their count sits behind the exchange slots (als_cg_cluster.hip)

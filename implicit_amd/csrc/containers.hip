@@ -427,6 +427,7 @@ int imp_release_workspaces(void) {
     c.cluster_xchg = {};
     c.cluster_fault_rows = {};
     c.nm_fix_rows = {};
+    c.w256_ws = {};
     std::lock_guard<std::mutex> g(c.small_mutex);
     for (auto &list : c.small_free) {
       for (void *p : list) (void)hipFree(p);
