@@ -297,6 +297,18 @@ def main():
             solver.calculate_yty(X, gram, 0.0)
             solver.least_squares_cholesky(Ciu_d, Y, gram, X, REG)
 
+    # The timed loop is fit()'s loop (implicit_amd/gpu/als.py): the four solver calls of an iteration are queued back to back
+    # (deferred mode) and the host waits ONCE per iteration -- what the product does; a host round trip after each of the
+    # four calls leaves the device idle for ~25 us each (2-3 % of a 4 ms step).  IMP_BENCH_SYNC_CALLS=1: synchronous calls.
+    deferred = os.environ.get("IMP_BENCH_SYNC_CALLS") is None
+    raw_step = step
+
+    def step():  # noqa: F811
+        raw_step()
+        if deferred:
+            gpu.synchronize()
+
+    gpu.set_deferred_sync(deferred)
     for _ in range(args.warmup):
         step()
     gpu.synchronize()
@@ -324,6 +336,7 @@ def main():
         step()
     gpu.synchronize()
     gpu.Profiler.enable(False)
+    gpu.set_deferred_sync(False)
 
     # ---- roofline: the WHOLE step (every row class of both half sweeps), per-class table as an extra ---------------
     cbytes = class_bytes_per_iteration(Cui, Ciu, FACTORS)
@@ -361,8 +374,10 @@ def main():
                     "avg_launch_ms": (sweep_ms / sweep_n) if sweep_n else None,
                     "half_sweeps_timed": sweep_n,
                     "frac_half_sweep_events": (total_bytes * args.steps / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if sweep_ms else None,
-                    "timing_source": "ms_per_step of the timed region (wall clock, synchronised both sides); "
-                                     "avg_launch_ms / frac_half_sweep_events: one HIP-event pair around each half sweep "
+                    "timing_source": "ms_per_step of the timed region (wall clock, synchronised both sides; inside it the "
+                                     + ("four solver calls of a step are queued and waited for once, as fit() does" if deferred
+                                        else "host waits after every solver call (IMP_BENCH_SYNC_CALLS)") +
+                                     "); avg_launch_ms / frac_half_sweep_events: one HIP-event pair around each half sweep "
                                      "inside the same timed region",
                     "note": "algorithmic bytes = nnz(4f+8) + rows(8f+8) + 4f^2 per half sweep (SURVEY 8d); per-class "
                             "figures in `row_classes` (separate pass after the timed region, one event pair per launch)"}
