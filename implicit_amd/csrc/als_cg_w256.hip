@@ -138,7 +138,7 @@ __global__ __launch_bounds__(1024) void als_cg_w256_kernel(const int32_t *__rest
   // flight.  Four products: H h, H l, L h and L l (the last is 2^-22 of the sum: with it the product is exact in the 22-bit halves)
   // The MFMA's 16 columns are the group's R rows; columns n >= R re-read column n % R (a column of the product depends on
   // nothing but its own operand column, and nobody reads those results).
-  auto product = [&]() {
+  auto product = [&]() __attribute__((always_inline)) {
     if (ko & 1) return;
     const int ln = opaque(lane);
     const int n = ln & 15, kq = ln >> 4;
@@ -175,10 +175,10 @@ __global__ __launch_bounds__(1024) void als_cg_w256_kernel(const int32_t *__rest
       if constexpr (PAIRED) {
         acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(L, bh, acc2, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(H, bh, acc, 0, 0, 0);
-      } else {
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(L, bl, acc2, 0, 0, 0);
+      } else {  // (one chain: the R = 16 form has no registers for a second accumulator)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(L, bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(L, bh, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(H, bl, acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(L, bh, acc2, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(H, bh, acc, 0, 0, 0);
       }
 #endif
@@ -229,98 +229,120 @@ __global__ __launch_bounds__(1024) void als_cg_w256_kernel(const int32_t *__rest
       c = data[k];
     }
   };
-  Share cur = share_of(blockIdx.x);
+  // tile slots 2 P, 2 P + 1 (entries 8 P .. 8 P + 7 of a share) from the staged entries: weights to the table, eight gathers per
+  // lane.  Entries past the count inside the pair repeat the share's last row with weight 0.
+  f32x2 y[4][8];
+  auto gather_pair = [&](auto Pc, int col, float c, int n_ent) __attribute__((always_inline)) {
+    constexpr int P = decltype(Pc)::value;
+    const int ln = opaque(lane);
+    if ((ln >> 3) == P) {  // lanes 8 P .. 8 P + 7 hold the pair's entries
+      const bool ok = ln < n_ent;
+      cw[ln] = ok ? fabsf(c) - 1.f : 0.f;
+      cw[16 + ln] = ok ? fmaxf(c, 0.f) : 0.f;
+    }
+    const int src = 4 * (ln >> 4);
+#pragma unroll
+    for (int q = 2 * P; q < 2 * P + 2; ++q) {
+      const unsigned cq = (unsigned)__builtin_amdgcn_ds_bpermute(src + 16 * q, col);
+      const float *p = Y + (size_t)cq * F + 4 * (ln & 15);
+#pragma unroll
+      for (int pc = 0; pc < 4; ++pc) {
+        const float4 v = *reinterpret_cast<const float4 *>(p + 64 * pc);
+        y[q][2 * pc] = f32x2{v.x, v.y}, y[q][2 * pc + 1] = f32x2{v.z, v.w};
+      }
+    }
+  };
+  // cur: the group being solved; nxt: the one after it.  ent_*: the staged entries of the group whose tile is not gathered yet --
+  // cur's until its tile is, nxt's from then on (two registers in flight while cur iterates).  The last pass of a group ROLLS
+  // nxt's tile in, pair by pair, as soon as a pair of registers has been used for the last time: the gathers (a quarter of a
+  // group's time when they start at its top, with the CU idle: one workgroup per CU) then overlap the leader's last update.
+  if (cg_steps <= 0) return;  // nothing is stored without a CG step (_als.pyx:208-244)
+  Share cur = share_of(blockIdx.x), nxt = cur;
   int ent_col;
   float ent_c;
   fetch_entries16(cur, ent_col, ent_c);
+  float4 x_next = make_float4(0.f, 0.f, 0.f, 0.f);  // leader: the next group's iterate, requested ahead of the rolling gathers
+  // the first group of the workgroup: plain start; every later tile rolls in during its predecessor's last pass
+  if (!(ko & 4)) {
+    static_for<2>([&](auto Pc) {
+      if (8 * decltype(Pc)::value < cur.cnt) gather_pair(Pc, ent_col, ent_c, cur.cnt);  // wave-uniform
+    });
+  }
+  nxt = share_of(blockIdx.x + g_step);
+  fetch_entries16(nxt, ent_col, ent_c);
+  if (leader && cur.valid) x_next = *reinterpret_cast<const float4 *>(X + (size_t)cur.u * F + 4 * opaque(lane));
   for (int g = blockIdx.x; g < groups; g += g_step) {
     const bool valid = cur.valid;
     const int u = cur.u, cnt = cur.cnt;
-    // ---- gather: entry t of the share in lane t, tile slot q of group g_ = entry 4 q + g_ --------------------------------------
-    f32x2 y[4][8];
-    {
-      const int col = ent_col;
-      const float c = ent_c;
-      if (lane < 16) {
-        const bool ok = lane < cnt;
-        cw[lane] = ok ? fabsf(c) - 1.f : 0.f;
-        cw[16 + lane] = ok ? fmaxf(c, 0.f) : 0.f;
-      }
-      const int src = 4 * (opaque(lane) >> 4);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (4 * q < cnt && !(ko & 4)) {  // wave-uniform; entries past the count inside a step repeat the last row with weight 0
-          const unsigned cq = (unsigned)__builtin_amdgcn_ds_bpermute(src + 16 * q, col);
-          const float *p = Y + (size_t)cq * F + 4 * (opaque(lane) & 15);
-#pragma unroll
-          for (int pc = 0; pc < 4; ++pc) {
-            const float4 v = *reinterpret_cast<const float4 *>(p + 64 * pc);
-            y[q][2 * pc] = f32x2{v.x, v.y}, y[q][2 * pc + 1] = f32x2{v.z, v.w};
-          }
-        } else {
-#pragma unroll
-          for (int h = 0; h < 8; ++h) y[q][h] = f32x2{0.f, 0.f};
-        }
-      }
-    }
-    // the next group's share: its row id, range and entries are on their way while this group iterates
-    cur = share_of(g + g_step);
-    fetch_entries16(cur, ent_col, ent_c);
+    // from here on: the tile is cur's, ent_* are nxt's entries, x_next is cur's iterate
 
     // ---- tile part of a pass: Sp[wave] = sum over the resident entries of w y ------------------------------------------------
     //   FIRST: w = c+ - (|c|-1) y.x   else: w = (|c|-1) y.p      (_als.pyx:190-201, 214-222)
-    auto tile_pass = [&](auto first_c, bool on) {
-      constexpr bool FIRST = decltype(first_c)::value;
+    //   LAST : the registers (and table slots) of a pair are re-filled with nxt's entries once the pair is done
+    auto tile_pass = [&](auto first_c, auto last_c, bool on) __attribute__((always_inline)) {
+      constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
       const int ln = opaque(lane);
-      float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (on && cnt > 0 && !(ko & 2)) {  // wave-uniform
-        const int gq = ln >> 4, m = ln & 15;
-        f32x2 ve[8], ae[8];
+      int roll_col = 0;
+      float roll_c = 0.f;
+      if constexpr (LAST) {  // one wait for the staged entries, before any rolling gather
+        roll_col = opaque(ent_col);
+        roll_c = __int_as_float(opaque(__float_as_int(ent_c)));
+      }
+      const bool work = on && !(ko & 2);
+      f32x2 ve[8], ae[8];
+      {  // the operand, expanded: slot e of lane (g, m) is factor 64 (e / 4) + 4 m + (e & 3)
+        const float *vp = vrow + 4 * (ln & 15);
 #pragma unroll
         for (int pc = 0; pc < 4; ++pc) {
-          const float4 t = *reinterpret_cast<const float4 *>(vrow + 64 * pc + 4 * m);
+          const float4 t = *reinterpret_cast<const float4 *>(vp + 64 * pc);
           ve[2 * pc] = f32x2{t.x, t.y}, ve[2 * pc + 1] = f32x2{t.z, t.w};
         }
-#pragma unroll
-        for (int h = 0; h < 8; ++h) ae[h] = f32x2{0.f, 0.f};
-        const float *cwg = cw + gq;
-        auto partial = [&](int q) {
-          f32x2 sacc = y[q][0] * ve[0];
-#pragma unroll
-          for (int h = 1; h < 8; ++h) sacc = __builtin_elementwise_fma(y[q][h], ve[h], sacc);
-          return sacc.x + sacc.y;
-        };
-        auto axpy = [&](int q, float w) {
-          const f32x2 w2 = {w, w};
-#pragma unroll
-          for (int h = 0; h < 8; ++h) ae[h] = __builtin_elementwise_fma(w2, y[q][h], ae[h]);
-        };
-        static_for<2>([&](auto Pc) {
-          constexpr int P = decltype(Pc)::value;
-          if (8 * P < cnt) {  // wave-uniform
-            const float cm1_0 = cwg[8 * P], cm1_1 = cwg[8 * P + 4];
-            float cp_0 = 0.f, cp_1 = 0.f;
-            if constexpr (FIRST) cp_0 = cwg[16 + 8 * P], cp_1 = cwg[16 + 8 * P + 4];
-            const float uu = reduce_pair(partial(2 * P), partial(2 * P + 1));
-            const float w0 = FIRST ? fmaf(-cm1_0, row_bcast_from<0>(uu), cp_0) : cm1_0 * row_bcast_from<0>(uu);
-            const float w1 = FIRST ? fmaf(-cm1_1, row_bcast_from<8>(uu), cp_1) : cm1_1 * row_bcast_from<8>(uu);
-            axpy(2 * P, w0);
-            axpy(2 * P + 1, w1);
-          }
-        });
-        // reduce-scatter across the four groups: expanded slot e of lane (g, m) is factor 64 (e >> 2) + 4 m + (e & 3); group g
-        // ends with slots 4 g .. 4 g + 3, i.e. lane l with factors 4 l .. 4 l + 3
-        float hsum[8];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          hsum[2 * i] = swap32_sum(ae[i].x, ae[i + 4].x);
-          hsum[2 * i + 1] = swap32_sum(ae[i].y, ae[i + 4].y);
-        }
-        out.x = swap16_sum(hsum[0], hsum[4]);
-        out.y = swap16_sum(hsum[1], hsum[5]);
-        out.z = swap16_sum(hsum[2], hsum[6]);
-        out.w = swap16_sum(hsum[3], hsum[7]);
       }
+#pragma unroll
+      for (int h = 0; h < 8; ++h) ae[h] = f32x2{0.f, 0.f};
+      const float *cwg = cw + (ln >> 4);
+      auto partial = [&](int q) {
+        f32x2 sacc = y[q][0] * ve[0];
+#pragma unroll
+        for (int h = 1; h < 8; ++h) sacc = __builtin_elementwise_fma(y[q][h], ve[h], sacc);
+        return sacc.x + sacc.y;
+      };
+      auto axpy = [&](int q, float w) {
+        const f32x2 w2 = {w, w};
+#pragma unroll
+        for (int h = 0; h < 8; ++h) ae[h] = __builtin_elementwise_fma(w2, y[q][h], ae[h]);
+      };
+      static_for<2>([&](auto Pc) {
+        constexpr int P = decltype(Pc)::value;
+        if (work && 8 * P < cnt) {  // wave-uniform
+          const float cm1_0 = cwg[8 * P], cm1_1 = cwg[8 * P + 4];
+          float cp_0 = 0.f, cp_1 = 0.f;
+          if constexpr (FIRST) cp_0 = cwg[16 + 8 * P], cp_1 = cwg[16 + 8 * P + 4];
+          const float uu = reduce_pair(partial(2 * P), partial(2 * P + 1));
+          const float w0 = FIRST ? fmaf(-cm1_0, row_bcast_from<0>(uu), cp_0) : cm1_0 * row_bcast_from<0>(uu);
+          const float w1 = FIRST ? fmaf(-cm1_1, row_bcast_from<8>(uu), cp_1) : cm1_1 * row_bcast_from<8>(uu);
+          axpy(2 * P, w0);
+          axpy(2 * P + 1, w1);
+        }
+        if constexpr (LAST) {
+          // ONE place per pair where its registers are re-filled, whether or not the pair did any work (two places -- an `else`
+          // for the waves whose row had stopped -- made the compiler keep a second copy of the tile: 40 registers spilled);
+          // fenced: hoisted above the pair's last FMAs the gathers would need a second set of registers as well
+          __builtin_amdgcn_sched_barrier(0);
+          if (8 * P < nxt.cnt && !(ko & 4)) gather_pair(Pc, roll_col, roll_c, nxt.cnt);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+      // reduce-scatter across the four groups: expanded slot e of lane (g, m) is factor 64 (e >> 2) + 4 m + (e & 3); group g
+      // ends with slots 4 g .. 4 g + 3, i.e. lane l with factors 4 l .. 4 l + 3 (all zeros for a wave without work)
+      float hsum[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        hsum[2 * i] = swap32_sum(ae[i].x, ae[i + 4].x);
+        hsum[2 * i + 1] = swap32_sum(ae[i].y, ae[i + 4].y);
+      }
+      const float4 out = make_float4(swap16_sum(hsum[0], hsum[4]), swap16_sum(hsum[1], hsum[5]), swap16_sum(hsum[2], hsum[6]),
+                                     swap16_sum(hsum[3], hsum[7]));
       *reinterpret_cast<float4 *>(Sp + (size_t)wave * F + 4 * ln) = out;
     };
 
@@ -369,17 +391,15 @@ __global__ __launch_bounds__(1024) void als_cg_w256_kernel(const int32_t *__rest
     float *const xrow = X + (size_t)u * F;
     float rsold = 0.f;
     bool active = false;
-    float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);  // the iterate (leader): lane l, factors 4 l ..
+    float4 x4 = x_next;  // the iterate (leader): lane l, factors 4 l ..
     if (leader) {
-      const int ln = opaque(lane);
-      if (valid) x4 = *reinterpret_cast<const float4 *>(xrow + 4 * ln);
       publish(x4, valid);
       if (lane == 0) Act[j] = valid ? 1 : 0;
     }
     lds_barrier();
     // ---- pass 0: r = -(A0 x) + sum_k (c+ - (|c|-1) y.x) y        (_als.pyx:187-201); the product first: it needs no gather ----
     product();
-    tile_pass(std::true_type{}, valid);
+    tile_pass(std::true_type{}, std::false_type{}, valid);
     lds_barrier();
     if (leader) {
       const int ln = opaque(lane);
@@ -394,14 +414,14 @@ __global__ __launch_bounds__(1024) void als_cg_w256_kernel(const int32_t *__rest
     }
     lds_barrier();
     const bool tiles_first = ((wave >> 2) & 1) != 0;
-    for (int it = 0; it < cg_steps; ++it) {
+    for (int it = 0; it + 1 < cg_steps; ++it) {  // all steps but the last
       const bool on = __builtin_amdgcn_readfirstlane(Act[j]) != 0;
       if (tiles_first) {
-        tile_pass(std::false_type{}, on);
+        tile_pass(std::false_type{}, std::false_type{}, on);
         product();
       } else {
         product();
-        tile_pass(std::false_type{}, on);
+        tile_pass(std::false_type{}, std::false_type{}, on);
       }
       lds_barrier();
       if (leader && active && !(ko & 8)) {  // wave-uniform
@@ -412,29 +432,51 @@ __global__ __launch_bounds__(1024) void als_cg_w256_kernel(const int32_t *__rest
         const float4 p4 = *reinterpret_cast<const float4 *>(vrow + 4 * ln);
         const float alpha = rsold * __builtin_amdgcn_rcpf(dot4(p4, Ap));
         x4.x = fmaf(alpha, p4.x, x4.x), x4.y = fmaf(alpha, p4.y, x4.y), x4.z = fmaf(alpha, p4.z, x4.z), x4.w = fmaf(alpha, p4.w, x4.w);
-        if (it + 1 == cg_steps) {  // the last step's r, rsnew, p are never read (_als.pyx:226-241)
+        float4 r4 = *reinterpret_cast<const float4 *>(Rs + (size_t)j * F + 4 * ln);
+        r4.x = fmaf(-alpha, Ap.x, r4.x), r4.y = fmaf(-alpha, Ap.y, r4.y), r4.z = fmaf(-alpha, Ap.z, r4.z), r4.w = fmaf(-alpha, Ap.w, r4.w);
+        const float rsnew = dot4(r4, r4);
+        if (rsnew < 1e-20f) {  // the oracle breaks here (_als.pyx:235)
           *reinterpret_cast<float4 *>(xrow + 4 * ln) = x4;
           active = false;
+          publish(make_float4(0.f, 0.f, 0.f, 0.f), false);
         } else {
-          float4 r4 = *reinterpret_cast<const float4 *>(Rs + (size_t)j * F + 4 * ln);
-          r4.x = fmaf(-alpha, Ap.x, r4.x), r4.y = fmaf(-alpha, Ap.y, r4.y), r4.z = fmaf(-alpha, Ap.z, r4.z), r4.w = fmaf(-alpha, Ap.w, r4.w);
-          const float rsnew = dot4(r4, r4);
-          if (rsnew < 1e-20f) {  // the oracle breaks here (_als.pyx:235)
-            *reinterpret_cast<float4 *>(xrow + 4 * ln) = x4;
-            active = false;
-            publish(make_float4(0.f, 0.f, 0.f, 0.f), false);
-          } else {
-            const float beta = rsnew * __builtin_amdgcn_rcpf(rsold);
-            const float4 pn = make_float4(fmaf(beta, p4.x, r4.x), fmaf(beta, p4.y, r4.y), fmaf(beta, p4.z, r4.z), fmaf(beta, p4.w, r4.w));
-            *reinterpret_cast<float4 *>(Rs + (size_t)j * F + 4 * ln) = r4;
-            publish(pn, true);
-            rsold = rsnew;
-          }
+          const float beta = rsnew * __builtin_amdgcn_rcpf(rsold);
+          const float4 pn = make_float4(fmaf(beta, p4.x, r4.x), fmaf(beta, p4.y, r4.y), fmaf(beta, p4.z, r4.z), fmaf(beta, p4.w, r4.w));
+          *reinterpret_cast<float4 *>(Rs + (size_t)j * F + 4 * ln) = r4;
+          publish(pn, true);
+          rsold = rsnew;
         }
         if (lane == 0) Act[j] = active ? 1 : 0;
       }
       lds_barrier();
     }
+    // The last step stands outside the loop (the compiler must see that nothing of this group follows it): the product first in
+    // every wave (its loads must not queue behind the gathers), then the tile entries with nxt's tile rolling in behind them;
+    // the next iterate is requested ahead of the gathers (loads return in order).  Only the step's x update is evaluated: its
+    // r, rsnew and p are never read (_als.pyx:226-241).
+    {
+      const bool on = __builtin_amdgcn_readfirstlane(Act[j]) != 0;
+      product();
+      float4 xn = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (leader && nxt.valid) xn = *reinterpret_cast<const float4 *>(X + (size_t)nxt.u * F + 4 * opaque(lane));
+      tile_pass(std::false_type{}, std::true_type{}, on);
+      lds_barrier();
+      if (leader && active && !(ko & 8)) {  // wave-uniform
+        const int ln = opaque(lane);
+        float4 dn, sp4;
+        collect(dn, sp4);
+        const float4 Ap = make_float4(dn.x + sp4.x, dn.y + sp4.y, dn.z + sp4.z, dn.w + sp4.w);
+        const float4 p4 = *reinterpret_cast<const float4 *>(vrow + 4 * ln);
+        const float alpha = rsold * __builtin_amdgcn_rcpf(dot4(p4, Ap));
+        x4.x = fmaf(alpha, p4.x, x4.x), x4.y = fmaf(alpha, p4.y, x4.y), x4.z = fmaf(alpha, p4.z, x4.z), x4.w = fmaf(alpha, p4.w, x4.w);
+        *reinterpret_cast<float4 *>(xrow + 4 * ln) = x4;
+      }
+      x_next = xn;
+      lds_barrier();
+    }
+    cur = nxt;
+    nxt = share_of(g + 2 * g_step);
+    fetch_entries16(nxt, ent_col, ent_c);
   }
 }
 
