@@ -74,7 +74,7 @@ SHORT_ROW, LONG_ROW = 32, 512  # imp_csr::kShortRow / kLongRow
 CLASS_KERNELS = {"short": ["als_cg_short_rows", "als_cg_short16_rows"],
                  "mid": ["als_cg_team2_rows", "als_cg_team4_rows", "als_cg_team8_rows", "als_cg_team16_rows"],
                  "long": ["als_cg_cluster16_rows", "als_cg_cluster8_rows", "als_cg_cluster4_rows", "als_cg_cluster_reset",
-                          "als_cg_long_partial", "als_cg_long_combine", "als_cg_nm_rows", "als_cg_nm_finish"]}
+                          "als_cg_long_partial", "als_cg_long_combine", "als_cg_nm_rows", "als_cg_nm_finish", "als_cg_fixup"]}
 
 
 def class_bytes_per_iteration(Cui, Ciu, f):
@@ -95,7 +95,8 @@ PMC_KERNELS = {"als_cg_group_kernel": ("short", lambda s: 1), "als_cg_team_kerne
                "als_cg_qfgroup_kernel": ("short", lambda s: 1), "als_cg_qfteam_kernel": ("mid", lambda s: 1),
                "cg_long_partial": ("long", lambda s: 1 + s), "cg_long_combine_kernel": ("long", lambda s: 1 + s),
                "als_cg_cluster_kernel": ("long", lambda s: 1), "als_cg_nm_kernel": ("long", lambda s: 1),
-               "als_cg_nm_finish_kernel": ("long", lambda s: 1), "als_cg_nm_reduce_kernel": ("long", lambda s: 1)}
+               "als_cg_nm_finish_kernel": ("long", lambda s: 1), "als_cg_nm_reduce_kernel": ("long", lambda s: 1),
+               "als_cg_fault_fixup_kernel": ("long", lambda s: 1)}
 
 
 def pmc_traffic_per_half_sweep(cg_steps):
