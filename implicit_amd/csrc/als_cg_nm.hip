@@ -143,10 +143,12 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // all ten tiles: 509 registers = one wavefront per SIMD at 6 cycles per instruction, and 156 K cycles of ds_add_f32 per row to
 // add the four copies up).  Registers: 48 accumulators + 32 landing + the operands in transit; two workgroups per CU.
 //
-// Weights without a pre-pass: w = |c| - 1 is dealt to the two operands as w 2^-e and 2^e with e = floor(log2|w| / 2) clamped to
-// [-12, 24] -- exact scalings; both operands stay within 2^k sqrt(2 |w|) |y| (k: the launch's operand scale).  Nothing bounds
-// |y| here: operands beyond the fp16 range turn into infinities, the image and the CG scalars stop being finite, and nm_cg hands
-// the row to the fp32 fix-up kernel instead of storing it.
+// Weights without a pre-pass (round 5): w = |c| - 1 enters both operands as sqrt|w| -- z = 2^k sqrt|w| y is split ONCE and is the y
+// operand as it stands and, with the sign of w flipped into the packed halves, the u operand (steps whose weights are all >= 0,
+// i.e. every step of the usual data, do not even write u).  Round 4 dealt w to two DIFFERENT operands (w 2^-e and 2^e, exact
+// scalings) and converted every gathered value twice; fp16 factor storage still does, because 2^e y is then an fp16 number and
+// needs no low half.  Nothing bounds |y| here: operands beyond the fp16 range turn into infinities, the image and the CG scalars
+// stop being finite, and nm_cg hands the row to the fp32 fix-up kernel instead of storing it.
 //
 // Returns with the image complete in the LDS (gramian added when `whole`), behind a barrier.
 template <int F, typename T>
@@ -205,6 +207,7 @@ __device__ __forceinline__ void nm_build(const int32_t *__restrict__ indices, co
     }
   };
   float *ops = smem;
+  int *negflag = reinterpret_cast<int *>(bvec + 2 * F + L::NP * F + 32);  // [4] (the reduction slots use the first 32 words)
   // entries: e0 = this round, e1 = next (its gather is issued at the end of this round's produce phase), e2 = the one after
   Entry e0{0, -1.f}, e1 = e0, e2 = e0;
   if (n_rounds > 0) {
@@ -219,10 +222,12 @@ __device__ __forceinline__ void nm_build(const int32_t *__restrict__ indices, co
     half8 h, l;
   };
   const float *lane_ops = ops + 4 * lane;
+  int negbits = 0;  // bit st: step st of the round carries a negative weight, its u quads are in the buffer (else u = z)
   auto ld_u = [&](int st, int I) {  // uh, ul of block I
     Pair p;
-    p.h = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4 *>(lane_ops + (st * 16 + 0 * 4 + I) * L::QUAD));
-    p.l = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4 *>(lane_ops + (st * 16 + 1 * 4 + I) * L::QUAD));
+    const int ku = (negbits >> st) & 1 ? 0 : 2;
+    p.h = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4 *>(lane_ops + (st * 16 + ku * 4 + I) * L::QUAD));
+    p.l = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4 *>(lane_ops + (st * 16 + (ku + 1) * 4 + I) * L::QUAD));
     return p;
   };
   auto ld_y = [&](int st, int J) {  // yh, yl of block J (fp16 factors: 2^e y is an fp16 number too, no low half)
@@ -238,6 +243,7 @@ __device__ __forceinline__ void nm_build(const int32_t *__restrict__ indices, co
     if constexpr (!kHalf) acc[k.value] = S::mfma(u.h, y.l, acc[k.value]);
   };
   auto consume = [&](int s0, int s1) {  // steps s0 .. s1 - 1 of the exchange buffer
+    negbits = __builtin_amdgcn_readfirstlane(negflag[0] | (negflag[1] << 1) | (negflag[2] << 2) | (negflag[3] << 3));
     if (wave == 0) {
       Pair u0 = ld_u(s0, 0), y0 = ld_y(s0, 0);
 #pragma unroll 1
@@ -284,44 +290,89 @@ __device__ __forceinline__ void nm_build(const int32_t *__restrict__ indices, co
     e2 = load_entry(r + 2);  // ahead of this round's gathers in the (in-order) load queue
     // ---- produce step `wave` of this round
     {
-      // this lane's entry: w = |c| - 1 dealt as wa = w 2^-e and sb = 2^e, e = floor((exponent of |w|) / 2) clamped to [-12, 12]
-      // (times the launch's operand scale 4^k, nm_gram_image_kernel: the image comes out scaled by 4^k and is scaled back,
-      // exactly, where it is written)
+      // this lane's entry.  fp32 factors: w = |c| - 1 (times the launch's operand scale 4^k, nm_gram_image_kernel: the image comes
+      // out scaled by 4^k and is scaled back, exactly, where it is written) enters BOTH operands as sqrt|w|: z = sqrt|w| y is
+      // split once and serves as y operand and -- with the sign of w, a bit flip of the packed halves -- as u operand: half the
+      // conversions of dealing w to two different operands (round 4), and steps without a negative weight (every step of the
+      // usual data, c >= 1) exchange half the quads.  v_sqrt_f32 is good to 1 ulp: z z carries w to 2^-23.
+      // fp16 factors: w dealt as wa = w 2^-e and sb = 2^e, e = floor((exponent of |w|) / 2) clamped to [-12, 24] -- exact
+      // scalings, 2^e y stays an fp16 number and needs no low half.
       const float w_mine = (fabsf(e0.c) - 1.f) * scale2;
-      unsigned hb = (((__float_as_uint(w_mine) & 0x7f800000u) + (127u << 23)) >> 1) & 0x7f800000u;
-      hb = min(max(hb, (127u - 12u) << 23), (127u + 24u) << 23);
-      const float sb_mine = __uint_as_float(hb), wa_mine = w_mine * __uint_as_float((254u << 23) - hb);
       const float cp_mine = e0.c > 0.f ? e0.c : 0.f;
-      float wa[8], sb[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        wa[q] = __shfl(wa_mine, 8 * g + q, 64);
-        sb[q] = __shfl(sb_mine, 8 * g + q, 64);
-        const float cp = __shfl(cp_mine, 8 * g + q, 64);
-        b4[0] = fmaf(cp, y[q].x, b4[0]);
-        b4[1] = fmaf(cp, y[q].y, b4[1]);
-        b4[2] = fmaf(cp, y[q].z, b4[2]);
-        b4[3] = fmaf(cp, y[q].w, b4[3]);
-      }
       float *mine = ops + (size_t)wave * 16 * L::QUAD + 4 * lane;
+      if constexpr (!kHalf) {
+        const float sq_mine = __builtin_amdgcn_sqrtf(fabsf(w_mine));
+        const unsigned ng_mine = w_mine < 0.f ? 0x8000u : 0u;
+        const bool any_neg = __builtin_amdgcn_ballot_w64(ng_mine != 0u) != 0ull;  // wave-uniform (lanes >= KCH hold copies)
+        if (lane == 0) negflag[wave] = any_neg ? 1 : 0;
+        float sq[8];
+        unsigned ng[8];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        u32x4 uh, ul, yh, yl;
-#pragma unroll
-        for (int q = 0; q < 8; q += 2) {
-          const float y0 = comp(y[q], c), y1 = comp(y[q + 1], c);
-          unsigned h, l;
-          split_pair(sb[q] * y0, sb[q + 1] * y1, h, l);
-          yh[q / 2] = h, yl[q / 2] = l;
-          split_pair(wa[q] * y0, wa[q + 1] * y1, h, l);
-          uh[q / 2] = h, ul[q / 2] = l;
+        for (int q = 0; q < 8; ++q) {
+          sq[q] = __shfl(sq_mine, 8 * g + q, 64);
+          ng[q] = (unsigned)__shfl((int)ng_mine, 8 * g + q, 64);
+          const float cp = __shfl(cp_mine, 8 * g + q, 64);
+          b4[0] = fmaf(cp, y[q].x, b4[0]);
+          b4[1] = fmaf(cp, y[q].y, b4[1]);
+          b4[2] = fmaf(cp, y[q].z, b4[2]);
+          b4[3] = fmaf(cp, y[q].w, b4[3]);
         }
-        *reinterpret_cast<u32x4 *>(mine + (0 * 4 + c) * L::QUAD) = uh;
-        *reinterpret_cast<u32x4 *>(mine + (1 * 4 + c) * L::QUAD) = ul;
-        *reinterpret_cast<u32x4 *>(mine + (2 * 4 + c) * L::QUAD) = yh;
-        if constexpr (!kHalf) *reinterpret_cast<u32x4 *>(mine + (3 * 4 + c) * L::QUAD) = yl;
-        __builtin_amdgcn_sched_barrier(0);  // one block's quads at a time: interleaved blocks spill, and a spill reload is a
-      }                                     // vector-memory load -- waiting for it (vmcnt 0) drains the gathers in flight
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          u32x4 zh, zl;
+#pragma unroll
+          for (int q = 0; q < 8; q += 2) {
+            unsigned h, l;
+            split_pair(sq[q] * comp(y[q], c), sq[q + 1] * comp(y[q + 1], c), h, l);
+            zh[q / 2] = h, zl[q / 2] = l;
+          }
+          *reinterpret_cast<u32x4 *>(mine + (2 * 4 + c) * L::QUAD) = zh;
+          *reinterpret_cast<u32x4 *>(mine + (3 * 4 + c) * L::QUAD) = zl;
+          if (any_neg) {  // u = sign(w) z, only where the step has a negative weight (the consumers read z otherwise)
+            u32x4 uh, ul;
+#pragma unroll
+            for (int q = 0; q < 8; q += 2) {
+              const unsigned m = ng[q] | (ng[q + 1] << 16);
+              uh[q / 2] = zh[q / 2] ^ m, ul[q / 2] = zl[q / 2] ^ m;
+            }
+            *reinterpret_cast<u32x4 *>(mine + (0 * 4 + c) * L::QUAD) = uh;
+            *reinterpret_cast<u32x4 *>(mine + (1 * 4 + c) * L::QUAD) = ul;
+          }
+          __builtin_amdgcn_sched_barrier(0);  // one block's quads at a time: interleaved blocks spill, and a spill reload is a
+        }                                     // vector-memory load -- waiting for it (vmcnt 0) drains the gathers in flight
+      } else {
+        unsigned hb = (((__float_as_uint(w_mine) & 0x7f800000u) + (127u << 23)) >> 1) & 0x7f800000u;
+        hb = min(max(hb, (127u - 12u) << 23), (127u + 24u) << 23);
+        const float sb_mine = __uint_as_float(hb), wa_mine = w_mine * __uint_as_float((254u << 23) - hb);
+        if (lane == 0) negflag[wave] = 1;  // the u quads are always written
+        float wa[8], sb[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          wa[q] = __shfl(wa_mine, 8 * g + q, 64);
+          sb[q] = __shfl(sb_mine, 8 * g + q, 64);
+          const float cp = __shfl(cp_mine, 8 * g + q, 64);
+          b4[0] = fmaf(cp, y[q].x, b4[0]);
+          b4[1] = fmaf(cp, y[q].y, b4[1]);
+          b4[2] = fmaf(cp, y[q].z, b4[2]);
+          b4[3] = fmaf(cp, y[q].w, b4[3]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          u32x4 uh, ul, yh;
+#pragma unroll
+          for (int q = 0; q < 8; q += 2) {
+            const float y0 = comp(y[q], c), y1 = comp(y[q + 1], c);
+            unsigned h, l;
+            yh[q / 2] = pack_pair(sb[q] * y0, sb[q + 1] * y1);
+            split_pair(wa[q] * y0, wa[q + 1] * y1, h, l);
+            uh[q / 2] = h, ul[q / 2] = l;
+          }
+          *reinterpret_cast<u32x4 *>(mine + (0 * 4 + c) * L::QUAD) = uh;
+          *reinterpret_cast<u32x4 *>(mine + (1 * 4 + c) * L::QUAD) = ul;
+          *reinterpret_cast<u32x4 *>(mine + (2 * 4 + c) * L::QUAD) = yh;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     }
     gather(e1, y);  // the landing registers are free again (beyond the last round: the segment's last row, unused)
   };
