@@ -1,5 +1,7 @@
 """CPU model of the operand arithmetic of the normal-matrix kernels (implicit_amd/csrc/als_cg_nm.hip), so that its precision and
-range claims are checked where no GPU is: the weight w = |c| - 1 is dealt to the two matrix-core operands as w 2^-e and 2^e
+range claims are checked where no GPU is.  fp32 factors (round 5): the weight w = |c| - 1 enters both operands as sqrt|w| (one
+split per gathered value, the sign of w as a bit flip of one operand) -- `root_products` below.  fp16 factor storage (and round 4
+for both): the weight w = |c| - 1 is dealt to the two matrix-core operands as w 2^-e and 2^e
 (e = floor(exponent(|w|) / 2), clamped to [-12, 24]; w carries the launch's operand scale 4^k), each operand is split into two fp16 halves (round to nearest), and a product
 keeps the three terms  u_h y_h + u_l y_h + u_h y_l  with fp32 accumulation.  The numpy code below restates nm_build's produce
 phase bit for bit (same integer expression for the exponent, same conversions); the GPU parity of the whole kernel is
@@ -130,3 +132,30 @@ def test_operands_beyond_the_fp16_range_become_infinite_not_wrong():
         assert np.isinf(h) and not np.isfinite(l)
         assert not np.isfinite(three_products(u, np.float32(0.5)))
         assert not np.isfinite(three_products(u, np.float32(0.0)))
+
+
+def root_products(w, y_i, y_j, k=0):
+    """nm_build's fp32-storage form: z = sqrt(|w| 4^k) y split once, u = sign(w) z; three products, scaled back by 4^-k."""
+    w = np.asarray(w, np.float32) * np.float32(4.0 ** k)
+    sq = np.sqrt(np.abs(w)).astype(np.float32)            # v_sqrt_f32: 1 ulp
+    zi, zj = sq * np.asarray(y_i, np.float32), sq * np.asarray(y_j, np.float32)
+    return np.sign(w).astype(np.float64) * three_products(zi, zj) * 4.0 ** -k
+
+
+def test_root_form_matches_the_dealt_form():
+    """One split per value instead of two: the product carries w to 2^-23 (the square root's ulp twice) on top of the halves' 2^-22,
+    for positive, negative (confidences below one: -1 < w < 0) and zero weights."""
+    rng = np.random.default_rng(5)
+    n = 200_000
+    y_i = (rng.standard_normal(n) * 0.1).astype(np.float32)
+    y_j = (rng.standard_normal(n) * 0.1).astype(np.float32)
+    w = np.concatenate([rng.random(n - 1000) * 40, -rng.random(999), [0.0]]).astype(np.float32)
+    k = operand_scale(float((y_i.astype(np.float64) ** 2).sum() / 100), n // 100)
+    got = root_products(w, y_i, y_j, k)
+    exact = w.astype(np.float64) * y_i * y_j
+    big = np.abs(exact) > 1e-4 * np.abs(exact).max()
+    rel = np.abs(got - exact)[big] / np.abs(exact)[big]
+    print("root form: k = %d, worst rel %.2e, mean %.2e" % (k, rel.max(), rel.mean()))
+    assert rel.max() < 2.0 ** -17 and rel.mean() < 2.0 ** -20
+    assert got[-1] == 0.0 and (np.sign(got[:-1]) == np.sign(exact[:-1]))[np.abs(exact[:-1]) > 0].all()
+    assert abs(got.sum() - exact.sum()) / np.abs(exact).sum() < 2e-7   # unbiased over a row
