@@ -42,7 +42,6 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 struct W256 {
   static constexpr int F = 256;
-  static constexpr int LDB = F + 8;   // halves per published operand row (conflict-free b128 fragment reads)
   static constexpr int LDO = F + 4;   // floats per row of the product's result (conflict-free b128 writes by 16 columns)
   static constexpr size_t kFragHalves = (size_t)16 * 8 * 2 * 512;  // [wave][k-step][H | L][lane][8]
 };
@@ -50,7 +49,7 @@ struct W256 {
 // first KRES of the 8 k-steps of its slice of H in the LDS for the whole launch (all of them from teams of 8 up) and streams
 // only the rest -- the product is bound by what it reads from L2 per pass.
 template <int R> struct W256Lds {
-  static constexpr int F = W256::F, LDB = W256::LDB, LDO = W256::LDO;
+  static constexpr int F = W256::F, LDO = W256::LDO;
   static constexpr int oV = 0;                          // [R rows][256] f32    operand of the pass, natural factor order
   static constexpr int oR = oV + R * F * 4;             // [R rows][256] f32    residual
   static constexpr int oSp = oR + R * F * 4;            // [16 waves][256] f32  tile part of each wavefront
@@ -58,8 +57,14 @@ template <int R> struct W256Lds {
   // the two result columns; R = 16: separate operand sets (high | low), four products per k-step
   static constexpr int COLS = R <= 8 ? 2 * R : 16;
   static constexpr int oOut = oSp + 16 * F * 4;         // [COLS][LDO] f32      matrix-core product (scaled units)
-  static constexpr int oPb = oOut + COLS * LDO * 4;     // [2 R][LDB] f16       operands for the matrix cores
-  static constexpr int oCw = oPb + 2 * R * LDB * 2;     // [16 waves][32] f32   |c| - 1, c+ of the resident entries
+  // the operands of the matrix cores in FRAGMENT order: [set][k-step][lane = column + 16 kq][8 halves], all 16 columns of a set
+  // whatever R is.  A row-major [column][k] array with padded rows -- the layout of the f = 128 short-row kernel -- is not
+  // conflict-free under the real lane groups of ds_read_b128 ({0-3, 12-15, 20-27}, ...: MI355X_MICROARCH.md), and re-reading
+  // column n % 2R for the unused columns made it worse: SQ_LDS_BANK_CONFLICT read 0.77 of the LDS's active cycles
+  // (profiles/r05_w256_counters.txt).  A lane-linear 1 KB block per k-step is conflict-free by construction.
+  static constexpr int SETS = R <= 8 ? 1 : 2;           // paired columns: one set; R = 16: high halves | low halves
+  static constexpr int oPb = oOut + COLS * LDO * 4;     // [SETS][8 k-steps][64 lanes][8] f16
+  static constexpr int oCw = oPb + SETS * 8 * 1024;     // [16 waves][32] f32   |c| - 1, c+ of the resident entries
   static constexpr int oAct = oCw + 16 * 32 * 4;        // [16 rows] int        row still iterating
   static constexpr int oH = oAct + 16 * 4;              // [16 waves][KRES][64 lanes][8] f16   resident part of H (fragment order)
   static constexpr int kLdsMax = 160 * 1024;
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(1024) void als_cg_w256_kernel(const int32_t *__rest
                                                            const float *__restrict__ Y, const _Float16 *__restrict__ gfrag,
                                                            const float *__restrict__ hdr, int cg_steps,
                                                            int ko) {  // ko: timing-only knock-outs (IMP_W256_KO), 0 in production
-  constexpr int F = W256::F, R = 16 / WPR, LDB = W256::LDB, LDO = W256::LDO;
+  constexpr int F = W256::F, R = 16 / WPR, LDO = W256::LDO;
   using M = W256Lds<R>;
   constexpr int KRES = M::KRES;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -127,6 +132,7 @@ __global__ __launch_bounds__(1024) void als_cg_w256_kernel(const int32_t *__rest
   const int j = wave / WPR, s = wave % WPR;  // row of the group, position in its team
   const bool leader = s == 0;
   const float ginv = hdr[0];
+  for (int e = threadIdx.x; e < M::SETS * 8 * 1024 / 4; e += 1024) reinterpret_cast<unsigned *>(Pb)[e] = 0u;  // unused columns
   float *const vrow = Vs + j * F, *const cw = Cw + wave * 32;
   const h8 *const gfw = reinterpret_cast<const h8 *>(gfrag) + (size_t)wave * 16 * 64;  // this wave's 16 blocks of 64 x 16 bytes
 #pragma unroll
@@ -136,8 +142,8 @@ __global__ __launch_bounds__(1024) void als_cg_w256_kernel(const int32_t *__rest
   // ---- matrix-core part: Out[n][16 wave + ..] = sum_k (H + L)[16 wave + i][k] (ph + pl)[n][k], three products ------------------
   // k-steps 0 .. KRES-1 take H from the LDS; per pass a wavefront streams L (8 blocks) and the rest of H from L2, eight loads in
   // flight.  Four products: H h, H l, L h and L l (the last is 2^-22 of the sum: with it the product is exact in the 22-bit halves)
-  // The MFMA's 16 columns are the group's R rows; columns n >= R re-read column n % R (a column of the product depends on
-  // nothing but its own operand column, and nobody reads those results).
+  // The MFMA's 16 columns are the group's R rows (2 R with paired columns); the columns beyond stay zero and nobody reads
+  // their results.
   auto product = [&]() __attribute__((always_inline)) {
     if (ko & 1) return;
     const int ln = opaque(lane);
@@ -145,29 +151,45 @@ __global__ __launch_bounds__(1024) void als_cg_w256_kernel(const int32_t *__rest
     const h8 *gl = gfw + ln;
     const h8 *hres = Hres + ln;
     constexpr bool PAIRED = R <= 8;  // both halves of the operands in one B fragment (columns 2 j, 2 j + 1)
-    const _Float16 *bh_row = Pb + (size_t)(PAIRED ? (n & (2 * R - 1)) : n) * LDB + 8 * kq, *bl_row = bh_row + R * LDB;
+    const h8 *bfrag = reinterpret_cast<const h8 *>(Pb) + ln;  // block ks of set t: bfrag[(t * 8 + ks) * 64]
     // two accumulators: the products with L and with H form independent chains (a dependent MFMA waits out its predecessor)
     v4f acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-    constexpr int NH = 8 - KRES;  // k-steps of H that are streamed: KRES .. 7
-    h8 lo[8], hi[NH > 0 ? NH : 1];
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
+    // The streamed blocks in the order they are used -- for k-step ks: H[ks] if it is not resident, then L[ks] -- through a ring of
+    // NB registers-quads: NB loads in flight, the slot of a block is re-filled as soon as the block has been multiplied.  (All
+    // eight L blocks plus the streamed H at once, the first form, left no registers for anything else: the R = 8 kernel
+    // spilled four registers of the TILE and reloaded them in every pass.)
+    constexpr int NH = 8 - KRES;       // k-steps of H that are streamed: KRES .. 7
+    constexpr int NF = 8 + NH, NB = 6;  // blocks per pass, ring size
+    h8 ring[NB];
+    // block i of the sequence: k-steps below KRES contribute one block (L), the others two (H, then L)
+    auto block_of = [](int i, int &ks, int &is_h) {
+      if (i < KRES) {
+        ks = i, is_h = 0;
+      } else {
+        ks = KRES + (i - KRES) / 2, is_h = ((i - KRES) & 1) == 0;
+      }
+    };
+    auto fetch = [&](auto Ic) {
+      constexpr int i = decltype(Ic)::value;
+      int ks = 0, is_h = 0;
+      block_of(i, ks, is_h);
 #ifdef W256_KO_NOLOAD  // timing-only builds (implicit_amd/_build.py build_variant)
-      lo[ks] = hres[0];
+      ring[i % NB] = hres[0];
 #else
-      lo[ks] = gl[(ks * 2 + 1) * 64];
+      ring[i % NB] = gl[(ks * 2 + (is_h ? 0 : 1)) * 64];
 #endif
-    }
-    // (without the fence the scheduler sinks every load to its first use to save registers: two loads in flight, eight L2 round
-    // trips per pass)
+    };
+    static_for<(NB < NF ? NB : NF)>([&](auto Ic) { fetch(Ic); });
+    // (without the fence the scheduler sinks every load to its first use to save registers: two loads in flight, an L2 round
+    // trip per k-step)
     __builtin_amdgcn_sched_barrier(0);
     auto step = [&](int ks, const h8 &H, const h8 &L) {
 #ifdef W256_KO_NOB
       const h8 bh = L, bl = H;
 #else
-      const h8 bh = *reinterpret_cast<const h8 *>(bh_row + 32 * ks);
+      const h8 bh = bfrag[ks * 64];
       h8 bl = bh;
-      if constexpr (!PAIRED) bl = *reinterpret_cast<const h8 *>(bl_row + 32 * ks);
+      if constexpr (!PAIRED) bl = bfrag[(8 + ks) * 64];
 #endif
 #ifdef W256_KO_NOMFMA
       asm volatile("" ::"v"(L), "v"(H), "v"(bh), "v"(bl));
@@ -183,19 +205,17 @@ __global__ __launch_bounds__(1024) void als_cg_w256_kernel(const int32_t *__rest
       }
 #endif
     };
-    // the streamed part of H goes into the registers the first k-steps' L halves free: at most eight blocks in flight
     static_for<8>([&](auto Kc) {
       constexpr int ks = decltype(Kc)::value;
-      if constexpr (ks < KRES) {
-        step(ks, hres[ks * 64], lo[ks]);
-        if constexpr (ks < NH) {
-          __builtin_amdgcn_sched_barrier(0);
-          hi[ks] = gl[((KRES + ks) * 2) * 64];
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      } else {
-        step(ks, hi[ks - KRES], lo[ks]);
-      }
+      // index of this k-step's L block in the sequence (its H block, if streamed, is the one before)
+      constexpr int iL = ks < KRES ? ks : KRES + 2 * (ks - KRES) + 1;
+      if constexpr (ks < KRES) step(ks, hres[ks * 64], ring[iL % NB]);
+      else step(ks, ring[(iL - 1) % NB], ring[iL % NB]);
+      // re-fill the slots just used (fenced: the re-fill may not move above the MFMAs that read the slot, nor sink to its use)
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ks >= KRES && iL - 1 + NB < NF) fetch(idx_t<(iL - 1 + NB < NF ? iL - 1 + NB : 0)>{});
+      if constexpr (iL + NB < NF) fetch(idx_t<(iL + NB < NF ? iL + NB : 0)>{});
+      __builtin_amdgcn_sched_barrier(0);
     });
     if (n < M::COLS)
       *reinterpret_cast<float4 *>(Out + (size_t)n * LDO + 16 * wave + 4 * kq) =
@@ -362,9 +382,13 @@ __global__ __launch_bounds__(1024) void als_cg_w256_kernel(const int32_t *__rest
       hi[0] = (_Float16)a0, hi[1] = (_Float16)a1, hi[2] = (_Float16)a2, hi[3] = (_Float16)a3;
       lo[0] = (_Float16)(a0 - (float)hi[0]), lo[1] = (_Float16)(a1 - (float)hi[1]);
       lo[2] = (_Float16)(a2 - (float)hi[2]), lo[3] = (_Float16)(a3 - (float)hi[3]);
+      // lane l holds k = 4 l .. 4 l + 3: k-step l / 8, lane group kq = (l % 8) / 2, elements 4 (l % 2) ..; column c of a set sits
+      // in lane c + 16 kq of the block
       constexpr bool PAIRED = R <= 8;
-      *reinterpret_cast<h4 *>(Pb + (size_t)(PAIRED ? 2 * j : j) * LDB + 4 * ln) = hi;
-      *reinterpret_cast<h4 *>(Pb + (size_t)(PAIRED ? 2 * j + 1 : R + j) * LDB + 4 * ln) = lo;
+      const int c_hi = PAIRED ? 2 * j : j, c_lo = PAIRED ? 2 * j + 1 : j;
+      _Float16 *blk = Pb + (size_t)(ln >> 3) * 512 + (size_t)(16 * ((ln & 7) >> 1)) * 8 + 4 * (ln & 1);
+      *reinterpret_cast<h4 *>(blk + c_hi * 8) = hi;
+      *reinterpret_cast<h4 *>(blk + (PAIRED ? 0 : 8 * 512) + c_lo * 8) = lo;
     };
     auto dot4 = [](const float4 &a, const float4 &b) { return wave_allsum(fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)))); };
     // dense product of this row + the team's tile parts, lane l: factors 4 l ..

@@ -2,7 +2,7 @@
 per-kernel HIP-event times.  IMP_F256_OLD=1 for the A/B."""
 import json, os, sys, time
 import numpy as np
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 import implicit_amd.gpu as gpu
 from implicit_amd.synthetic import SHAPES, named
