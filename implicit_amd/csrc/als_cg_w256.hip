@@ -73,6 +73,9 @@ template <int R> struct W256Lds {
   static_assert(oH % 16 == 0 && oPb % 16 == 0 && KRES >= 1, "LDS map");
 };
 
+#ifdef W256_STATS  // timing-only build (build_variant): shader-clock cycles per phase, summed over the waves of a launch
+__device__ unsigned long long g_w256_stats[8];  // [0] product [2] tile entries [3] wait at B2 [4] leader update [5] wait at B1 [6] group start [7] lifetime
+#endif
 __device__ __forceinline__ int wave_of(unsigned tid) { return __builtin_amdgcn_readfirstlane((int)(tid >> 6)); }
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -131,6 +134,19 @@ __global__ __launch_bounds__(1024) void als_cg_w256_kernel(const int32_t *__rest
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = wave / WPR, s = wave % WPR;  // row of the group, position in its team
   const bool leader = s == 0;
+#ifdef W256_STATS
+  unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = __builtin_amdgcn_s_memtime();
+  const unsigned long long t_begin = t_last;
+  auto tick = [&](int slot) {
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long now = __builtin_amdgcn_s_memtime();
+    tk[slot] += now - t_last;
+    t_last = now;
+    __builtin_amdgcn_sched_barrier(0);
+  };
+#else
+  auto tick = [](int) {};
+#endif
   const float ginv = hdr[0];
   for (int e = threadIdx.x; e < M::SETS * 8 * 1024 / 4; e += 1024) reinterpret_cast<unsigned *>(Pb)[e] = 0u;  // unused columns
   float *const vrow = Vs + j * F, *const cw = Cw + wave * 32;
@@ -420,11 +436,16 @@ __global__ __launch_bounds__(1024) void als_cg_w256_kernel(const int32_t *__rest
       publish(x4, valid);
       if (lane == 0) Act[j] = valid ? 1 : 0;
     }
+    tick(6);
     lds_barrier();
+    tick(5);
     // ---- pass 0: r = -(A0 x) + sum_k (c+ - (|c|-1) y.x) y        (_als.pyx:187-201); the product first: it needs no gather ----
     product();
+    tick(0);
     tile_pass(std::true_type{}, std::false_type{}, valid);
+    tick(2);
     lds_barrier();
+    tick(3);
     if (leader) {
       const int ln = opaque(lane);
       float4 dn, sp4;
@@ -436,18 +457,25 @@ __global__ __launch_bounds__(1024) void als_cg_w256_kernel(const int32_t *__rest
       publish(r4, active);
       if (lane == 0) Act[j] = active ? 1 : 0;
     }
+    tick(4);
     lds_barrier();
+    tick(5);
     const bool tiles_first = ((wave >> 2) & 1) != 0;
     for (int it = 0; it + 1 < cg_steps; ++it) {  // all steps but the last
       const bool on = __builtin_amdgcn_readfirstlane(Act[j]) != 0;
       if (tiles_first) {
         tile_pass(std::false_type{}, std::false_type{}, on);
+        tick(2);
         product();
+        tick(0);
       } else {
         product();
+        tick(0);
         tile_pass(std::false_type{}, std::false_type{}, on);
+        tick(2);
       }
       lds_barrier();
+      tick(3);
       if (leader && active && !(ko & 8)) {  // wave-uniform
         const int ln = opaque(lane);
         float4 dn, sp4;
@@ -472,7 +500,9 @@ __global__ __launch_bounds__(1024) void als_cg_w256_kernel(const int32_t *__rest
         }
         if (lane == 0) Act[j] = active ? 1 : 0;
       }
+      tick(4);
       lds_barrier();
+      tick(5);
     }
     // The last step stands outside the loop (the compiler must see that nothing of this group follows it): the product first in
     // every wave (its loads must not queue behind the gathers), then the tile entries with nxt's tile rolling in behind them;
@@ -481,10 +511,13 @@ __global__ __launch_bounds__(1024) void als_cg_w256_kernel(const int32_t *__rest
     {
       const bool on = __builtin_amdgcn_readfirstlane(Act[j]) != 0;
       product();
+      tick(0);
       float4 xn = make_float4(0.f, 0.f, 0.f, 0.f);
       if (leader && nxt.valid) xn = *reinterpret_cast<const float4 *>(X + (size_t)nxt.u * F + 4 * opaque(lane));
       tile_pass(std::false_type{}, std::true_type{}, on);
+      tick(2);
       lds_barrier();
+      tick(3);
       if (leader && active && !(ko & 8)) {  // wave-uniform
         const int ln = opaque(lane);
         float4 dn, sp4;
@@ -496,12 +529,21 @@ __global__ __launch_bounds__(1024) void als_cg_w256_kernel(const int32_t *__rest
         *reinterpret_cast<float4 *>(xrow + 4 * ln) = x4;
       }
       x_next = xn;
+      tick(4);
       lds_barrier();
+      tick(5);
     }
     cur = nxt;
     nxt = share_of(g + 2 * g_step);
     fetch_entries16(nxt, ent_col, ent_c);
   }
+#ifdef W256_STATS
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) atomicAdd(&g_w256_stats[k], tk[k]);
+    atomicAdd(&g_w256_stats[7], (unsigned long long)__builtin_amdgcn_s_memtime() - t_begin);
+  }
+#endif
 }
 
 template <int WPR>
@@ -520,6 +562,17 @@ void launch_w256_class(const imp_csr *C, int first, int count, float *X, const f
   kern<<<grid, 1024, lds_bytes, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(), C->data.data(), X, Y,
                                               gfrag, hdr, cg_steps, ko);
   IMP_CHECK_HIP(hipGetLastError());
+#ifdef W256_STATS
+  {
+    unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    IMP_CHECK_HIP(hipStreamSynchronize(stream()));
+    IMP_CHECK_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_w256_stats), sizeof(h)));
+    IMP_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_w256_stats), z, sizeof(z)));
+    const double wg = (double)grid * 16.0, gr = (double)groups * 16.0;  // waves launched, wave-groups processed
+    fprintf(stderr, "[w256-stats] %s groups=%d  cycles per wave and group: product %.0f  tiles %.0f  wait-B2 %.0f  update %.0f  wait-B1 %.0f  "
+                    "start %.0f | lifetime per wave %.0f\n", name, groups, h[0] / gr, h[2] / gr, h[3] / gr, h[4] / gr, h[5] / gr, h[6] / gr, h[7] / wg);
+  }
+#endif
 }
 
 }  // namespace
