@@ -110,7 +110,7 @@ __device__ __forceinline__ float comp(const float4 &v, int c) { return c == 0 ? 
 // because the diagonal carries the regularisation) to about 8; it never scales down (k >= 0), and a row whose scaled operands
 // leave the fp16 range is caught by nm_cg's finiteness check and re-solved in fp32 (the fix-up list).  ctl[2] counts those rows.
 template <int F> __global__ void nm_gram_image_kernel(const float *__restrict__ A0, float *__restrict__ img, int *__restrict__ ctl,
-                                                      float y_rows, int forced_k) {
+                                                      float y_rows, int forced_k, float reg = 0.f) {  // reg: added to the diagonal (Cholesky path: YtY arrives bare)
   using L = NmLayout<F>;
   if (blockIdx.x == 0 && threadIdx.x < 64) {
     float d = 0.f;
@@ -118,16 +118,17 @@ template <int F> __global__ void nm_gram_image_kernel(const float *__restrict__ 
     d = wave_allmax(d);
     if (threadIdx.x == 0) {
       int k = 0;
-      const float rms = sqrtf(d / fmaxf(y_rows, 1.f));
+      const float rms = sqrtf((d + reg) / fmaxf(y_rows, 1.f));
       if (rms > 0.f && rms < 8.f) k = min((int)floorf(log2f(8.f / rms)), 16);  // NaN / inf / zero diagonal: k = 0
       ctl[0] = 0;
       ctl[1] = forced_k >= 0 ? forced_k : k;
       ctl[2] = 0;
+      ctl[3] = 0;
     }
   }
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < L::IMG; e += gridDim.x * blockDim.x) {
     const int n = e % L::TS, m = (e / L::TS) % L::M, t = e / (L::TS * L::M);
-    img[e] = n < L::M ? A0[(size_t)(4 * m + t / 4) * F + 4 * n + t % 4] : 0.f;
+    img[e] = n < L::M ? A0[(size_t)(4 * m + t / 4) * F + 4 * n + t % 4] + ((m == n && t / 4 == t % 4) ? reg : 0.f) : 0.f;
   }
 }
 
@@ -494,10 +495,175 @@ __device__ __forceinline__ bool nm_cg(const float *img, const float *bvec, float
   return false;
 }
 
+// ---- Cholesky on the LDS image (round 5): x = A_u^-1 b, what the CPU reference's posv does per row (_als.pyx:75-142) ---------------
+// f = 128, 256 threads.  The image's 4 x 4 interleaving makes position (m, n) of its sixteen tiles the 4 x 4 block
+// A[4m .. 4m+3][4n .. 4n+3]: the 528 blocks of the lower triangle are dealt to the threads (at most three each) and stay in
+// REGISTERS for the whole factorisation -- right-looking, one block column per turn:
+//   * everybody reads the (updated) diagonal block its owner published and factors it redundantly (4 x 4 Cholesky, v_rsq + one
+//     Newton step): no serial phase, no extra barrier;
+//   * the owners of the blocks below it solve them against the diagonal factor (they are L now) and publish the panel;
+//   * barrier; every block to the right takes its rank-4 update from the panel (two 4 x 4 operands from the LDS, 64 FMAs), the
+//     owner of the next diagonal block publishes it; barrier.
+// b rides along as a 129th row (thread t holds b[4t .. 4t+3]): z = L^-1 b is complete when the factorisation is.  L then goes to
+// the LDS row-major (the image's space: F (F + 4) floats exactly) and x = L^-T z is a blocked back substitution, one barrier per
+// block.  Returns true -- and stores nothing -- when a pivot is not positive (or not finite): the caller lists the row for the
+// workgroup-per-row fp32 kernel, which then decides whether it is a failure (_als.pyx:136-138).
+template <int F>
+__device__ __forceinline__ bool nm_chol(float *img, float *bvec, float *scr, float *xrow, int tid) {
+  static_assert(F == 128, "block ownership and the LDS budget are laid out for f = 128");
+  using L = NmLayout<F>;
+  constexpr int NB = F / 4, NBLK = NB * (NB + 1) / 2, LDL = F + 4, SL = (NBLK + 255) / 256;
+  static_assert(F * LDL <= L::kVec, "the row-major factor re-uses the image's space");
+  float *pan = scr;                // [2][F][4]  panel: L[i][4 kb .. 4 kb + 3] of the current block column
+  float *dblk = scr + 2 * F * 4;   // [2][16]    the diagonal block of the coming turn, as updated so far
+  int bm[SL], bn[SL];
+  float B[SL][4][4];
+#pragma unroll
+  for (int s = 0; s < SL; ++s) {
+    const int bid = tid + 256 * s;
+    bm[s] = bn[s] = -1;
+    if (bid < NBLK) {
+      int m = (int)((sqrtf(8.f * (float)bid + 1.f) - 1.f) * 0.5f);
+      while (m * (m + 1) / 2 > bid) --m;
+      while ((m + 1) * (m + 2) / 2 <= bid) ++m;
+      bm[s] = m, bn[s] = bid - m * (m + 1) / 2;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) B[s][a][c] = img[L::at(a, c, bm[s], bn[s])];
+    }
+  }
+  float rb[4] = {0.f, 0.f, 0.f, 0.f};  // b[4 tid ..] (the image's vectors are stored position I M + m = factor 4 m + I)
+  if (tid < NB) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) rb[c] = bvec[c * L::M + tid];
+  }
+  __syncthreads();  // the image and b have been read: their space is free
+  if (tid == 0) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) *reinterpret_cast<float4 *>(dblk + 4 * a) = make_float4(B[0][a][0], B[0][a][1], B[0][a][2], B[0][a][3]);
+  }
+  __syncthreads();
+  bool fail = false;
+#pragma unroll 1
+  for (int kb = 0; kb < NB; ++kb) {
+    const float *D = dblk + (kb & 1) * 16;
+    float *P = pan + (size_t)(kb & 1) * F * 4;
+    const float4 d0 = *reinterpret_cast<const float4 *>(D), d1 = *reinterpret_cast<const float4 *>(D + 4),
+                 d2 = *reinterpret_cast<const float4 *>(D + 8), d3 = *reinterpret_cast<const float4 *>(D + 12);
+    auto rsq = [](float d) {  // 1 / sqrt(d): v_rsq_f32 + one Newton step
+      const float r = __builtin_amdgcn_rsqf(d);
+      return r * fmaf(-0.5f * d * r, r, 1.5f);
+    };
+    // 4 x 4 Cholesky of the diagonal block, by every thread alike
+    const float p0 = d0.x, r0 = rsq(p0), l00 = p0 * r0;
+    const float l10 = d1.x * r0, l20 = d2.x * r0, l30 = d3.x * r0;
+    const float p1 = fmaf(-l10, l10, d1.y), r1 = rsq(p1), l11 = p1 * r1;
+    const float l21 = fmaf(-l20, l10, d2.y) * r1, l31 = fmaf(-l30, l10, d3.y) * r1;
+    const float p2 = fmaf(-l21, l21, fmaf(-l20, l20, d2.z)), r2 = rsq(p2), l22 = p2 * r2;
+    const float l32 = fmaf(-l31, l21, fmaf(-l30, l20, d3.z)) * r2;
+    const float p3 = fmaf(-l32, l32, fmaf(-l31, l31, fmaf(-l30, l30, d3.w))), r3 = rsq(p3), l33 = p3 * r3;
+    if (!(p0 > 0.f && p1 > 0.f && p2 > 0.f && p3 > 0.f && p3 < 3.0e38f)) {  // uniform: every thread holds the same values
+      fail = true;
+      break;
+    }
+    auto solve_row = [&](float (&v)[4]) {  // v <- v L_D^-T
+      const float x0 = v[0] * r0;
+      const float x1 = fmaf(-x0, l10, v[1]) * r1;
+      const float x2 = fmaf(-x1, l21, fmaf(-x0, l20, v[2])) * r2;
+      const float x3 = fmaf(-x2, l32, fmaf(-x1, l31, fmaf(-x0, l30, v[3]))) * r3;
+      v[0] = x0, v[1] = x1, v[2] = x2, v[3] = x3;
+    };
+#pragma unroll
+    for (int s = 0; s < SL; ++s) {
+      if (bn[s] == kb) {
+        if (bm[s] > kb) {
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            solve_row(B[s][a]);
+            *reinterpret_cast<float4 *>(P + (size_t)(4 * bm[s] + a) * 4) = make_float4(B[s][a][0], B[s][a][1], B[s][a][2], B[s][a][3]);
+          }
+        } else {  // the diagonal block itself: its factor
+          B[s][0][0] = l00, B[s][1][0] = l10, B[s][1][1] = l11, B[s][2][0] = l20, B[s][2][1] = l21, B[s][2][2] = l22;
+          B[s][3][0] = l30, B[s][3][1] = l31, B[s][3][2] = l32, B[s][3][3] = l33;
+        }
+      }
+    }
+    if (tid == kb) {  // z[4 kb ..]: the right-hand side's block of this column
+      solve_row(rb);
+      *reinterpret_cast<float4 *>(bvec + 4 * kb) = make_float4(rb[0], rb[1], rb[2], rb[3]);
+    }
+    __syncthreads();
+    float *Dn = dblk + ((kb + 1) & 1) * 16;
+#pragma unroll
+    for (int s = 0; s < SL; ++s) {
+      if (bn[s] > kb) {  // (bm >= bn > kb)
+        float4 pm[4], pn[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          pm[a] = *reinterpret_cast<const float4 *>(P + (size_t)(4 * bm[s] + a) * 4);
+          pn[a] = *reinterpret_cast<const float4 *>(P + (size_t)(4 * bn[s] + a) * 4);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            B[s][a][c] = fmaf(-pm[a].w, pn[c].w, fmaf(-pm[a].z, pn[c].z, fmaf(-pm[a].y, pn[c].y, fmaf(-pm[a].x, pn[c].x, B[s][a][c]))));
+        if (bn[s] == kb + 1 && bm[s] == kb + 1) {
+#pragma unroll
+          for (int a = 0; a < 4; ++a) *reinterpret_cast<float4 *>(Dn + 4 * a) = make_float4(B[s][a][0], B[s][a][1], B[s][a][2], B[s][a][3]);
+        }
+      }
+    }
+    if (tid < NB && tid > kb) {
+      const float4 z4 = *reinterpret_cast<const float4 *>(bvec + 4 * kb);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 pc = *reinterpret_cast<const float4 *>(P + (size_t)(4 * tid + c) * 4);
+        rb[c] = fmaf(-z4.w, pc.w, fmaf(-z4.z, pc.z, fmaf(-z4.y, pc.y, fmaf(-z4.x, pc.x, rb[c]))));
+      }
+    }
+    __syncthreads();
+  }
+  if (fail) return true;
+  // L, row-major, into the image's space (the lower triangle; nothing above the diagonal is read)
+#pragma unroll
+  for (int s = 0; s < SL; ++s) {
+    if (bm[s] >= 0) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+        *reinterpret_cast<float4 *>(img + (size_t)(4 * bm[s] + a) * LDL + 4 * bn[s]) = make_float4(B[s][a][0], B[s][a][1], B[s][a][2], B[s][a][3]);
+    }
+  }
+  __syncthreads();
+  // x = L^-T z, four unknowns per turn from the bottom: every thread solves the 4 x 4 block alike, thread i < 4 kb takes the
+  // solved unknowns out of z[i]
+  float *xs = pan;
+#pragma unroll 1
+  for (int kb = NB - 1; kb >= 0; --kb) {
+    const float *row = img + (size_t)(4 * kb) * LDL + 4 * kb;
+    const float4 q0 = *reinterpret_cast<const float4 *>(row), q1 = *reinterpret_cast<const float4 *>(row + LDL),
+                 q2 = *reinterpret_cast<const float4 *>(row + 2 * LDL), q3 = *reinterpret_cast<const float4 *>(row + 3 * LDL);
+    const float4 z = *reinterpret_cast<const float4 *>(bvec + 4 * kb);
+    const float x3 = z.w / q3.w;
+    const float x2 = fmaf(-q3.z, x3, z.z) / q2.z;
+    const float x1 = fmaf(-q3.y, x3, fmaf(-q2.y, x2, z.y)) / q1.y;
+    const float x0 = fmaf(-q3.x, x3, fmaf(-q2.x, x2, fmaf(-q1.x, x1, z.x))) / q0.x;
+    if (tid < 4 * kb) {  // (elements below 4 kb: nobody reads them in this turn)
+      const float *col = img + (size_t)(4 * kb) * LDL + tid;
+      bvec[tid] = fmaf(-col[3 * LDL], x3, fmaf(-col[2 * LDL], x2, fmaf(-col[LDL], x1, fmaf(-col[0], x0, bvec[tid]))));
+    }
+    if (tid == 0) *reinterpret_cast<float4 *>(xs + 4 * kb) = make_float4(x0, x1, x2, x3);
+    __syncthreads();
+  }
+  if (tid < F) xrow[tid] = xs[tid];
+  return false;
+}
+
 // One workgroup per segment of plan_nm at a time; a row that is ONE segment is solved here, the others leave partial[seg] =
 // (image part, b part).  Segments are handed out through a ticket counter in plan order (longest first): with fixed shares the
 // average wavefront was alive for 66 % of the launch (segments of up to `nm_segment` nonzeros = up to 100 us each in a 320 us launch).
-template <int F, typename T>
+template <int F, typename T, bool CHOL = false>
 __global__ __launch_bounds__(256, 2) void als_cg_nm_kernel(const LongPlanDev plan, const int32_t *__restrict__ indices,
                                                            const float *__restrict__ data, T *__restrict__ X, const T *__restrict__ Y,
                                                            const float *__restrict__ gram_img, int cg_steps, float *__restrict__ partial,
@@ -526,7 +692,9 @@ __global__ __launch_bounds__(256, 2) void als_cg_nm_kernel(const LongPlanDev pla
     if (tid == 0) drawn = (int)gridDim.x + atomicAdd(ticket, 1);
     if (!(ko & 4)) {
       if (whole) {
-        const bool bad = nm_cg<F, T>(img, bvec, pv, parts, red, X + (size_t)plan.rows[li] * F, cg_steps, tid);
+        bool bad = false;
+        if constexpr (CHOL) bad = nm_chol<F>(img, bvec, pv, X + (size_t)plan.rows[li] * F, tid);  // (a separate instantiation: inlined
+        else bad = nm_cg<F, T>(img, bvec, pv, parts, red, X + (size_t)plan.rows[li] * F, cg_steps, tid);  // beside the CG it cost the CG kernel 9 spills)
         if (bad && tid == 0) fix_rows[atomicAdd(ticket + 2, 1)] = (unsigned)plan.rows[li];
       } else {
         float *out = partial + (size_t)s * (L::IMG + F);
@@ -577,7 +745,7 @@ __global__ __launch_bounds__(256) void als_cg_nm_reduce_kernel(const LongPlanDev
 }
 
 // step 2: the CG of those rows on the summed image
-template <int F, typename T>
+template <int F, typename T, bool CHOL = false>
 __global__ __launch_bounds__(256) void als_cg_nm_finish_kernel(const LongPlanDev plan, int n_multi, T *__restrict__ X, int cg_steps,
                                                                const float *__restrict__ partial, int *__restrict__ ctl,
                                                                unsigned *__restrict__ fix_rows) {
@@ -591,8 +759,45 @@ __global__ __launch_bounds__(256) void als_cg_nm_finish_kernel(const LongPlanDev
     for (int e = tid; e < L::IMG / 4; e += 256) reinterpret_cast<float4 *>(img)[e] = reinterpret_cast<const float4 *>(in)[e];
     if (tid < F) bvec[tid] = in[L::IMG + tid];
     __syncthreads();
-    const bool bad = nm_cg<F, T>(img, bvec, pv, parts, red, X + (size_t)plan.rows[li] * F, cg_steps, tid);
+    bool bad = false;
+    if constexpr (CHOL) bad = nm_chol<F>(img, bvec, pv, X + (size_t)plan.rows[li] * F, tid);
+    else bad = nm_cg<F, T>(img, bvec, pv, parts, red, X + (size_t)plan.rows[li] * F, cg_steps, tid);
     if (bad && tid == 0) fix_rows[atomicAdd(ctl + 2, 1)] = (unsigned)plan.rows[li];
+  }
+}
+
+// Cholesky, rows of the classes below the long one (1 .. 512 nonzeros): one workgroup per row at a time, rows handed out by a
+// ticket (ctl[3]) in schedule order -- the row's normal matrix on the matrix cores (nm_build, the gramian with reg on its diagonal
+// added on the way), the factorisation on the LDS image.
+template <int F>
+__global__ __launch_bounds__(256, 2) void als_chol_nm_rows_kernel(const int32_t *__restrict__ order, int first, int count,
+                                                                  const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                                  const float *__restrict__ data, float *__restrict__ X,
+                                                                  const float *__restrict__ Y, const float *__restrict__ gram_img,
+                                                                  int *__restrict__ ctl, unsigned *__restrict__ fix_rows) {
+  using L = NmLayout<F>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ int next_item;
+  float *img = smem, *bvec = img + L::kVec, *pv = bvec + F;
+  const int tid = threadIdx.x;
+  const int scale_k = __builtin_amdgcn_readfirstlane(ctl[1]);
+  for (int i = blockIdx.x; i < count;) {
+    const int u = order[first + i];
+    const int begin = indptr[u], end = indptr[u + 1];
+    __syncthreads();  // the previous row's solve has read the factor and z
+    nm_build<F, float>(indices, data, Y, gram_img, true, begin, end, smem, bvec, tid, 0, scale_k);
+    if (tid < F) {
+      const float *bstage = bvec + 2 * F + L::NP * F + 64;
+      bvec[tid] = (bstage[tid] + bstage[F + tid]) + (bstage[2 * F + tid] + bstage[3 * F + tid]);
+    }
+    __syncthreads();
+    int drawn = 0;
+    if (tid == 0) drawn = (int)gridDim.x + atomicAdd(ctl + 3, 1);
+    const bool bad = nm_chol<F>(img, bvec, pv, X + (size_t)u * F, tid);
+    if (bad && tid == 0) fix_rows[atomicAdd(ctl + 2, 1)] = (unsigned)u;
+    if (tid == 0) next_item = drawn;
+    __syncthreads();
+    i = next_item;
   }
 }
 
@@ -640,6 +845,57 @@ template <int F, typename T> void launch_nm(const imp_csr *C, T *X, const T *Y, 
 bool nm_enabled() {
   static const bool on = !(getenv("IMP_NM") && atoi(getenv("IMP_NM")) == 0);
   return on;
+}
+
+// Cholesky half sweep at f = 128 (round 5): every non-empty row's normal matrix on the matrix cores, factorised on its LDS image
+// (nm_chol).  Queues: the gramian image (reg on the diagonal), the long rows through the segment plan of the CG path (partial
+// images, their sum, the finishing kernel in Cholesky mode), every other row through als_chol_nm_rows_kernel.  Rows whose pivots
+// are not positive and finite are NOT stored: they are listed (count / rows on the device) for the caller's fp32 kernel.
+CholNmList least_squares_cholesky_nm(const imp_csr *C, float *X, const float *Y, size_t y_rows, const float *YtY, float reg) {
+  constexpr int F = 128;
+  using L = NmLayout<F>;
+  const LongPlan &lp = C->plan_nm;
+  const int32_t *b = C->bin_start;
+  const size_t lds = (L::lds_floats + 128) * sizeof(float);  // + the factorisation's panel and diagonal-block buffers
+  const int n_multi = C->nm_multi_rows, n_multi_seg = C->nm_multi_segs;
+  auto &ws = ctx().long_ws;
+  const size_t need = (size_t)L::IMG + (size_t)n_multi_seg * (L::IMG + F);
+  if (ws.size < need) ws.alloc(need);
+  float *gram_img = ws.data(), *partial = gram_img + L::IMG;
+  auto &tk = ctx().nm_ticket;  // [0] segment ticket, [1] operand scale, [2] rows left to the caller, [3] row ticket
+  if (tk.size < 4) tk.alloc(4, true);
+  auto &fix = ctx().nm_fix_rows;
+  const int capacity = C->nonempty();
+  if (fix.size < (size_t)std::max(capacity, 1)) fix.alloc((size_t)std::max(capacity, 1));
+  static const int forced_k = getenv("IMP_NM_SCALE") ? atoi(getenv("IMP_NM_SCALE")) : -1;
+  {
+    IMP_PROF("als_cholesky_nm_long");
+    nm_gram_image_kernel<F><<<(L::IMG + 255) / 256, 256, 0, stream()>>>(YtY, gram_img, tk.data(), (float)y_rows, std::min(forced_k, 16), reg);
+    if (lp.n_seg > 0) {
+      LongPlanDev plan = lp.dev(C->order.data());
+      auto kern = als_cg_nm_kernel<F, float, true>;
+      auto fin = als_cg_nm_finish_kernel<F, float, true>;
+      IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      kern<<<std::min(lp.n_seg, ctx().num_cus * 2), 256, lds, stream()>>>(plan, C->indices.data(), C->data.data(), X, Y, gram_img, -1, partial,
+                                                                          tk.data(), fix.data(), 0);
+      if (n_multi > 0) {
+        als_cg_nm_reduce_kernel<F><<<std::min(n_multi * 16, ctx().num_cus * 16), 256, 0, stream()>>>(plan, n_multi, gram_img, partial);
+        fin<<<std::min(n_multi, ctx().num_cus * 2), 256, lds, stream()>>>(plan, n_multi, X, -1, partial, tk.data(), fix.data());
+      }
+    }
+    IMP_CHECK_HIP(hipGetLastError());
+  }
+  const int count = b[7] - b[1];
+  if (count > 0) {
+    IMP_PROF("als_cholesky_nm_rows");
+    auto rk = als_chol_nm_rows_kernel<F>;
+    IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    rk<<<std::min(count, ctx().num_cus * 2), 256, lds, stream()>>>(C->order.data(), b[1], count, C->indptr.data(), C->indices.data(),
+                                                                    C->data.data(), X, Y, gram_img, tk.data(), fix.data());
+    IMP_CHECK_HIP(hipGetLastError());
+  }
+  return CholNmList{reinterpret_cast<const unsigned *>(tk.data() + 2), fix.data(), capacity};
 }
 
 template <typename T> void least_squares_cg_nm(const imp_csr *C, T *X, const T *Y, size_t y_rows, const float *A0, int f, int cg_steps) {

@@ -156,7 +156,9 @@ __global__ __launch_bounds__(256) void als_cholesky_blocked_kernel(const int32_t
                                                                    const float *__restrict__ data, float *__restrict__ X,
                                                                    const float *__restrict__ Y, const float *__restrict__ YtY,
                                                                    int f, float reg, int lda, unsigned long long *failed_row,
-                                                                   int ko) {  // ko: timing-only knock-out mask (IMP_CHOL_KO), 0 in production
+                                                                   int ko,  // ko: timing-only knock-out mask (IMP_CHOL_KO), 0 in production
+                                                                   const unsigned *__restrict__ dev_count = nullptr) {  // rows of `order` to take, if fewer than `count`
+  if (dev_count) count = min(count, (int)*dev_count);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int m = f + 1;                         // rows of the augmented triangle (row f = b^T -> z^T), f columns
   const int nbr = (m + 3) >> 2, nbc = (f + 3) >> 2;  // 4 x 4 blocks
@@ -908,6 +910,13 @@ int64_t least_squares_cholesky(const imp_csr *C, imp_matrix *X, const imp_matrix
     sync();
     return failed_m == ~0ULL ? -1 : (int64_t)failed_m;
   }
+  // f = 128 (round 5): the rows' normal matrices on the matrix cores, factorised on their LDS images (als_cg_nm.hip); the
+  // workgroup kernel below then only takes the rows that path listed (non-positive or non-finite pivots: normally none).
+  // IMP_CHOL_NM=0: every row on the workgroup kernel (A/B, parity)
+  static const bool chol_nm = !(getenv("IMP_CHOL_NM") && atoi(getenv("IMP_CHOL_NM")) == 0);
+  CholNmList nm_list{nullptr, nullptr, 0};
+  const bool use_nm = f == 128 && chol_nm && nonempty > 0;
+  if (use_nm) nm_list = least_squares_cholesky_nm(C, X->f32(), Y->f32(), Y->rows, YtY->f32(), (float)reg);
   // other f <= 64: rows up to 256 nnz go to the register-resident wave kernel; longer rows (and any larger f) to the
   // workgroup kernel, whose 256 threads share the A-build of one row
   const int n_block = (f <= 64 && !no_wave) ? C->bin_start[2] : nonempty;
@@ -927,7 +936,7 @@ int64_t least_squares_cholesky(const imp_csr *C, imp_matrix *X, const imp_matrix
   }
   if (n_block > 0) {
     // IMP_CHOL_UNBLOCKED=1: the round-1 column-by-column kernel (A/B, parity)
-    static const bool unblocked = getenv("IMP_CHOL_UNBLOCKED") != nullptr;
+    static const bool unblocked = getenv("IMP_CHOL_UNBLOCKED") != nullptr && !use_nm;
     if (!unblocked) {
       const int m = f + 1, nbr = (m + 3) / 4, nbc = (f + 3) / 4;
       const size_t a_words = packed ? (size_t)m * (m + 1) / 2 : (size_t)m * lda;
@@ -945,8 +954,13 @@ int64_t least_squares_cholesky(const imp_csr *C, imp_matrix *X, const imp_matrix
       static const int ko = getenv("IMP_CHOL_KO") ? atoi(getenv("IMP_CHOL_KO")) : 0;  // timing-only knock-outs of the phases
       auto kern = packed ? als_cholesky_blocked_kernel<true> : als_cholesky_blocked_kernel<false>;
       IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      kern<<<grid, 256, lds, stream()>>>(C->order.data(), 0, n_block, C->indptr.data(), C->indices.data(), C->data.data(), X->f32(),
-                                         Y->f32(), YtY->f32(), f, (float)reg, lda, g_failed, ko);
+      if (use_nm)  // the listed rows only (the list stands in for the schedule; a zero count makes every workgroup return at once)
+        kern<<<std::min(nm_list.capacity, ctx().num_cus * per_cu), 256, lds, stream()>>>(
+            reinterpret_cast<const int32_t *>(nm_list.rows), 0, nm_list.capacity, C->indptr.data(), C->indices.data(), C->data.data(),
+            X->f32(), Y->f32(), YtY->f32(), f, (float)reg, lda, g_failed, ko, nm_list.count);
+      else
+        kern<<<grid, 256, lds, stream()>>>(C->order.data(), 0, n_block, C->indptr.data(), C->indices.data(), C->data.data(), X->f32(),
+                                           Y->f32(), YtY->f32(), f, (float)reg, lda, g_failed, ko, nullptr);
     }
     IMP_CHECK_HIP(hipGetLastError());
   }

@@ -309,6 +309,13 @@ struct imp_coo {
 };
 
 namespace imp {
+// als_cg_nm.hip: Cholesky half sweep at f = 128 through the rows' normal matrices on the matrix cores; what it could not factorise
+// comes back as a device-side list for the workgroup-per-row fp32 kernel (als_cholesky.hip)
+struct CholNmList {
+  const unsigned *count, *rows;
+  int capacity;
+};
+CholNmList least_squares_cholesky_nm(const imp_csr *C, float *X, const float *Y, size_t y_rows, const float *YtY, float reg);
 // als_cg_cluster.hip: the fp32 one-wavefront-per-row solver for the rows listed in rows[0 .. *count) (F = 64 / 128, float / __half)
 template <int F, typename T>
 void launch_cg_fixup(const unsigned *count, const unsigned *rows, int capacity, const imp_csr *C, T *X, const T *Y, const float *A0,
