@@ -152,7 +152,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // stop being finite, and nm_cg hands the row to the fp32 fix-up kernel instead of storing it.
 //
 // Returns with the image complete in the LDS (gramian added when `whole`), behind a barrier.
-template <int F, typename T>
+template <int F, typename T, bool TRIM = false>  // TRIM: the last round multiplies only the steps that hold nonzeros (short rows)
 __device__ __forceinline__ void nm_build(const int32_t *__restrict__ indices, const float *__restrict__ data, const T *__restrict__ Y,
                                          const float *__restrict__ gram_img, bool whole, int begin, int end, float *smem, float *bvec,
                                          int tid, int ko, int scale_k) {
@@ -384,7 +384,8 @@ __device__ __forceinline__ void nm_build(const int32_t *__restrict__ indices, co
   for (int r = 0; r < n_rounds; ++r) {
     produce(r, yb);
     lds_barrier();
-    consume(0, 4);  // (raising the wave priority here changes nothing: 0.556 against 0.560 ms)
+    if constexpr (TRIM) consume(0, min(4, (end - begin - r * L::ROUND + L::KCH - 1) / L::KCH));  // a row of 20 nonzeros has one step
+    else consume(0, 4);  // (raising the wave priority here changes nothing: 0.556 against 0.560 ms)
     lds_barrier();  // the exchange buffer is free again (and, after the last round, free for the image)
   }
   // b: lane (a, g) holds its nonzeros' share of factors 4a .. 4a+3 = positions c M + a
@@ -495,6 +496,23 @@ __device__ __forceinline__ bool nm_cg(const float *img, const float *bvec, float
   return false;
 }
 
+#ifdef CHOL_NM_STATS  // timing-only build: shader-clock cycles per phase of als_chol_nm_rows_kernel, wave 0 lane 0 of every workgroup
+__device__ unsigned long long g_chol_nm_stats[8];  // [0] build [1] block load [2] factorisation [3] L store [4] back substitution [5] rows
+#define CHOL_TICK(slot)                                                          \
+  do {                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                           \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();                \
+    if (threadIdx.x == 0) atomicAdd(&g_chol_nm_stats[slot], now_ - chol_t_last); \
+    chol_t_last = now_;                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                           \
+  } while (0)
+__device__ unsigned long long chol_t_last_dummy;
+#else
+#define CHOL_TICK(slot) ((void)0)
+#endif
+struct NoGram {  // nm_chol's gramian argument when the image already carries the gramian
+  __device__ __forceinline__ float operator()(int, int, int, int) const { return 0.f; }
+};
 // ---- Cholesky on the LDS image (round 5): x = A_u^-1 b, what the CPU reference's posv does per row (_als.pyx:75-142) ---------------
 // f = 128, 256 threads.  The image's 4 x 4 interleaving makes position (m, n) of its sixteen tiles the 4 x 4 block
 // A[4m .. 4m+3][4n .. 4n+3]: the 528 blocks of the lower triangle are dealt to the threads (at most three each) and stay in
@@ -508,9 +526,12 @@ __device__ __forceinline__ bool nm_cg(const float *img, const float *bvec, float
 // the LDS row-major (the image's space: F (F + 4) floats exactly) and x = L^-T z is a blocked back substitution, one barrier per
 // block.  Returns true -- and stores nothing -- when a pivot is not positive (or not finite): the caller lists the row for the
 // workgroup-per-row fp32 kernel, which then decides whether it is a failure (_als.pyx:136-138).
-template <int F>
-__device__ __forceinline__ bool nm_chol(float *img, float *bvec, float *scr, float *xrow, int tid) {
+template <int F, typename GB>
+__device__ __forceinline__ bool nm_chol(float *img, float *bvec, float *scr, float *xrow, int tid, const GB &gblocks) {
   static_assert(F == 128, "block ownership and the LDS budget are laid out for f = 128");
+#ifdef CHOL_NM_STATS
+  unsigned long long chol_t_last = __builtin_amdgcn_s_memtime();
+#endif
   using L = NmLayout<F>;
   constexpr int NB = F / 4, NBLK = NB * (NB + 1) / 2, LDL = F + 4, SL = (NBLK + 255) / 256;
   static_assert(F * LDL <= L::kVec, "the row-major factor re-uses the image's space");
@@ -530,7 +551,7 @@ __device__ __forceinline__ bool nm_chol(float *img, float *bvec, float *scr, flo
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) B[s][a][c] = img[L::at(a, c, bm[s], bn[s])];
+        for (int c = 0; c < 4; ++c) B[s][a][c] = img[L::at(a, c, bm[s], bn[s])] + gblocks(a, c, bm[s], bn[s]);
     }
   }
   float rb[4] = {0.f, 0.f, 0.f, 0.f};  // b[4 tid ..] (the image's vectors are stored position I M + m = factor 4 m + I)
@@ -539,6 +560,7 @@ __device__ __forceinline__ bool nm_chol(float *img, float *bvec, float *scr, flo
     for (int c = 0; c < 4; ++c) rb[c] = bvec[c * L::M + tid];
   }
   __syncthreads();  // the image and b have been read: their space is free
+  CHOL_TICK(1);
   if (tid == 0) {
 #pragma unroll
     for (int a = 0; a < 4; ++a) *reinterpret_cast<float4 *>(dblk + 4 * a) = make_float4(B[0][a][0], B[0][a][1], B[0][a][2], B[0][a][3]);
@@ -556,13 +578,13 @@ __device__ __forceinline__ bool nm_chol(float *img, float *bvec, float *scr, flo
       return r * fmaf(-0.5f * d * r, r, 1.5f);
     };
     // 4 x 4 Cholesky of the diagonal block, by every thread alike
-    const float p0 = d0.x, r0 = rsq(p0), l00 = p0 * r0;
+    const float p0 = d0.x, r0 = rsq(p0);
     const float l10 = d1.x * r0, l20 = d2.x * r0, l30 = d3.x * r0;
-    const float p1 = fmaf(-l10, l10, d1.y), r1 = rsq(p1), l11 = p1 * r1;
+    const float p1 = fmaf(-l10, l10, d1.y), r1 = rsq(p1);
     const float l21 = fmaf(-l20, l10, d2.y) * r1, l31 = fmaf(-l30, l10, d3.y) * r1;
-    const float p2 = fmaf(-l21, l21, fmaf(-l20, l20, d2.z)), r2 = rsq(p2), l22 = p2 * r2;
+    const float p2 = fmaf(-l21, l21, fmaf(-l20, l20, d2.z)), r2 = rsq(p2);
     const float l32 = fmaf(-l31, l21, fmaf(-l30, l20, d3.z)) * r2;
-    const float p3 = fmaf(-l32, l32, fmaf(-l31, l31, fmaf(-l30, l30, d3.w))), r3 = rsq(p3), l33 = p3 * r3;
+    const float p3 = fmaf(-l32, l32, fmaf(-l31, l31, fmaf(-l30, l30, d3.w))), r3 = rsq(p3);
     if (!(p0 > 0.f && p1 > 0.f && p2 > 0.f && p3 > 0.f && p3 < 3.0e38f)) {  // uniform: every thread holds the same values
       fail = true;
       break;
@@ -583,9 +605,10 @@ __device__ __forceinline__ bool nm_chol(float *img, float *bvec, float *scr, flo
             solve_row(B[s][a]);
             *reinterpret_cast<float4 *>(P + (size_t)(4 * bm[s] + a) * 4) = make_float4(B[s][a][0], B[s][a][1], B[s][a][2], B[s][a][3]);
           }
-        } else {  // the diagonal block itself: its factor
-          B[s][0][0] = l00, B[s][1][0] = l10, B[s][1][1] = l11, B[s][2][0] = l20, B[s][2][1] = l21, B[s][2][2] = l22;
-          B[s][3][0] = l30, B[s][3][1] = l31, B[s][3][2] = l32, B[s][3][3] = l33;
+        } else {  // the diagonal block itself: its factor, with the RECIPROCALS of the pivots' roots on the diagonal (what the
+                  // back substitution multiplies by)
+          B[s][0][0] = r0, B[s][1][0] = l10, B[s][1][1] = r1, B[s][2][0] = l20, B[s][2][1] = l21, B[s][2][2] = r2;
+          B[s][3][0] = l30, B[s][3][1] = l31, B[s][3][2] = l32, B[s][3][3] = r3;
         }
       }
     }
@@ -598,6 +621,8 @@ __device__ __forceinline__ bool nm_chol(float *img, float *bvec, float *scr, flo
 #pragma unroll
     for (int s = 0; s < SL; ++s) {
       if (bn[s] > kb) {  // (bm >= bn > kb)
+        // (a transposed second copy of the panel and 32 v_pk_fma_f32 per block instead of 64 FMAs was measured slower: 117 K
+        // against 99 K cycles per row for the factorisation)
         float4 pm[4], pn[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
@@ -625,6 +650,7 @@ __device__ __forceinline__ bool nm_chol(float *img, float *bvec, float *scr, flo
     }
     __syncthreads();
   }
+  CHOL_TICK(2);
   if (fail) return true;
   // L, row-major, into the image's space (the lower triangle; nothing above the diagonal is read)
 #pragma unroll
@@ -636,6 +662,7 @@ __device__ __forceinline__ bool nm_chol(float *img, float *bvec, float *scr, flo
     }
   }
   __syncthreads();
+  CHOL_TICK(3);
   // x = L^-T z, four unknowns per turn from the bottom: every thread solves the 4 x 4 block alike, thread i < 4 kb takes the
   // solved unknowns out of z[i]
   float *xs = pan;
@@ -645,10 +672,10 @@ __device__ __forceinline__ bool nm_chol(float *img, float *bvec, float *scr, flo
     const float4 q0 = *reinterpret_cast<const float4 *>(row), q1 = *reinterpret_cast<const float4 *>(row + LDL),
                  q2 = *reinterpret_cast<const float4 *>(row + 2 * LDL), q3 = *reinterpret_cast<const float4 *>(row + 3 * LDL);
     const float4 z = *reinterpret_cast<const float4 *>(bvec + 4 * kb);
-    const float x3 = z.w / q3.w;
-    const float x2 = fmaf(-q3.z, x3, z.z) / q2.z;
-    const float x1 = fmaf(-q3.y, x3, fmaf(-q2.y, x2, z.y)) / q1.y;
-    const float x0 = fmaf(-q3.x, x3, fmaf(-q2.x, x2, fmaf(-q1.x, x1, z.x))) / q0.x;
+    const float x3 = z.w * q3.w;  // (the diagonal holds 1 / L[i][i])
+    const float x2 = fmaf(-q3.z, x3, z.z) * q2.z;
+    const float x1 = fmaf(-q3.y, x3, fmaf(-q2.y, x2, z.y)) * q1.y;
+    const float x0 = fmaf(-q3.x, x3, fmaf(-q2.x, x2, fmaf(-q1.x, x1, z.x))) * q0.x;
     if (tid < 4 * kb) {  // (elements below 4 kb: nobody reads them in this turn)
       const float *col = img + (size_t)(4 * kb) * LDL + tid;
       bvec[tid] = fmaf(-col[3 * LDL], x3, fmaf(-col[2 * LDL], x2, fmaf(-col[LDL], x1, fmaf(-col[0], x0, bvec[tid]))));
@@ -656,6 +683,7 @@ __device__ __forceinline__ bool nm_chol(float *img, float *bvec, float *scr, flo
     if (tid == 0) *reinterpret_cast<float4 *>(xs + 4 * kb) = make_float4(x0, x1, x2, x3);
     __syncthreads();
   }
+  CHOL_TICK(4);
   if (tid < F) xrow[tid] = xs[tid];
   return false;
 }
@@ -693,7 +721,7 @@ __global__ __launch_bounds__(256, 2) void als_cg_nm_kernel(const LongPlanDev pla
     if (!(ko & 4)) {
       if (whole) {
         bool bad = false;
-        if constexpr (CHOL) bad = nm_chol<F>(img, bvec, pv, X + (size_t)plan.rows[li] * F, tid);  // (a separate instantiation: inlined
+        if constexpr (CHOL) bad = nm_chol<F>(img, bvec, pv, X + (size_t)plan.rows[li] * F, tid, NoGram{});  // (a separate instantiation: inlined
         else bad = nm_cg<F, T>(img, bvec, pv, parts, red, X + (size_t)plan.rows[li] * F, cg_steps, tid);  // beside the CG it cost the CG kernel 9 spills)
         if (bad && tid == 0) fix_rows[atomicAdd(ticket + 2, 1)] = (unsigned)plan.rows[li];
       } else {
@@ -760,7 +788,7 @@ __global__ __launch_bounds__(256) void als_cg_nm_finish_kernel(const LongPlanDev
     if (tid < F) bvec[tid] = in[L::IMG + tid];
     __syncthreads();
     bool bad = false;
-    if constexpr (CHOL) bad = nm_chol<F>(img, bvec, pv, X + (size_t)plan.rows[li] * F, tid);
+    if constexpr (CHOL) bad = nm_chol<F>(img, bvec, pv, X + (size_t)plan.rows[li] * F, tid, NoGram{});
     else bad = nm_cg<F, T>(img, bvec, pv, parts, red, X + (size_t)plan.rows[li] * F, cg_steps, tid);
     if (bad && tid == 0) fix_rows[atomicAdd(ctl + 2, 1)] = (unsigned)plan.rows[li];
   }
@@ -781,19 +809,33 @@ __global__ __launch_bounds__(256, 2) void als_chol_nm_rows_kernel(const int32_t 
   float *img = smem, *bvec = img + L::kVec, *pv = bvec + F;
   const int tid = threadIdx.x;
   const int scale_k = __builtin_amdgcn_readfirstlane(ctl[1]);
+  // The image is built WITHOUT the gramian (nm_build's own addition reads it tile slot by tile slot: three dependent L2 round trips
+  // per row); nm_chol adds this thread's blocks of it where it takes its blocks out of the image -- 48 loads in flight at once.
+  // (Keeping the blocks in registers for the whole launch does not fit beside nm_build's 250 registers: 132 spilled.)
+  struct GramBlocks {
+    const float *img;
+    __device__ __forceinline__ float operator()(int a, int c, int m, int n) const { return img[L::at(a, c, m, n)]; }
+  } gb{gram_img};
   for (int i = blockIdx.x; i < count;) {
     const int u = order[first + i];
     const int begin = indptr[u], end = indptr[u + 1];
     __syncthreads();  // the previous row's solve has read the factor and z
-    nm_build<F, float>(indices, data, Y, gram_img, true, begin, end, smem, bvec, tid, 0, scale_k);
+#ifdef CHOL_NM_STATS
+    unsigned long long chol_t_last = __builtin_amdgcn_s_memtime();
+#endif
+    nm_build<F, float, true>(indices, data, Y, gram_img, false, begin, end, smem, bvec, tid, 0, scale_k);
     if (tid < F) {
       const float *bstage = bvec + 2 * F + L::NP * F + 64;
       bvec[tid] = (bstage[tid] + bstage[F + tid]) + (bstage[2 * F + tid] + bstage[3 * F + tid]);
     }
     __syncthreads();
+    CHOL_TICK(0);
+#ifdef CHOL_NM_STATS
+    if (tid == 0) atomicAdd(&g_chol_nm_stats[5], 1ull);
+#endif
     int drawn = 0;
     if (tid == 0) drawn = (int)gridDim.x + atomicAdd(ctl + 3, 1);
-    const bool bad = nm_chol<F>(img, bvec, pv, X + (size_t)u * F, tid);
+    const bool bad = nm_chol<F>(img, bvec, pv, X + (size_t)u * F, tid, gb);
     if (bad && tid == 0) fix_rows[atomicAdd(ctl + 2, 1)] = (unsigned)u;
     if (tid == 0) next_item = drawn;
     __syncthreads();
@@ -894,6 +936,17 @@ CholNmList least_squares_cholesky_nm(const imp_csr *C, float *X, const float *Y,
     rk<<<std::min(count, ctx().num_cus * 2), 256, lds, stream()>>>(C->order.data(), b[1], count, C->indptr.data(), C->indices.data(),
                                                                     C->data.data(), X, Y, gram_img, tk.data(), fix.data());
     IMP_CHECK_HIP(hipGetLastError());
+#ifdef CHOL_NM_STATS
+    {
+      unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      IMP_CHECK_HIP(hipStreamSynchronize(stream()));
+      IMP_CHECK_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_chol_nm_stats), sizeof(h)));
+      IMP_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_chol_nm_stats), z, sizeof(z)));
+      const double n = (double)std::max<unsigned long long>(1, h[5]);
+      fprintf(stderr, "[chol-nm-stats] rows=%llu cycles per row: build %.0f  block load %.0f  factorisation %.0f  L store %.0f  back substitution %.0f\n",
+              h[5], h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n);
+    }
+#endif
   }
   return CholNmList{reinterpret_cast<const unsigned *>(tk.data() + 2), fix.data(), capacity};
 }
