@@ -564,7 +564,8 @@ def extra_factor_grid(gpu, Cui, Ciu):
 
 def extra_cholesky_f128(gpu, Cui, Ciu):
     """The Cholesky solver at the factor count the metric is quoted on (`use_cg=False`, implicit/cpu/als.py:418-423) on the
-    configs[2] matrix: f = 128 has no register / MFMA kernel (only f = 64 does), it runs the workgroup-per-row LDS kernel."""
+    configs[2] matrix: since round 5 the rows' normal matrices are built on the matrix cores and factorised on their LDS images
+    (als_cg_nm.hip nm_chol; IMP_CHOL_NM=0: the workgroup-per-row LDS kernel of round 4)."""
     f = FACTORS
     rng = np.random.default_rng(7)
     X = gpu.Matrix(rng.random((Cui.shape[0], f), dtype=np.float32) * 0.01)
@@ -582,7 +583,7 @@ def extra_cholesky_f128(gpu, Cui, Ciu):
     t, kernels = _time_iterations(gpu, chol, iters=2)
     rows = Cui.shape[0] + Cui.shape[1]
     flops = 2.0 * Cui.nnz * 2 * f * f + rows * (f ** 3 / 3.0 + 2.0 * f * f)
-    return {"cholesky_c3_f128": {"workload": "configs[2] matrix, f=128, Cholesky (LDS workgroup-per-row kernel)", "ms_per_iter": 1e3 * t,
+    return {"cholesky_c3_f128": {"workload": "configs[2] matrix, f=128, Cholesky (normal matrices on the matrix cores, LDS-image factorisation)", "ms_per_iter": 1e3 * t,
                                  "updates_per_s": rows / t, "tflops": flops / t / 1e12,
                                  "roofline": {"bound": "fp32", "achieved": flops / t / 1e12, "peak": FP32_PEAK_TFLOPS,
                                               "unit": "TFLOP/s", "frac": flops / t / 1e12 / FP32_PEAK_TFLOPS},

@@ -544,10 +544,14 @@ __device__ __forceinline__ bool nm_chol(float *img, float *bvec, float *scr, flo
     const int bid = tid + 256 * s;
     bm[s] = bn[s] = -1;
     if (bid < NBLK) {
-      int m = (int)((sqrtf(8.f * (float)bid + 1.f) - 1.f) * 0.5f);
-      while (m * (m + 1) / 2 > bid) --m;
-      while ((m + 1) * (m + 2) / 2 <= bid) ++m;
-      bm[s] = m, bn[s] = bid - m * (m + 1) / 2;
+      // Blocks are numbered by block COLUMN from the right (column NB-1 first), top to bottom inside a column: the blocks still to
+      // be updated at turn kb (columns > kb) are then a PREFIX of the numbering, i.e. the first slot of the first threads -- a
+      // wavefront runs ceil(active / 256) passes of the update per turn instead of one per slot it holds a live block in (row by
+      // row, most turns cost every wavefront two passes).
+      int t = (int)((sqrtf(8.f * (float)bid + 1.f) - 1.f) * 0.5f);
+      while (t * (t + 1) / 2 > bid) --t;
+      while ((t + 1) * (t + 2) / 2 <= bid) ++t;
+      bn[s] = NB - 1 - t, bm[s] = bn[s] + (bid - t * (t + 1) / 2);
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -561,9 +565,12 @@ __device__ __forceinline__ bool nm_chol(float *img, float *bvec, float *scr, flo
   }
   __syncthreads();  // the image and b have been read: their space is free
   CHOL_TICK(1);
-  if (tid == 0) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a) *reinterpret_cast<float4 *>(dblk + 4 * a) = make_float4(B[0][a][0], B[0][a][1], B[0][a][2], B[0][a][3]);
+  for (int s = 0; s < SL; ++s) {
+    if (bm[s] == 0 && bn[s] == 0) {  // the first diagonal block's owner
+#pragma unroll
+      for (int a = 0; a < 4; ++a) *reinterpret_cast<float4 *>(dblk + 4 * a) = make_float4(B[s][a][0], B[s][a][1], B[s][a][2], B[s][a][3]);
+    }
   }
   __syncthreads();
   bool fail = false;
