@@ -820,15 +820,20 @@ def bench_topk(gpu, Cui, X, Y, k=10, queries=20_000, batch=1000):
     if gemm_ms > 0:
         tf = per_batch_flops / (gemm_ms * 1e-3) / 1e12
         split = os.environ.get("IMP_TOPK_FP32_MFMA") is None and Y.shape[1] % 16 == 0
-        peak = BF16_PEAK_TFLOPS / 6.0 if split else FP32_PEAK_TFLOPS
+        six = os.environ.get("IMP_TOPK_BF16X3") is not None   # the round-3 form: three bf16 terms, six products
+        peak = (BF16_PEAK_TFLOPS / (6.0 if six else 3.0)) if split else FP32_PEAK_TFLOPS
         roofline = {"bound": "mfma", "kernel": "score_gemm_direct_kernel<2> (emit epilogue)", "achieved": tf, "peak": peak,
                     "unit": "TFLOP/s", "frac": tf / peak, "avg_launch_ms": gemm_ms,
                     "flops_per_launch": per_batch_flops, "traffic": _pmc_kernel_traffic("score_gemm_direct_kernel<2"),
                     "traffic_note": "HBM bytes per launch of the emit GEMM from the committed rocprofv3 PMC summary "
                                     "(FETCH_SIZE corrected for gfx950); algorithmic operand bytes = items x f x 4 once per launch",
-                    "note": ("fp32-equivalent flops (2 x batch x items x f per launch); the product runs as 6 bf16 partial products "
-                             "of three-way split operands on v_mfma_f32_32x32x16_bf16 (fp32 accumulation, error below an fp32 FMA "
-                             "chain's): peak = 2500 TFLOP/s dense bf16 / 6") if split else
+                    "note": (("fp32-equivalent flops (2 x batch x items x f per launch); the product runs as 6 bf16 partial products "
+                              "of three-way split operands on v_mfma_f32_32x32x16_bf16 (fp32 accumulation, error below an fp32 FMA "
+                              "chain's): peak = 2500 TFLOP/s dense bf16 / 6") if six else
+                             ("fp32-equivalent flops (2 x batch x items x f per launch); the product runs as 3 fp16 partial products "
+                              "(l h, h l, h h) of two-way split operands, scaled per call by a power of two, on "
+                              "v_mfma_f32_32x32x16_f16 with fp32 accumulation (operands to 2^-22; overflowing rows re-scored by the "
+                              "six-product bf16 form): peak = 2500 TFLOP/s dense fp16 / 3")) if split else
                             "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32); 2 x batch x items x f flops per launch"}
     # the model-level call a user makes (recommend(): host COO build of the liked items + upload + KnnQuery.topk per batch)
     rec = None

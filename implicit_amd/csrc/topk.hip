@@ -280,6 +280,7 @@ struct EmitArgs {
   uint64_t *cand;             // [nq][cap]
   unsigned int *count;        // [nq]
   int cap;
+  const unsigned *maxbits;    // fp16 form only: bits of the largest query / sampled item magnitude (topk_absmax_kernel)
 };
 
 // TQ / TI: storage type of the query / item factors (float or __half).  fp16 factors are read as they are stored and
@@ -331,6 +332,124 @@ __global__ void split_query_rows_kernel(const T *__restrict__ Q, __bf16 *__restr
   }
 }
 
+// H2 (round 5; fp32 factors on the emit path, default): two fp16 terms per operand value instead of three bf16 terms, THREE partial
+// products (l h, h l, h h; the dropped l l is 2^-22 of the product) instead of six on v_mfma_f32_32x32x16_f16 -- the matrix pipe's
+// share of the emit GEMM was 0.17 of its 0.42 ms and did not overlap the operand traffic.  fp16 has 5 exponent bits, so both
+// operands are scaled by a power of two per call (exact, taken out again in the epilogue): the queries by the batch's largest
+// magnitude, the items by the largest magnitude of every 16th row (a full pass over the items would cost 30 us of a 500 us call),
+// both brought to [2^11, 2^12) -- values down to 2^-14 of the largest keep 22 bits, smaller ones an ABSOLUTE error of 2^-25 of
+// the scaled unit.  An item value more than 16 x above the sampled maximum overflows fp16: its high half is an infinity, its
+// low half the opposite one, and every score it takes part in is a NaN (h h and h l are infinities of opposite sign, or 0 x
+// inf) -- the emit epilogue passes NaNs on as +inf candidates, the threshold pass stores them as +inf, and select_candidates
+// hands a row whose best candidate is not finite to the materialising path, which keeps the six-product form.
+// IMP_TOPK_BF16X3=1 keeps the six-product form everywhere (A/B, switch test).
+typedef _Float16 tk_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 tk_f16x2 __attribute__((ext_vector_type(2)));
+typedef float tk_f32x2 __attribute__((ext_vector_type(2)));
+struct split_f16 {
+  _Float16 v;
+};
+template <typename TQ> struct presplit {
+  static constexpr int terms = 0;
+};
+template <> struct presplit<split_bf16> {
+  static constexpr int terms = 3;
+};
+template <> struct presplit<split_f16> {
+  static constexpr int terms = 2;
+};
+// 2^k with k = 11 - exponent(largest magnitude), clamped to +-60 (an all-zero or non-finite operand: whatever comes out is
+// what the guard above catches)
+__device__ __forceinline__ int h2_scale_exp(unsigned maxbits) { return max(-60, min(60, 11 - ((int)(maxbits >> 23) - 127))); }
+__device__ __forceinline__ float h2_pow2(int k) { return __uint_as_float((unsigned)(k + 127) << 23); }
+__device__ __forceinline__ void split8_f16(const float4 &v0, const float4 &v1, float s, tk_f16x8 &h, tk_f16x8 &l) {
+  const tk_f32x2 x[4] = {{v0.x * s, v0.y * s}, {v0.z * s, v0.w * s}, {v1.x * s, v1.y * s}, {v1.z * s, v1.w * s}};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const tk_f16x2 hi = __builtin_convertvector(x[e], tk_f16x2);
+    const tk_f16x2 lo = __builtin_convertvector(x[e] - __builtin_convertvector(hi, tk_f32x2), tk_f16x2);
+    h[2 * e] = hi[0], h[2 * e + 1] = hi[1], l[2 * e] = lo[0], l[2 * e + 1] = lo[1];
+  }
+}
+// largest magnitudes: out[0] of the query values, out[1] of every 16th item row (as the bits of a non-negative float: unsigned
+// order is value order).  One launch, no reset: every workgroup leaves its pair in out[4 + 2 b ..], the last one to arrive at the
+// counter out[2] (zero at rest) folds them and puts the counter back (a memset + per-wavefront atomics cost 55 us of a 500 us call).
+constexpr int kAbsmaxBlocks = 256;
+template <typename TQ, typename TI>
+__global__ __launch_bounds__(256) void topk_absmax_kernel(const TQ *__restrict__ Q, size_t nq_vals, const TI *__restrict__ I, size_t ni, int f,
+                                                          unsigned *__restrict__ out) {
+  const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+  float mq = 0.f, mi = 0.f;
+  for (size_t i = tid; i < nq_vals; i += nth) mq = fmaxf(mq, fabsf((float)Q[i]));
+  // a sampled item row per wavefront and turn (a flat index cost a 64-bit division per value)
+  const int lane = threadIdx.x & 63;
+  const size_t nw = nth >> 6;
+  for (size_t r0 = (tid >> 6) * 16; r0 < ni; r0 += nw * 64) {  // four rows in flight: the loop is latency, not bandwidth
+    for (int c = lane; c < f; c += 64) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const size_t row = r0 + j * nw * 16;
+        v[j] = row < ni ? (float)I[row * (size_t)f + c] : 0.f;
+      }
+      mi = fmaxf(fmaxf(mi, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    mq = fmaxf(mq, __shfl_xor(mq, off, 64));
+    mi = fmaxf(mi, __shfl_xor(mi, off, 64));
+  }
+  __shared__ float red[2][4];
+  __shared__ bool last;
+  const int wave = threadIdx.x >> 6;
+  if (lane == 0) red[0][wave] = mq, red[1][wave] = mi;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mq = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    mi = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+    __hip_atomic_store(out + 4 + 2 * blockIdx.x, __float_as_uint(mq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(out + 5 + 2 * blockIdx.x, __float_as_uint(mi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = __hip_atomic_fetch_add(out + 2, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  unsigned bq = 0, bi = 0;
+  if (threadIdx.x < gridDim.x) {
+    bq = __hip_atomic_load(out + 4 + 2 * threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bi = __hip_atomic_load(out + 5 + 2 * threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    bq = max(bq, (unsigned)__shfl_xor((int)bq, off, 64));
+    bi = max(bi, (unsigned)__shfl_xor((int)bi, off, 64));
+  }
+  __shared__ unsigned redu[2][4];
+  if (lane == 0) redu[0][wave] = bq, redu[1][wave] = bi;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = max(max(redu[0][0], redu[0][1]), max(redu[0][2], redu[0][3]));
+    out[1] = max(max(redu[1][0], redu[1][1]), max(redu[1][2], redu[1][3]));
+    __hip_atomic_store(out + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+template <typename T>
+__global__ void split_query_rows_f16_kernel(const T *__restrict__ Q, _Float16 *__restrict__ out, size_t rows, size_t rows_pad, int f,
+                                            const unsigned *__restrict__ maxbits) {
+  const size_t n = rows_pad * (size_t)f;
+  const int steps16 = f / 16;
+  const float s = h2_pow2(h2_scale_exp(maxbits[0]));
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t q = i / f;
+    const int c = (int)(i - q * f);
+    const float x = q < rows ? (float)Q[i] * s : 0.f;
+    const _Float16 hi = (_Float16)x;
+    const int lane = (int)(q & 31) + 32 * ((c >> 3) & 1);
+    _Float16 *o = out + ((((q >> 5) * steps16 + (c >> 4)) * 2) * 64 + lane) * 8 + (c & 7);
+    o[0] = hi, o[64 * 8] = (_Float16)(x - (float)hi);
+  }
+}
+
 // four consecutive factors as they are stored, and their fp32 values
 template <typename T> struct raw4 {
   using type = float4;
@@ -360,8 +479,10 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
   const int r = lane & 31, kh = lane >> 5;
   const int q_base = blockIdx.y * 128 + 64 * (wave >> 1);
   const int i_base = (MODE == 1 ? blockIdx.x * block_stride : blockIdx.x) * 128 + 64 * (wave & 1);
-  constexpr bool QS = std::is_same<TQ, split_bf16>::value;  // query rows already split: [3][f] bf16 per row
-  static_assert(!QS || BF3, "split query rows feed the bf16 form only");
+  constexpr bool QS = presplit<TQ>::terms > 0;  // query rows already split, in fragment order: 3 bf16 or 2 fp16 terms per value
+  constexpr int NT = QS ? presplit<TQ>::terms : 3;
+  constexpr bool H2 = std::is_same<TQ, split_f16>::value;  // the fp16 form: items split here, scaled; three products
+  static_assert(!QS || BF3, "split query rows feed the matrix-core forms only");
   f32x16 acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -379,15 +500,15 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
     //  * factor ROWS (items; queries when they are not pre-split): 1 KB per DMA instruction = whole 64- / 32-byte row pieces
     //    (16 rows fp32, 32 rows fp16), the 16-byte chunks of a row XOR-swizzled -- on the SOURCE side, the DMA destination is
     //    lane-linear -- so that the 32 rows of a fragment read spread over all banks;
-    //  * pre-split queries: 12 fragment pieces of 1 KB (4 tiles x 3 terms), lane-linear as stored.
-    // The 8 (4) + 12 instructions of a step are dealt to the four waves; double buffer, one barrier per step: a wave requests
+    //  * pre-split queries: 12 (8) fragment pieces of 1 KB (4 tiles x 3 bf16 / 2 fp16 terms), lane-linear as stored.
+    // The 8 (4) + 12 (8) instructions of a step are dealt to the four waves; double buffer, one barrier per step: a wave requests
     // step s + 1 after the barrier of step s, which every wave reaches only with its fragment reads of step s - 1 consumed.
     constexpr int CHI = (int)sizeof(TI), CHQ = QS ? 4 : (int)sizeof(TQ);  // 16-byte chunks per row and step: 4 (fp32), 2 (fp16)
-    constexpr int Q_BYTES = QS ? 12 * 1024 : CHQ * 2048, I_BYTES = CHI * 2048;
+    constexpr int Q_BYTES = QS ? 4 * NT * 1024 : CHQ * 2048, I_BYTES = CHI * 2048;
     __shared__ __attribute__((aligned(1024))) unsigned char stage[2][Q_BYTES + I_BYTES];
     const int i_block = i_base - 64 * (wave & 1), q_block = q_base - 64 * (wave >> 1);
     // DMA sources of this wave (rows are clamped: what the extra rows produce is discarded)
-    constexpr int NI_W = 2 * CHI / 4, NQ_W = QS ? 3 : 2 * CHQ / 4;  // instructions per wave and step
+    constexpr int NI_W = 2 * CHI / 4, NQ_W = QS ? NT : 2 * CHQ / 4;  // instructions per wave and step
     const TI *isrc[NI_W];
     const void *qsrc[NQ_W];
 #pragma unroll
@@ -398,8 +519,8 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
 #pragma unroll
     for (int i = 0; i < NQ_W; ++i) {
       if constexpr (QS) {
-        const int idx = wave * 3 + i, tile = idx / 3, plane = idx % 3;
-        qsrc[i] = reinterpret_cast<const __bf16 *>(Q) + (((size_t)(q_block / 32 + tile) * (f / 16)) * 3 + plane) * 512 + lane * 8;
+        const int idx = wave * NT + i, tile = idx / NT, plane = idx % NT;
+        qsrc[i] = reinterpret_cast<const uint16_t *>(Q) + (((size_t)(q_block / 32 + tile) * (f / 16)) * NT + plane) * 512 + lane * 8;
       } else {
         const int j = wave + 4 * i, rho = lane / CHQ, pos = lane % CHQ, sw = (rho / (8 / CHQ)) & (CHQ - 1);
         qsrc[i] = Q + (size_t)min(q_block + j * (64 / CHQ) + rho, nq - 1) * f + (pos ^ sw) * (16 / (int)sizeof(TQ));
@@ -408,8 +529,8 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
     auto dma = [&](int buf, int s16) {
 #pragma unroll
       for (int i = 0; i < NQ_W; ++i) {
-        const unsigned char *src = reinterpret_cast<const unsigned char *>(qsrc[i]) + (QS ? (size_t)s16 * 3 * 1024 : (size_t)s16 * 16 * sizeof(TQ));
-        const int slot = QS ? wave * 3 + i : wave + 4 * i;
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(qsrc[i]) + (QS ? (size_t)s16 * NT * 1024 : (size_t)s16 * 16 * sizeof(TQ));
+        const int slot = QS ? wave * NT + i : wave + 4 * i;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                          (__attribute__((address_space(3))) void *)&stage[buf][slot * 1024], 16, 0, 0);
       }
@@ -427,7 +548,7 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       i_off[t] = Q_BYTES + row_offset(64 * (wave & 1) + 32 * t + r, CHI);
-      q_off[t] = QS ? ((2 * (wave >> 1) + t) * 3 * 64 + lane) * 16 : row_offset(64 * (wave >> 1) + 32 * t + r, CHQ);
+      q_off[t] = QS ? ((2 * (wave >> 1) + t) * NT * 64 + lane) * 16 : row_offset(64 * (wave >> 1) + 32 * t + r, CHQ);
     }
     auto read_rows = [&](const unsigned char *base, int off, int CH, float4 &v0, float4 &v1) {
       if (CH == 4) {
@@ -444,11 +565,11 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
       float4 ra[2][2], rb[2][2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        if constexpr (QS) {
+        if constexpr (QS && !H2) {
           ah[t] = *reinterpret_cast<const tk_bf16x8 *>(base + q_off[t]);
           am[t] = *reinterpret_cast<const tk_bf16x8 *>(base + q_off[t] + 1024);
           al[t] = *reinterpret_cast<const tk_bf16x8 *>(base + q_off[t] + 2048);
-        } else {
+        } else if constexpr (!QS) {
           read_rows(base, q_off[t], CHQ, ra[t][0], ra[t][1]);
         }
         read_rows(base, i_off[t], CHI, rb[t][0], rb[t][1]);
@@ -474,14 +595,59 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
           }
       };
     };
+    float item_scale = 1.f;
+    if constexpr (H2) item_scale = h2_pow2(h2_scale_exp(emit.maxbits[1]));
+    auto multiply16_h2 = [&](int buf) {
+      const unsigned char *base = &stage[buf][0];
+      tk_f16x8 ah[2], al[2], bh[2], bl[2];
+      float4 rb[2][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        ah[t] = *reinterpret_cast<const tk_f16x8 *>(base + q_off[t]);
+        al[t] = *reinterpret_cast<const tk_f16x8 *>(base + q_off[t] + 1024);
+        read_rows(base, i_off[t], CHI, rb[t][0], rb[t][1]);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) split8_f16(rb[t][0], rb[t][1], item_scale, bh[t], bl[t]);
+      return [=](auto &accr) {
+#pragma unroll
+        for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+          for (int ti = 0; ti < 2; ++ti) {
+            f32x16 c = accr[tq][ti];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tq], bh[ti], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tq], bl[ti], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tq], bh[ti], c, 0, 0, 0);
+            accr[tq][ti] = c;
+          }
+      };
+    };
     const int steps16 = f / 16;
     dma(0, 0);
     for (int s16 = 0; s16 < steps16; ++s16) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of step s16 have landed ...
       __syncthreads();                                   // ... and so have everybody else's
-      auto products = multiply16(s16 & 1);               // fragments out of LDS, splits
-      if (s16 + 1 < steps16) dma((s16 + 1) & 1, s16 + 1);
-      products(acc);
+      if constexpr (H2) {
+        auto products = multiply16_h2(s16 & 1);
+        if (s16 + 1 < steps16) dma((s16 + 1) & 1, s16 + 1);
+        products(acc);
+      } else {
+        auto products = multiply16(s16 & 1);             // fragments out of LDS, splits
+        if (s16 + 1 < steps16) dma((s16 + 1) & 1, s16 + 1);
+        products(acc);
+      }
+    }
+    if constexpr (H2) {  // the operands' scales out again (a power of two: exact); a NaN is an overflowed operand (see H2 above)
+      const float unscale = h2_pow2(-h2_scale_exp(emit.maxbits[0]) - h2_scale_exp(emit.maxbits[1]));
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const float v = acc[a][b][e] * unscale;
+            acc[a][b][e] = MODE == 1 ? (v == v ? v : INFINITY) : v;
+          }
     }
   } else {
   // 8 factors per step; the operands of step s + 1 are requested before the 16 MFMAs of step s (two register sets), so
@@ -591,6 +757,7 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
           for (int ti = 0; ti < 2; ++ti) {
             float sc = acc[tq][ti][e];
             if (!(sc < tf)) {
+              if (!(sc == sc)) sc = INFINITY;  // (the fp16 form's overflow guard: select_candidates sends the row to the exact path)
               const int item = i_base + 32 * ti + r;
               if (q < nq && item < ni && ordered(sc) >= t) {
                 const uint32_t bit = 1u << (item & 31);
@@ -972,6 +1139,10 @@ __global__ __launch_bounds__(BLOCK) void select_candidates_kernel(const uint64_t
       __syncthreads();
     }
   }
+  if ((uint32_t)(cand[0] >> 32) >= 0xFF800000u) {  // best candidate +inf / NaN (uniform): an operand left the fp16 form's range
+    if (tid == 0) fallback[q] = 1;                 // (or the scores really are infinite) -- the exact path decides
+    return;
+  }
   const uint32_t t32 = (uint32_t)(cand[k - 1] >> 32);
   const bool tie = (int)n_c > k && t32 == (uint32_t)(cand[k] >> 32);
   if (!tie) {
@@ -1116,7 +1287,8 @@ struct imp_knn {
   // emit path
   DeviceArray<float> sub_scores, fb_query, fb_dist;
   DeviceArray<float> pad_items, pad_query;  // zero-padded fp32 copies for factor counts that are not a multiple of 16
-  DeviceArray<split_bf16> query_split;      // [nq][3][f] bf16 terms of the query rows (emit path, split form)
+  DeviceArray<split_bf16> query_split;      // [nq][3][f] bf16 (or [nq][2][f] fp16) terms of the query rows (emit path, split forms)
+  DeviceArray<unsigned> h2_max;             // fp16 form: bits of the largest query / sampled item magnitude of the call
   DeviceArray<uint32_t> tau, row_bits, item_bits;
   DeviceArray<unsigned int> cand_count;
   DeviceArray<uint64_t> cand;
@@ -1315,21 +1487,42 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
       const int *flags = host_flags;
       std::vector<int32_t> fb_list;
       static const bool no_qsplit = getenv("IMP_TOPK_NO_QSPLIT") != nullptr;
+      static const bool bf16x3 = getenv("IMP_TOPK_BF16X3") != nullptr;
       constexpr bool kCanSplit = BF3;
+      constexpr bool kCanH2 = BF3;  // (fp16-stored factors too: their values are their own high halves, and the scores stay
+                                    // bit-identical to scoring fp32 copies of them)
       const bool qsplit = kCanSplit && !no_qsplit;
+      const bool h2 = kCanH2 && qsplit && !bf16x3;  // two fp16 terms, three products (see H2 at split8_f16)
       split_bf16 *qs = nullptr;
+      unsigned *maxbits = nullptr;
       if (qsplit) {
         IMP_PROF("split_query_rows");
         const size_t nq_pad = (nq + 127) / 128 * 128;  // whole 128-row query blocks: a workgroup reads all four tiles of its block
         qs = imp_knn::ensure(knn->query_split, nq_pad * 3 * (size_t)f);
         const int grid = (int)std::max<size_t>(1, std::min<size_t>((nq_pad * (size_t)f + 255) / 256, (size_t)ctx().num_cus * 16));
-        split_query_rows_kernel<TQ><<<grid, 256, 0, stream()>>>(Qb, reinterpret_cast<__bf16 *>(qs), nq, nq_pad, f);
+        if (h2) {
+          if (knn->h2_max.size < 4 + 2 * kAbsmaxBlocks) knn->h2_max.alloc(4 + 2 * kAbsmaxBlocks, true);  // (the arrival counter starts at zero)
+          maxbits = knn->h2_max.data();
+          topk_absmax_kernel<TQ, TI><<<std::min(ctx().num_cus, kAbsmaxBlocks), 256, 0, stream()>>>(Qb, nq * (size_t)f, Ib, ni, f, maxbits);
+          split_query_rows_f16_kernel<TQ><<<grid, 256, 0, stream()>>>(Qb, reinterpret_cast<_Float16 *>(qs), nq, nq_pad, f, maxbits);
+        } else {
+          split_query_rows_kernel<TQ><<<grid, 256, 0, stream()>>>(Qb, reinterpret_cast<__bf16 *>(qs), nq, nq_pad, f);
+        }
         IMP_CHECK_HIP(hipGetLastError());
       }
       // the two GEMM launches of a batch: query rows pre-split (default) or in their storage type
       auto gemm = [&](auto mode_c, size_t start, dim3 grid, int rows, float *S_out, int bstride, const EmitArgs &ea) {
         constexpr int M = decltype(mode_c)::value;
         const float *norms_p = item_norms ? item_norms->f32() : nullptr;
+        if constexpr (kCanH2) {
+          if (h2) {
+            EmitArgs eh = ea;
+            eh.maxbits = maxbits;
+            score_gemm_direct_kernel<M, split_f16, TI, true><<<grid, 256, 0, stream()>>>(reinterpret_cast<const split_f16 *>(qs) + start * 2 * (size_t)f,
+                                                                                   rows, Ib, (int)ni, f, norms_p, S_out, nullptr, 0, bstride, eh);
+            return;
+          }
+        }
         if constexpr (kCanSplit) {
           if (qsplit) {
             score_gemm_direct_kernel<M, split_bf16, TI, true><<<grid, 256, 0, stream()>>>(qs + start * 3 * (size_t)f, rows, Ib, (int)ni, f, norms_p,

@@ -254,6 +254,45 @@ def test_emit_path_over_several_query_batches(gpu, oracle, dtype):
     assert_array_equal(ids[ok], want_ids[ok])
 
 
+@pytest.mark.parametrize("item_scale,query_scale", [(1.0, 1.0), (1e-4, 30.0), (2e3, 1e-3), (1e-6, 1e-6)])
+def test_fp16_form_follows_the_operands_magnitude(gpu, oracle, item_scale, query_scale):
+    """The emit path scores fp32 factors as two fp16 terms per value, scaled per call by a power of two taken from the largest
+    magnitudes (topk.hip, H2): trained-size, tiny and large factors keep the same relative accuracy, and rows of mixed size
+    inside one matrix (every 7th item 1000 x smaller) are ranked like the oracle ranks them."""
+    rng = np.random.default_rng(17)
+    ni, nq, f, k = 30_000, 200, 128, 10
+    items = (rng.standard_normal((ni, f)) * 0.1 * item_scale).astype(np.float32)
+    items[::7] *= 1e-3
+    q = (rng.standard_normal((nq, f)) * 0.1 * query_scale).astype(np.float32)
+    q[::5] *= 1e-2
+    ids, d = gpu.KnnQuery().topk(gpu.Matrix(items), gpu.Matrix(q), k)
+    want_ids, want_d = oracle.topk(items, q, k + 1)
+    assert_allclose(d, want_d[:, :k], rtol=3e-5, atol=0)
+    ok = ~_near_tie_rows(want_d, f)
+    assert ok.mean() > 0.9
+    assert_array_equal(ids[ok], want_ids[ok, :k])
+
+
+def test_fp16_form_hands_overflowing_rows_to_the_exact_path(gpu, oracle):
+    """An item row far above the sampled magnitude (rows 0, 16, 32 ... are sampled; row 7 is 10^4 x the rest) leaves the fp16
+    range after scaling: its scores come out as NaN, travel as +inf candidates, and every query row that saw one is re-scored
+    by the materialising path -- the result is the oracle's, with the outlier first or absent as its sign decides."""
+    rng = np.random.default_rng(23)
+    ni, nq, f, k = 20_000, 150, 64, 10
+    items = (rng.standard_normal((ni, f)) * 0.1).astype(np.float32)
+    items[7] *= 1e4
+    items[4001] *= 3e3
+    q = (rng.standard_normal((nq, f)) * 0.1).astype(np.float32)
+    liked = sp.random(nq, ni, density=10.0 / ni, format="csr", random_state=9, dtype=np.float32)
+    ids, d = gpu.KnnQuery().topk(gpu.Matrix(items), gpu.Matrix(q), k, query_filter=gpu.COOMatrix(liked.tocoo()))
+    assert np.isfinite(d).all()
+    want_ids, want_d = oracle.topk(items, q, k + 1, filter_query_items=liked)
+    assert_allclose(d, want_d[:, :k], rtol=3e-5, atol=1e-7)
+    ok = ~_near_tie_rows(want_d, f)
+    assert_array_equal(ids[ok], want_ids[ok, :k])
+    assert (ids[:, 0] == 7).sum() > nq // 4      # the outlier leads wherever its score is positive
+
+
 @pytest.mark.parametrize("shape", [(20_000, 64, 300, 10), (3_000, 40, 70, 100), (40_000, 128, 1500, 10)])
 def test_device_output_pointers(gpu, shape):
     """imp_knn_topk writes into DEVICE buffers when the caller passes device pointers (the reference detects where its output
