@@ -260,8 +260,9 @@ __global__ __launch_bounds__(BLOCK) void select_kernel(const float *__restrict__
 
 
 // ---- fast path (f % 8 == 0): 128 x 128 block tile, 4 waves as 2 x 2, each wave 64 queries x 64 items = 2 x 2 MFMA tiles -----
-// Split-bf16 form (f % 16 == 0, default): v_mfma_f32_32x32x16_bf16 on three-way split operands, both operands staged per
-// workgroup and 16-factor step by LDS-DMA (see the kernel).  Exact-fp32 form (v_mfma_f32_32x32x2_f32; f % 8 == 0 off the
+// Split-bf16 form (f % 16 == 0; materialising path and fallback): v_mfma_f32_32x32x16_bf16 on three-way split operands, both
+// operands staged per workgroup and 16-factor step by LDS-DMA (see the kernel).  fp16 form (f % 16 == 0; the emit path's two
+// GEMMs, round 5): the same staging, two fp16 terms per value and three products (H2 at split8_f16).  Exact-fp32 form (v_mfma_f32_32x32x2_f32; f % 8 == 0 off the
 // 16-grid, IMP_TOPK_FP32_MFMA=1): operands straight from global memory, no LDS, no barriers -- lane (r = l & 31, kh = l >> 5)
 // loads ONE float4 = 4 consecutive factors [k0 + 4 kh, +4) of its query / item row per 8-factor block; MFMA step s of the
 // block uses factor k0 + 4 kh + s for BOTH operands (the k index inside an MFMA is a free permutation), so one dwordx4 per
