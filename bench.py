@@ -309,6 +309,7 @@ def main():
         if deferred:
             gpu.synchronize()
 
+    clock_idle = round(gpu.core_clock_mhz(50), 1)
     gpu.set_deferred_sync(deferred)
     for _ in range(args.warmup):
         step()
@@ -337,6 +338,12 @@ def main():
         step()
     gpu.synchronize()
     gpu.Profiler.enable(False)
+    # the shader clock the steps run at: a one-wavefront probe queued right behind a step (the pool's boxes differ by a few per
+    # cent in step time; this is the first thing to look at)
+    clock_mhz = []
+    for _ in range(3):
+        raw_step()
+        clock_mhz.append(round(gpu.core_clock_mhz(50), 1))
     gpu.set_deferred_sync(False)
 
     # ---- roofline: the WHOLE step (every row class of both half sweeps), per-class table as an extra ---------------
@@ -413,6 +420,9 @@ def main():
         "kernels_ms_per_step": {k: v["total_ms"] / detail_steps for k, v in kernels.items()},
         "kernels_note": f"per-kernel HIP-event times from {detail_steps} extra iterations after the timed region",
         "setup_s": {"generate": t_gen, "upload": t_upload},
+        "core_clock_mhz": {"behind_a_step": clock_mhz, "before_warmup": clock_idle,
+                           "note": "imp_debug_core_clock: core cycles over 50 us of the constant-rate wall clock, one wavefront "
+                                   "queued behind the work named"},
     }
 
     if not args.no_topk:

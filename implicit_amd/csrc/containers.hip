@@ -325,6 +325,19 @@ __global__ __launch_bounds__(256) void occupy_kernel(long long ticks) {
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
 
+// imp_debug_core_clock: one wavefront counts core-clock cycles (s_memtime) over a stretch of the constant-rate wall clock
+__global__ void core_clock_kernel(long long ticks, unsigned long long *out) {
+  const long long w0 = wall_clock64();
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+  long long w1 = w0;
+  while (w1 - w0 < ticks) {
+    __builtin_amdgcn_s_sleep(8);
+    w1 = wall_clock64();
+  }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) out[0] = c1 - c0, out[1] = (unsigned long long)(w1 - w0);
+}
+
 static imp_matrix *new_matrix(size_t rows, size_t cols, size_t itemsize, bool zero) {
   if (itemsize != 4 && itemsize != 2) throw std::invalid_argument("invalid itemsize for Matrix (must be 2 or 4)");
   auto m = std::make_unique<imp_matrix>();
@@ -391,6 +404,22 @@ int imp_debug_occupy(int workgroups, int microseconds) {
     const long long ticks = (long long)microseconds * rate_khz / 1000;
     occupy_kernel<<<workgroups, 256, 32 * 1024, c.occupy_stream>>>(ticks);
     IMP_CHECK_HIP(hipGetLastError());
+  });
+}
+int imp_debug_core_clock(int microseconds, double *mhz) {
+  return guarded([&] {
+    if (!mhz) throw std::invalid_argument("imp_debug_core_clock: null output");
+    auto &c = ctx();
+    int rate_khz = 100000;
+    IMP_CHECK_HIP(hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, c.device));
+    DeviceArray<unsigned long long> out;
+    out.alloc(2, true);
+    core_clock_kernel<<<1, 64, 0, stream()>>>((long long)std::max(1, microseconds) * rate_khz / 1000, out.data());
+    IMP_CHECK_HIP(hipGetLastError());
+    unsigned long long h[2] = {0, 0};
+    IMP_CHECK_HIP(hipMemcpyAsync(h, out.data(), sizeof(h), hipMemcpyDeviceToHost, stream()));
+    sync();
+    *mhz = h[1] ? (double)h[0] / ((double)h[1] / rate_khz * 1e3) : 0.0;  // cycles per microsecond
   });
 }
 int imp_get_device(int *device) {

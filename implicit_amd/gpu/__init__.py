@@ -11,7 +11,7 @@ HAS_RMM = False
 
 try:
     from ._cuda import (COOMatrix, Comm, CSRMatrix, IntVector, KnnQuery, LeastSquaresSolver, Matrix,  # noqa: F401
-                        Profiler, RandomState, bpr_update, calculate_norms, debug_occupy, fixup_rows, get_device, get_device_count, get_oversubscribe, release_workspaces,
+                        Profiler, RandomState, bpr_update, calculate_norms, core_clock_mhz, debug_occupy, fixup_rows, get_device, get_device_count, get_oversubscribe, release_workspaces,
                         set_deferred_sync, set_device, set_oversubscribe, synchronize)
     from ._hip import lib as _lib
 

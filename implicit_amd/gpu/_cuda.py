@@ -466,6 +466,13 @@ def debug_occupy(workgroups, microseconds):
     check(lib().imp_debug_occupy(int(workgroups), int(microseconds)))
 
 
+def core_clock_mhz(microseconds=50):
+    """Measurement aid: the shader core clock (MHz) seen by a probe kernel queued behind the work already on the stream."""
+    mhz = ctypes.c_double(0.0)
+    check(lib().imp_debug_core_clock(int(microseconds), ctypes.byref(mhz)))
+    return mhz.value
+
+
 def synchronize():
     check(lib().imp_device_synchronize())
 

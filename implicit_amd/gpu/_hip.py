@@ -24,6 +24,7 @@ _SIGNATURES = {
     "imp_get_oversubscribe": [ctypes.POINTER(ctypes.c_int)],
     "imp_set_deferred_sync": [ctypes.c_int],
     "imp_debug_occupy": [ctypes.c_int, ctypes.c_int],
+    "imp_debug_core_clock": [ctypes.c_int, ctypes.POINTER(ctypes.c_double)],
     "imp_device_synchronize": [],
     "imp_solver_fixup_rows": [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int],
     "imp_mem_get_info": [ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)],
