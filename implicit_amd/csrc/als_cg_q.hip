@@ -438,7 +438,6 @@ template <int F, typename T> static void run_classes_q(const imp_csr *C, T *X, c
   // IMP_TEAM_FUSED=0: the round-2 team kernels (dense part, then tile part; gathers at the row start) -- A/B and the
   // IMP_CG_STATS instrumentation; a bit mask selects the round-3 kernel per team width (1: 16 waves, 2: 8, 4: 4, 8: 2, 16: 1, 32: the lock-step short-row kernel)
   static const int fused = getenv("IMP_TEAM_FUSED") ? atoi(getenv("IMP_TEAM_FUSED")) : 63;
-  static const bool want_stats = getenv("IMP_CG_STATS") != nullptr;
   auto team = [&](int bit, int width, int first, int count, const char *name, auto old) {
     class_stream_next();
     if (fused & bit) launch_team_fused<T>(C, F, width, first, count, X, Y, A0, cg_steps, name);  // IMP_CG_STATS: its own instrumented form
