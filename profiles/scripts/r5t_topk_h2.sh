@@ -5,7 +5,7 @@ set -u
 O=gpurun_out/r5t; mkdir -p $O
 python -m pytest tests/test_gpu_topk.py tests/test_gpu_round2.py -x -q -m gpu -k "topk or emit or fp16_form or TOPK or knn" 2>&1 | tail -4 > $O/pytest.log
 tail -3 $O/pytest.log
-for form in h2 bf16x3 h2 bf16x3; do
+for form in ${FORMS:-h2 bf16x3 h2 bf16x3}; do
   if [ $form = bf16x3 ]; then export IMP_TOPK_BF16X3=1; else unset IMP_TOPK_BF16X3; fi
   python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras > $O/bench_$form.json 2> $O/bench_$form.err
   python - <<PY
