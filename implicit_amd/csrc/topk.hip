@@ -1290,6 +1290,7 @@ struct imp_knn {
   DeviceArray<float> pad_items, pad_query;  // zero-padded fp32 copies for factor counts that are not a multiple of 16
   DeviceArray<split_bf16> query_split;      // [nq][3][f] bf16 (or [nq][2][f] fp16) terms of the query rows (emit path, split forms)
   DeviceArray<unsigned> h2_max;             // fp16 form: bits of the largest query / sampled item magnitude of the call
+  bool h2_off = false;                      // fp16 form given up for this handle (see the emit path)
   DeviceArray<uint32_t> tau, row_bits, item_bits;
   DeviceArray<unsigned int> cand_count;
   DeviceArray<uint64_t> cand;
@@ -1493,7 +1494,9 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
       constexpr bool kCanH2 = BF3;  // (fp16-stored factors too: their values are their own high halves, and the scores stay
                                     // bit-identical to scoring fp32 copies of them)
       const bool qsplit = kCanSplit && !no_qsplit;
-      const bool h2 = kCanH2 && qsplit && !bf16x3;  // two fp16 terms, three products (see H2 at split8_f16)
+      // two fp16 terms, three products (see H2 at split8_f16); a handle whose catalogue sent most rows of a batch to the exact path
+      // (item rows far above the sampled magnitude: every query row then sees a NaN) stays on the six-product form from then on
+      const bool h2 = kCanH2 && qsplit && !bf16x3 && !knn->h2_off;
       split_bf16 *qs = nullptr;
       unsigned *maxbits = nullptr;
       if (qsplit) {
@@ -1582,6 +1585,7 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
         fb_list.clear();
         for (size_t i = 0; i < rows; ++i)
           if (flags[i]) fb_list.push_back((int32_t)i);
+        if (h2 && fb_list.size() * 2 > rows) knn->h2_off = true;
         static const bool debug = getenv("IMP_TOPK_DEBUG") != nullptr;
         if (debug && !fb_list.empty()) {
           std::vector<unsigned int> hc(rows);

@@ -291,6 +291,27 @@ def test_fp16_form_hands_overflowing_rows_to_the_exact_path(gpu, oracle):
     ok = ~_near_tie_rows(want_d, f)
     assert_array_equal(ids[ok], want_ids[ok, :k])
     assert (ids[:, 0] == 7).sum() > nq // 4      # the outlier leads wherever its score is positive
+    # the same handle again: it has given the fp16 form up (most rows of the batch went to the exact path) -- same answer
+    knn = gpu.KnnQuery()
+    first = knn.topk(gpu.Matrix(items), gpu.Matrix(q), k)
+    second = knn.topk(gpu.Matrix(items), gpu.Matrix(q), k)
+    assert_array_equal(first[0], second[0])
+    assert_allclose(first[1], second[1], rtol=3e-5)
+
+
+def test_fp16_form_on_heavy_tailed_item_norms(gpu, oracle):
+    """Item rows whose magnitudes spread over four decades (log-uniform row scales): the sampled maximum is within the fp16 form's
+    headroom of the true one or it is not -- either way the answer is the oracle's."""
+    rng = np.random.default_rng(29)
+    ni, nq, f, k = 24_000, 120, 64, 10
+    items = (rng.standard_normal((ni, f)) * 0.1).astype(np.float32) * (10.0 ** rng.uniform(-2, 2, (ni, 1))).astype(np.float32)
+    q = (rng.standard_normal((nq, f)) * 0.1).astype(np.float32)
+    ids, d = gpu.KnnQuery().topk(gpu.Matrix(items), gpu.Matrix(q), k)
+    want_ids, want_d = oracle.topk(items, q, k + 1)
+    assert_allclose(d, want_d[:, :k], rtol=3e-5, atol=0)
+    ok = ~_near_tie_rows(want_d, f)
+    assert ok.mean() > 0.9
+    assert_array_equal(ids[ok], want_ids[ok, :k])
 
 
 @pytest.mark.parametrize("shape", [(20_000, 64, 300, 10), (3_000, 40, 70, 100), (40_000, 128, 1500, 10)])
