@@ -61,12 +61,14 @@ def whole_step_check(out_dir, stats_csv):
                 rl = j["roofline"]
                 rec[label] = {"ms_per_step": j["ms_per_step"], "frac": rl["frac"], "half_sweep_ms_hip_events": rl["avg_launch_ms"],
                               "frac_half_sweep_events": rl["frac_half_sweep_events"],
-                              "algorithmic_bytes_per_step": rl["algorithmic_bytes_per_step"], "steps": j["steps"], "warmup": j["warmup"]}
+                              "algorithmic_bytes_per_step": rl["algorithmic_bytes_per_step"], "steps": j["steps"], "warmup": j["warmup"],
+                              # (round 5: three more steps, each with the core-clock probe queued behind it)
+                              "probe_steps": len(j.get("core_clock_mhz", {}).get("behind_a_step", []))}
             except Exception as e:  # noqa: BLE001
                 rec[label] = {"error": str(e)}
     prof = rec.get("bench_under_rocprof.json", {})
     if os.path.exists(stats_csv) and "steps" in prof:
-        steps_run = prof["steps"] + prof["warmup"] + min(prof["steps"], 3)
+        steps_run = prof["steps"] + prof["warmup"] + min(prof["steps"], 3) + prof.get("probe_steps", 0)
         total_ns = sum(float(r["TotalDurationNs"]) for r in csv.DictReader(open(stats_csv))
                        if "als_cg" in r["Name"] or "cg_long" in r["Name"])
         ms = total_ns / 1e6 / steps_run
