@@ -377,7 +377,7 @@ __device__ __forceinline__ void split8_f16(const float4 &v0, const float4 &v1, f
 // counter out[2] (zero at rest) folds them and puts the counter back (a memset + per-wavefront atomics cost 55 us of a 500 us call).
 constexpr int kAbsmaxBlocks = 256;
 template <typename TQ, typename TI>
-__global__ __launch_bounds__(256) void topk_absmax_kernel(const TQ *__restrict__ Q, size_t nq_vals, const TI *__restrict__ I, size_t ni, int f,
+__global__ __launch_bounds__(1024) void topk_absmax_kernel(const TQ *__restrict__ Q, size_t nq_vals, const TI *__restrict__ I, size_t ni, int f,
                                                           unsigned *__restrict__ out) {
   const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
   float mq = 0.f, mi = 0.f;
@@ -401,14 +401,14 @@ __global__ __launch_bounds__(256) void topk_absmax_kernel(const TQ *__restrict__
     mq = fmaxf(mq, __shfl_xor(mq, off, 64));
     mi = fmaxf(mi, __shfl_xor(mi, off, 64));
   }
-  __shared__ float red[2][4];
+  __shared__ float red[2][16];  // (16 wavefronts: the sample is latency, so many of them with few rows each)
   __shared__ bool last;
   const int wave = threadIdx.x >> 6;
   if (lane == 0) red[0][wave] = mq, red[1][wave] = mi;
   __syncthreads();
   if (threadIdx.x == 0) {
-    mq = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
-    mi = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+    mq = mi = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) mq = fmaxf(mq, red[0][w]), mi = fmaxf(mi, red[1][w]);
     __hip_atomic_store(out + 4 + 2 * blockIdx.x, __float_as_uint(mq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(out + 5 + 2 * blockIdx.x, __float_as_uint(mi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     last = __hip_atomic_fetch_add(out + 2, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
@@ -425,12 +425,13 @@ __global__ __launch_bounds__(256) void topk_absmax_kernel(const TQ *__restrict__
     bq = max(bq, (unsigned)__shfl_xor((int)bq, off, 64));
     bi = max(bi, (unsigned)__shfl_xor((int)bi, off, 64));
   }
-  __shared__ unsigned redu[2][4];
+  __shared__ unsigned redu[2][16];
   if (lane == 0) redu[0][wave] = bq, redu[1][wave] = bi;
   __syncthreads();
   if (threadIdx.x == 0) {
-    out[0] = max(max(redu[0][0], redu[0][1]), max(redu[0][2], redu[0][3]));
-    out[1] = max(max(redu[1][0], redu[1][1]), max(redu[1][2], redu[1][3]));
+    unsigned fq = 0u, fi = 0u;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) fq = max(fq, redu[0][w]), fi = max(fi, redu[1][w]);
+    out[0] = fq, out[1] = fi;
     __hip_atomic_store(out + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
@@ -1507,7 +1508,7 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
         if (h2) {
           if (knn->h2_max.size < 4 + 2 * kAbsmaxBlocks) knn->h2_max.alloc(4 + 2 * kAbsmaxBlocks, true);  // (the arrival counter starts at zero)
           maxbits = knn->h2_max.data();
-          topk_absmax_kernel<TQ, TI><<<std::min(ctx().num_cus, kAbsmaxBlocks), 256, 0, stream()>>>(Qb, nq * (size_t)f, Ib, ni, f, maxbits);
+          topk_absmax_kernel<TQ, TI><<<std::min(ctx().num_cus, kAbsmaxBlocks), 1024, 0, stream()>>>(Qb, nq * (size_t)f, Ib, ni, f, maxbits);
           split_query_rows_f16_kernel<TQ><<<grid, 256, 0, stream()>>>(Qb, reinterpret_cast<_Float16 *>(qs), nq, nq_pad, f, maxbits);
         } else {
           split_query_rows_kernel<TQ><<<grid, 256, 0, stream()>>>(Qb, reinterpret_cast<__bf16 *>(qs), nq, nq_pad, f);
