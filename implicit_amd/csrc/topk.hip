@@ -469,6 +469,9 @@ __device__ __forceinline__ float4 widen4(const uint2 &raw) {
   return make_float4(a.x, a.y, b.x, b.y);
 }
 
+#ifndef IMP_TOPK_KO
+#define IMP_TOPK_KO 0  // timing-only knock-outs of the fp16 form (build variants, wrong results): 1 no MFMAs, 2 no item DMA, 4 no query
+#endif                 // DMA, 8 no low halves of the items (one conversion per value), 16 no epilogue (profiles/scripts/r5u_topk_ko.sh)
 #ifndef IMP_TOPK_MIN_WAVES
 #define IMP_TOPK_MIN_WAVES 3  // waves per SIMD the register allocation leaves room for (split-bf16 emit GEMM at C3: 2 waves 0.83 ms, 3: 0.73, 4: 0.80)
 #endif
@@ -531,6 +534,7 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
     auto dma = [&](int buf, int s16) {
 #pragma unroll
       for (int i = 0; i < NQ_W; ++i) {
+        if (H2 && (IMP_TOPK_KO & 4)) break;
         const unsigned char *src = reinterpret_cast<const unsigned char *>(qsrc[i]) + (QS ? (size_t)s16 * NT * 1024 : (size_t)s16 * 16 * sizeof(TQ));
         const int slot = QS ? wave * NT + i : wave + 4 * i;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
@@ -538,6 +542,7 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
       }
 #pragma unroll
       for (int i = 0; i < NI_W; ++i)
+        if (!(H2 && (IMP_TOPK_KO & 2)))
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(isrc[i] + 16 * s16),
                                          (__attribute__((address_space(3))) void *)&stage[buf][Q_BYTES + (wave + 4 * i) * 1024], 16, 0, 0);
     };
@@ -610,8 +615,16 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
         read_rows(base, i_off[t], CHI, rb[t][0], rb[t][1]);
       }
 #pragma unroll
-      for (int t = 0; t < 2; ++t) split8_f16(rb[t][0], rb[t][1], item_scale, bh[t], bl[t]);
+      for (int t = 0; t < 2; ++t) {
+        split8_f16(rb[t][0], rb[t][1], item_scale, bh[t], bl[t]);
+        if (IMP_TOPK_KO & 8) bl[t] = bh[t];
+      }
       return [=](auto &accr) {
+        if (IMP_TOPK_KO & 1) {  // operands kept alive, nothing multiplied
+#pragma unroll
+          for (int t = 0; t < 2; ++t) asm volatile("" ::"v"(ah[t]), "v"(al[t]), "v"(bh[t]), "v"(bl[t]));
+          return;
+        }
 #pragma unroll
         for (int tq = 0; tq < 2; ++tq)
 #pragma unroll
@@ -650,6 +663,13 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
             const float v = acc[a][b][e] * unscale;
             acc[a][b][e] = MODE == 1 ? (v == v ? v : INFINITY) : v;
           }
+      if (MODE == 2 && (IMP_TOPK_KO & 16)) {
+        float sink = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sink += acc[0][0][e] + acc[0][1][e] + acc[1][0][e] + acc[1][1][e];
+        if (sink == 1.2345e-33f) emit.count[0] = 1u;
+        return;
+      }
     }
   } else {
   // 8 factors per step; the operands of step s + 1 are requested before the 16 MFMAs of step s (two register sets), so
@@ -1586,7 +1606,7 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
         fb_list.clear();
         for (size_t i = 0; i < rows; ++i)
           if (flags[i]) fb_list.push_back((int32_t)i);
-        if (h2 && fb_list.size() * 2 > rows) knn->h2_off = true;
+        if (h2 && IMP_TOPK_KO == 0 && fb_list.size() * 2 > rows) knn->h2_off = true;
         static const bool debug = getenv("IMP_TOPK_DEBUG") != nullptr;
         if (debug && !fb_list.empty()) {
           std::vector<unsigned int> hc(rows);
