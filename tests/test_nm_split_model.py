@@ -159,3 +159,35 @@ def test_root_form_matches_the_dealt_form():
     assert rel.max() < 2.0 ** -17 and rel.mean() < 2.0 ** -20
     assert got[-1] == 0.0 and (np.sign(got[:-1]) == np.sign(exact[:-1]))[np.abs(exact[:-1]) > 0].all()
     assert abs(got.sum() - exact.sum()) / np.abs(exact).sum() < 2e-7   # unbiased over a row
+
+
+def chol_block_of(bid, nb=32):
+    """nm_chol's ownership map (als_cg_nm.hip): block id -> (block row, block column) of the lower triangle's 4 x 4 blocks, numbered
+    by block COLUMN from the right, top to bottom inside a column -- the same float expression and fix-up loops as the kernel."""
+    t = int((np.sqrt(np.float32(8.0) * np.float32(bid) + np.float32(1.0)) - np.float32(1.0)) * np.float32(0.5))
+    while t * (t + 1) // 2 > bid:
+        t -= 1
+    while (t + 1) * (t + 2) // 2 <= bid:
+        t += 1
+    bn = nb - 1 - t
+    return bn + (bid - t * (t + 1) // 2), bn
+
+
+def test_cholesky_block_numbering_covers_the_triangle_and_keeps_live_blocks_a_prefix():
+    """f = 128: 528 blocks over 256 threads x 3 slots.  Every block of the lower triangle is owned exactly once, and the blocks
+    still to be updated at turn kb (block columns > kb) are exactly the ids below (31 - kb)(32 - kb) / 2 -- the first slot of the
+    first threads, which is what lets a wavefront run ceil(live / 256) passes of the trailing update per turn."""
+    nb = 32
+    n_blocks = nb * (nb + 1) // 2
+    owned = [chol_block_of(b, nb) for b in range(n_blocks)]
+    assert len(set(owned)) == n_blocks
+    assert all(0 <= bn <= bm < nb for bm, bn in owned)
+    for kb in range(nb):
+        live = [b for b, (bm, bn) in enumerate(owned) if bn > kb]
+        n_live = (nb - 1 - kb) * (nb - kb) // 2
+        assert live == list(range(n_live))
+    # inside a block column the blocks are consecutive ids, top (the diagonal block) to bottom
+    for t in range(nb):
+        ids = [b for b, (bm, bn) in enumerate(owned) if bn == nb - 1 - t]
+        assert ids == list(range(t * (t + 1) // 2, (t + 1) * (t + 2) // 2))
+        assert [owned[b][0] for b in ids] == list(range(nb - 1 - t, nb))
