@@ -767,6 +767,32 @@ static void least_squares_cg_padded(const imp_csr *C, imp_matrix *X, const imp_m
   }
 }
 
+// The Cholesky entry's use of the same workspaces (als_cholesky.hip: 64 < f < 128 rides the f = 128 path): Y, the solved rows of X and the
+// gramian zero-padded to F columns, the gramian with a unit diagonal block -- the padded system is block diagonal, its solution the
+// original one followed by zeros.  The CG path's "same Y as last time" shortcut does not survive another user of pad_y.
+void cholesky_pad_in(const imp_matrix *X, const imp_matrix *Y, const imp_matrix *YtY, size_t rx, int F) {
+  const int f = (int)X->cols;
+  auto &c = ctx();
+  const size_t ry = Y->rows;
+  if (c.pad_x.size < rx * F) c.pad_x.alloc(rx * F);
+  c.pad_y_src = nullptr;
+  if (c.pad_y.size < ry * F) c.pad_y.alloc(ry * F);
+  if (c.pad_gram.size < (size_t)F * F) c.pad_gram.alloc((size_t)F * F);
+  auto grid = [&](size_t n) { return (int)std::max<size_t>(1, std::min<size_t>((n + 255) / 256, (size_t)c.num_cus * 16)); };
+  IMP_PROF("pad_factors");
+  if (ry) pad_rows_kernel<<<grid(ry * F), 256, 0, stream()>>>(Y->f32(), c.pad_y.data(), ry, f, F);
+  if (rx) pad_rows_kernel<<<grid(rx * F), 256, 0, stream()>>>(X->f32(), c.pad_x.data(), rx, f, F);
+  pad_gram_kernel<<<grid((size_t)F * F), 256, 0, stream()>>>(YtY->f32(), c.pad_gram.data(), f, F);
+  IMP_CHECK_HIP(hipGetLastError());
+}
+void cholesky_pad_out(imp_matrix *X, size_t rx, int F) {
+  auto &c = ctx();
+  auto grid = [&](size_t n) { return (int)std::max<size_t>(1, std::min<size_t>((n + 255) / 256, (size_t)c.num_cus * 16)); };
+  IMP_PROF("unpad_factors");
+  if (rx) unpad_rows_kernel<<<grid(rx * X->cols), 256, 0, stream()>>>(c.pad_x.data(), X->f32(), rx, (int)X->cols, F);
+  IMP_CHECK_HIP(hipGetLastError());
+}
+
 void least_squares_cg(const imp_csr *C, imp_matrix *X, const imp_matrix *YtY, const imp_matrix *Y, int cg_steps) {
   note_device_write(X->data, (size_t)C->rows * X->cols * X->itemsize);  // the rows this call solves
   // one event pair around ALL launches of the half sweep (every row class): what bench.py's whole-step `roofline` is timed on

@@ -826,6 +826,27 @@ void zero_rows(const int32_t *order, int first, int count, float *X, int f);  //
 int64_t least_squares_cholesky(const imp_csr *C, imp_matrix *X, const imp_matrix *YtY, const imp_matrix *Y, double reg) {
   const int f = (int)X->cols;
   if (f > 256) throw std::invalid_argument("least_squares_cholesky: factors must be <= 256 in this build");
+  // 64 < f < 128 (the reference's CPU default is 100): zero-padded onto the f = 128 path below -- Y and the gramian padded, the gramian
+  // with a unit diagonal block: the padded system is block diagonal and its solution the original one followed by zeros (its 4 x 4
+  // blocks factorise in the same order; the padded block rows never touch the others).  125 -> about 62 ms per configs[2]-shaped
+  // iteration at f = 100 against the workgroup kernel.  IMP_CHOL_PAD=0 (and the switches that ask for the workgroup kernels) keep it.
+  static const bool chol_pad = !(getenv("IMP_CHOL_PAD") && atoi(getenv("IMP_CHOL_PAD")) == 0) &&
+                               !(getenv("IMP_CHOL_NM") && atoi(getenv("IMP_CHOL_NM")) == 0) && getenv("IMP_CHOL_UNBLOCKED") == nullptr;
+  // (not for a handful of rows against a large Y -- fold-in calls: the padded copy of Y would cost more than the solve)
+  if (f > 64 && f < 128 && chol_pad && C->nonempty() > 0 && (size_t)C->nnz * 4 >= Y->rows && X->itemsize == 4 && Y->itemsize == 4) {
+    constexpr int F = 128;
+    const size_t rx = (size_t)C->rows;
+    cholesky_pad_in(X, Y, YtY, rx, F);
+    auto &c = ctx();
+    imp_matrix Xp, Yp, Gp;
+    Xp.rows = rx, Xp.cols = F, Xp.data = c.pad_x.data();
+    Yp.rows = Y->rows, Yp.cols = F, Yp.data = c.pad_y.data();
+    Gp.rows = F, Gp.cols = F, Gp.data = c.pad_gram.data();
+    const int64_t failed = least_squares_cholesky(C, &Xp, &Gp, &Yp, reg);
+    cholesky_pad_out(X, rx, F);
+    sync();
+    return failed;
+  }
   int lda = (f + 1) | 1;  // odd
   // Packed rows of the augmented triangle (i (i + 1) / 2 + j): a must beyond f = 160, where the square image no longer fits the
   // LDS, and a gain well below that -- at f = 128 the packed image lets THREE workgroups share a CU instead of two (measured

@@ -311,6 +311,9 @@ struct imp_coo {
 namespace imp {
 // als_cg_nm.hip: Cholesky half sweep at f = 128 through the rows' normal matrices on the matrix cores; what it could not factorise
 // comes back as a device-side list for the workgroup-per-row fp32 kernel (als_cholesky.hip)
+// 64 < f < 128 Cholesky on the f = 128 path (als_cg.hip owns the pad kernels and workspaces)
+void cholesky_pad_in(const imp_matrix *X, const imp_matrix *Y, const imp_matrix *YtY, size_t rx, int F);
+void cholesky_pad_out(imp_matrix *X, size_t rx, int F);
 struct CholNmList {
   const unsigned *count, *rows;
   int capacity;

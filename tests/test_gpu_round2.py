@@ -224,7 +224,7 @@ print("switch ok")
                                     "IMP_CHOL_NO_MFMA=1", "IMP_CHOL_NO_WAVE=1", "IMP_TOPK_NO_FAST=1", "IMP_NO_CLUSTER=1", "IMP_CLUSTER_SC1=1",
                                     "IMP_GRAM_NO_VEC=1", "IMP_CHOL_NO_SPLIT=1", "IMP_TEAM16_CLUSTER=1", "IMP_F256_GENERIC=1",
                                     "IMP_OVERSUB=3", "IMP_STRIPE_REUSE=1", "IMP_QGROUP_PER_CU=1", "IMP_TEAM_FUSED=0", "IMP_TEAM_FUSED=31", "IMP_SHORT_STAGGER=0", "IMP_SHORT_BF16X3=0",
-                                    "IMP_TOPK_FP32_MFMA=1", "IMP_NO_PAD=1", "IMP_TOPK_NO_PAD=1", "IMP_TOPK_NO_QSPLIT=1", "IMP_HALF_TILE64=0", "IMP_TILE64=15", "IMP_CHOL_UNBLOCKED=1", "IMP_NM=0", "IMP_NM_SEGMENT=128", "IMP_CHOL_PACKED=1000", "IMP_CLASS_STREAMS=1", "IMP_F256_OLD=1", "IMP_NM_SCALE=0", "IMP_CHOL_NM=0", "IMP_TOPK_BF16X3=1", "IMP_GRAM_BF16X3=1"])
+                                    "IMP_TOPK_FP32_MFMA=1", "IMP_NO_PAD=1", "IMP_TOPK_NO_PAD=1", "IMP_TOPK_NO_QSPLIT=1", "IMP_HALF_TILE64=0", "IMP_TILE64=15", "IMP_CHOL_UNBLOCKED=1", "IMP_NM=0", "IMP_NM_SEGMENT=128", "IMP_CHOL_PACKED=1000", "IMP_CLASS_STREAMS=1", "IMP_F256_OLD=1", "IMP_NM_SCALE=0", "IMP_CHOL_NM=0", "IMP_TOPK_BF16X3=1", "IMP_GRAM_BF16X3=1", "IMP_CHOL_PAD=0"])
 def test_ab_switch_paths_keep_parity(gpu, switch):
     """Every debug / A-B environment switch selects kernels the default run does not take (they are read once per
     process, hence the subprocess): CG both orientations at f = 64 / 128, Cholesky f = 64 and top-k against the oracle."""
