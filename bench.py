@@ -575,29 +575,34 @@ def extra_factor_grid(gpu, Cui, Ciu):
 def extra_cholesky_f128(gpu, Cui, Ciu):
     """The Cholesky solver at the factor count the metric is quoted on (`use_cg=False`, implicit/cpu/als.py:418-423) on the
     configs[2] matrix: since round 5 the rows' normal matrices are built on the matrix cores and factorised on their LDS images
-    (als_cg_nm.hip nm_chol; IMP_CHOL_NM=0: the workgroup-per-row LDS kernel of round 4)."""
-    f = FACTORS
-    rng = np.random.default_rng(7)
-    X = gpu.Matrix(rng.random((Cui.shape[0], f), dtype=np.float32) * 0.01)
-    Y = gpu.Matrix(rng.random((Cui.shape[1], f), dtype=np.float32) * 0.01)
+    (als_cg_nm.hip nm_chol; IMP_CHOL_NM=0: the workgroup-per-row LDS kernel of round 4) -- and at f = 100, the reference's CPU
+    default, which rides the same path zero-padded (IMP_CHOL_PAD=0: the workgroup kernel)."""
+    out = {}
     Cd, Ctd = gpu.CSRMatrix(Cui), gpu.CSRMatrix(Ciu)
-    gram = gpu.Matrix.zeros(f, f)
     solver = gpu.LeastSquaresSolver()
-
-    def chol():
-        solver.calculate_yty(Y, gram, 0.0)
-        solver.least_squares_cholesky(Cd, X, gram, Y, REG)
-        solver.calculate_yty(X, gram, 0.0)
-        solver.least_squares_cholesky(Ctd, Y, gram, X, REG)
-
-    t, kernels = _time_iterations(gpu, chol, iters=2)
     rows = Cui.shape[0] + Cui.shape[1]
-    flops = 2.0 * Cui.nnz * 2 * f * f + rows * (f ** 3 / 3.0 + 2.0 * f * f)
-    return {"cholesky_c3_f128": {"workload": "configs[2] matrix, f=128, Cholesky (normal matrices on the matrix cores, LDS-image factorisation)", "ms_per_iter": 1e3 * t,
-                                 "updates_per_s": rows / t, "tflops": flops / t / 1e12,
-                                 "roofline": {"bound": "fp32", "achieved": flops / t / 1e12, "peak": FP32_PEAK_TFLOPS,
-                                              "unit": "TFLOP/s", "frac": flops / t / 1e12 / FP32_PEAK_TFLOPS},
-                                 "kernels_ms_per_iter": kernels}}
+    for f, key, what in ((FACTORS, "cholesky_c3_f128", "normal matrices on the matrix cores, LDS-image factorisation"),
+                         (100, "cholesky_c3_f100", "zero-padded onto the f=128 path")):
+        rng = np.random.default_rng(7)
+        X = gpu.Matrix(rng.random((Cui.shape[0], f), dtype=np.float32) * 0.01)
+        Y = gpu.Matrix(rng.random((Cui.shape[1], f), dtype=np.float32) * 0.01)
+        gram = gpu.Matrix.zeros(f, f)
+
+        def chol():
+            solver.calculate_yty(Y, gram, 0.0)
+            solver.least_squares_cholesky(Cd, X, gram, Y, REG)
+            solver.calculate_yty(X, gram, 0.0)
+            solver.least_squares_cholesky(Ctd, Y, gram, X, REG)
+
+        t, kernels = _time_iterations(gpu, chol, iters=2)
+        flops = 2.0 * Cui.nnz * 2 * f * f + rows * (f ** 3 / 3.0 + 2.0 * f * f)   # of the f the caller asked for, not the padded one
+        out[key] = {"workload": f"configs[2] matrix, f={f}, Cholesky ({what})", "ms_per_iter": 1e3 * t,
+                    "updates_per_s": rows / t, "tflops": flops / t / 1e12,
+                    "roofline": {"bound": "fp32", "achieved": flops / t / 1e12, "peak": FP32_PEAK_TFLOPS,
+                                 "unit": "TFLOP/s", "frac": flops / t / 1e12 / FP32_PEAK_TFLOPS},
+                    "kernels_ms_per_iter": kernels}
+        del X, Y, gram
+    return out
 
 
 def extra_c2(gpu, SHAPES):

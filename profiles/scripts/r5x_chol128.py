@@ -27,4 +27,5 @@ print("per-row rel", np.array2string(err, precision=2), "max", err.max(), "fixup
 if "time" in sys.argv:
     C3 = named("lastfm360k")
     out = bench.extra_cholesky_f128(gpu, C3, C3.T.tocsr())
-    print(json.dumps({k: v for k, v in out["cholesky_c3_f128"].items() if k in ("ms_per_iter", "tflops", "kernels_ms_per_iter")}))
+    for key in out:
+        print(key, json.dumps({k: v for k, v in out[key].items() if k in ("ms_per_iter", "tflops", "kernels_ms_per_iter")}))
