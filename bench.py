@@ -197,6 +197,7 @@ def cpu_baseline(Cui, Ciu, X0, Y0, seconds):
         "unit": "updates/s",
         "cores": cores,
         "kind": kind,
+        "sample_short": f"CG(3) f={X0.shape[1]} half sweeps over {su}+{si} rows ({nnz} nnz), {t:.1f}s, {cores} of {os.cpu_count()} cores",
         "sample": f"one CG(cg_steps=3,f={X0.shape[1]}) half-sweep over {su} users + {si} items taken at a uniform stride "
                   f"({nnz} nnz) of the same matrix, {t:.1f}s, OpenMP num_threads={cores} of {os.cpu_count()} logical cores, "
                   f"BLAS threads=1",
@@ -266,7 +267,7 @@ def main():
 
         result = sharded.bench(args, gpu, SHAPES, FACTORS, REG, CG_STEPS, rank0_roofline)
         if rank == 0:
-            emit(saved_stdout, result)
+            emit(saved_stdout, compact_sharded_line(result))
         return
 
     # ---- single GPU ---------------------------------------------------------------------------------
@@ -394,7 +395,7 @@ def main():
                           "frac_of_8TBps": total_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS}
 
     out = {
-        "metric": "ALS user+item updates/sec per iteration (factors=128)",
+        "metric": "ALS user+item updates/sec per iteration (factors=128); top-k recs/sec",
         "value": value,
         "unit": "updates/s",
         "n_gpus": 1,
@@ -440,6 +441,7 @@ def main():
         for name, fn in (("fit_c3", lambda: extra_fit(gpu, Cui)), ("fp16_c3", lambda: extra_fp16(gpu, Cui, Ciu, X0, Y0)),
                          ("factor_grid", lambda: extra_factor_grid(gpu, Cui, Ciu)),
                          ("cholesky_f128", lambda: extra_cholesky_f128(gpu, Cui, Ciu)),
+                         ("c1", lambda: extra_c1(gpu)),
                          ("c2", lambda: extra_c2(gpu, SHAPES)),
                          ("c5", lambda: extra_c5(gpu, SHAPES)), ("c4", lambda: extra_c4(gpu, SHAPES))):
             t0 = time.time()
@@ -448,7 +450,109 @@ def main():
             except Exception as e:  # an extra must never cost the headline line
                 out[name + "_error"] = f"{type(e).__name__}: {e}"
             out.setdefault("extras_s", {})[name] = round(time.time() - t0, 1)
-    emit(saved_stdout, out)
+    emit(saved_stdout, compact_line(out, args))
+
+
+def compact_line(full, args):
+    """The ONE stdout line.  The driver's record keeps the last 2000 characters of stdout and, of the parsed line, the contract
+    keys + `roofline` + `cpu_baseline` + `config` (strings cut at 120 characters): so the line carries both halves of
+    BASELINE.json's metric as short top-level keys, short strings only, one [ms, roofline fraction] pair per secondary
+    configuration -- and every table (per-kernel times, row classes, PMC traffic per class, notes) goes to a side file:
+    gpurun_out/bench_detail.json (override: IMP_BENCH_DETAIL=<path>; profiles/<round>_bench_detail.json is a committed copy)."""
+    detail_path = os.environ.get("IMP_BENCH_DETAIL", os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+    try:
+        os.makedirs(os.path.dirname(detail_path), exist_ok=True)
+        with open(detail_path, "w") as fh:
+            json.dump(full, fh, indent=1)
+    except OSError as e:
+        sys.stderr.write(f"bench.py: could not write {detail_path}: {e}\n")
+        detail_path = None
+    line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                 "scaling", "vs_baseline", "dtype", "data")}
+    topk = full.get("topk")
+    if topk:
+        # SURVEY 8(d): recs/s is quoted through model.recommend(userids, user_items[userids], N=k) with the liked-items filter
+        line["topk_recs_per_s"] = _r(topk.get("value"))
+        line["knn_topk_recs_per_s"] = _r(topk.get("knn_topk_recs_per_s"))
+    c = full["config"]
+    line["config"] = {"workload": c["workload"], "users": c["users"], "items": c["items"], "nnz": c["nnz"], "factors": c["factors"],
+                      "solver": c["solver"], "cg_steps": c["cg_steps"], "topk": "recommend() k=10, 20000 users in batches of 1000, liked-items filter on"
+                      if topk else None}
+    r = full.get("roofline")
+    if r:
+        line["roofline"] = {"bound": r["bound"], "achieved": _r(r["achieved"]), "peak": r["peak"], "unit": r["unit"], "frac": _r(r["frac"], 4),
+                            "traffic": _r(r["traffic"]), "kernel": "CG half sweep (all row-class launches of least_squares)",
+                            "avg_launch_ms": _r(r["avg_launch_ms"], 4), "frac_half_sweep_events": _r(r["frac_half_sweep_events"], 4),
+                            "bytes_per_step": r["algorithmic_bytes_per_step"],
+                            "classes_frac": {k: _r(v["frac"], 3) for k, v in full.get("row_classes", {}).items()},
+                            "split_precision": "rows>512 nnz: fp16x2 MFMA normal matrix (22-bit operands, fp32 accumulate, fp32 "
+                                               "fix-up); rows<=32: bf16x3 gramian product; else fp32"}
+    cb = full.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "cores_total": os.cpu_count(),
+                                "kind": cb["kind"], "sample": cb["sample_short"]}
+        tcb = (topk or {}).get("cpu_baseline")
+        if tcb:
+            line["cpu_baseline"]["topk_recs_per_s"] = _r(tcb["value"])
+            line["cpu_baseline"]["topk_cores"] = tcb["cores"]
+    if topk:
+        tr = topk.get("roofline") or {}
+        line["topk"] = {"value": _r(topk.get("value")), "unit": "recs/s", "k": topk.get("k"), "via": "model.recommend()",
+                        "gemm_ms": _r(tr.get("avg_launch_ms"), 4), "gemm_frac_of_mfma_peak": _r(tr.get("frac"), 3),
+                        "gemm_traffic": _r(tr.get("traffic"))}
+    extras = {}
+    for key, v in full.items():
+        if isinstance(v, dict) and "roofline" in v and key not in ("topk",) and isinstance(v.get("roofline"), dict):
+            ms = v.get("ms_per_iter", v.get("compute_ms_per_iter", v.get("ms_per_batch")))
+            extras[key] = [_r(ms, 3), _r(v["roofline"].get("frac"), 3)]
+        elif key.startswith("c1_") and isinstance(v, dict):  # configs[0]: [GPU ms, reference 1-thread ms, worst rel. Frobenius]
+            extras[key] = [_r(v["ms_per_iter"], 3), _r(v["cpu_1thread_ms_per_iter"], 3),
+                           float(f"{max(v['rel_frobenius_gpu_vs_cpu'].values()):.2g}")]
+    if extras:
+        line["extras_ms_frac"] = extras
+    errs = [k for k in full if k.endswith("_error")]
+    if errs:
+        line["extras_errors"] = errs
+    line["detail"] = os.path.relpath(detail_path, ROOT) if detail_path else None
+    return line
+
+
+def compact_sharded_line(full):
+    """The N > 1 line (and `--gpus 1 --shape c4`): contract keys, the roofline of rank 0's compute, how the step divides on
+    rank 0 (own kernels against exposed exchange), the ranks RCCL really connected; tables go to the side file."""
+    detail_path = os.environ.get("IMP_BENCH_DETAIL", os.path.join(ROOT, "gpurun_out", f"bench_detail_n{full['n_gpus']}.json"))
+    try:
+        os.makedirs(os.path.dirname(detail_path), exist_ok=True)
+        with open(detail_path, "w") as fh:
+            json.dump(full, fh, indent=1)
+    except OSError:
+        detail_path = None
+    line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                 "scaling", "vs_baseline", "dtype", "data")}
+    line["value"] = _r(line["value"])
+    c = full["config"]
+    line["config"] = {"workload": c["workload"][:118], "users": c["users"], "items": c["items"], "nnz": c["nnz"],
+                      "factors": c["factors"], "cg_steps": c["cg_steps"], "parallelism": c["parallelism"][:118]}
+    r = full.get("roofline")
+    if r:
+        line["roofline"] = {"bound": r["bound"], "achieved": _r(r["achieved"]), "peak": r["peak"], "unit": r["unit"],
+                            "frac": _r(r["frac"], 4), "traffic": r.get("traffic"), "scope": "rank 0's shard, compute only",
+                            "avg_launch_ms": _r(r.get("avg_launch_ms"), 4)}
+    line["rccl_ranks_seen"] = full.get("rccl_ranks_seen")
+    line["rank0_compute_ms"] = _r(full.get("rank0_compute_ms_per_step"), 3)
+    line["rank0_exposed_exchange_ms"] = _r(full.get("rank0_exposed_exchange_ms_per_step"), 3)
+    line["exchange_GB_per_rank"] = _r(full.get("exchange_GB_received_per_rank_per_step"), 4)
+    line["detail"] = os.path.relpath(detail_path, ROOT) if detail_path else None
+    return line
+
+
+def _r(x, digits=None):
+    """Rounded for the compact line (None and strings pass through)."""
+    if not isinstance(x, (int, float)) or isinstance(x, bool):
+        return x
+    if digits is None:
+        return float(f"{x:.5g}")
+    return round(float(x), digits)
 
 
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
@@ -602,6 +706,79 @@ def extra_cholesky_f128(gpu, Cui, Ciu):
                                  "unit": "TFLOP/s", "frac": flops / t / 1e12 / FP32_PEAK_TFLOPS},
                     "kernels_ms_per_iter": kernels}
         del X, Y, gram
+    return out
+
+
+def extra_c1(gpu):
+    """BASELINE configs[0]: MovieLens-100K shape (943 x 1682, ~100 K nnz), f = 16 -- the reference's own CPU-runnable case
+    (1 CPU thread, plumbing): the compiled reference (oracle/_ref, else the plain-C port) timed on ONE thread beside the GPU on
+    the same inputs, CG cg_steps=3 and Cholesky, with the relative Frobenius distance of one iteration from identical factors."""
+    from implicit_amd.synthetic import named
+    from oracle import oracle as port
+    from oracle import ref
+
+    f = 16
+    C = named("ml100k")
+    Ct = C.T.tocsr()
+    rng = np.random.default_rng(7)
+    X0 = rng.random((C.shape[0], f), dtype=np.float32) * 0.1 - 0.05
+    Y0 = rng.random((C.shape[1], f), dtype=np.float32) * 0.1 - 0.05
+    als_ref, _ = ref.load()
+    if als_ref is None:
+        port.build()
+    Cd, Ctd = gpu.CSRMatrix(C), gpu.CSRMatrix(Ct)
+    solver = gpu.LeastSquaresSolver()
+    gram = gpu.Matrix.zeros(f, f)
+    rows = C.shape[0] + C.shape[1]
+    out = {}
+    for solver_name in ("cg", "cholesky"):
+        X, Y = gpu.Matrix(X0), gpu.Matrix(Y0)
+
+        def gpu_iter():
+            if solver_name == "cg":
+                solver.calculate_yty(Y, gram, REG)
+                solver.least_squares(Cd, X, gram, Y, CG_STEPS)
+                solver.calculate_yty(X, gram, REG)
+                solver.least_squares(Ctd, Y, gram, X, CG_STEPS)
+            else:
+                solver.calculate_yty(Y, gram, 0.0)
+                solver.least_squares_cholesky(Cd, X, gram, Y, REG)
+                solver.calculate_yty(X, gram, 0.0)
+                solver.least_squares_cholesky(Ctd, Y, gram, X, REG)
+
+        def cpu_iter(Xh, Yh):
+            if als_ref is not None:
+                if solver_name == "cg":
+                    als_ref.least_squares_cg(C, Xh, Yh, REG, num_threads=1, cg_steps=CG_STEPS)
+                    als_ref.least_squares_cg(Ct, Yh, Xh, REG, num_threads=1, cg_steps=CG_STEPS)
+                else:
+                    als_ref.least_squares(C, Xh, Yh, REG, num_threads=1)
+                    als_ref.least_squares(Ct, Yh, Xh, REG, num_threads=1)
+            elif solver_name == "cg":
+                port.least_squares_cg(C, Xh, Yh, REG, num_threads=1, cg_steps=CG_STEPS)
+                port.least_squares_cg(Ct, Yh, Xh, REG, num_threads=1, cg_steps=CG_STEPS)
+            else:
+                port.least_squares(C, Xh, Yh, REG, num_threads=1)
+                port.least_squares(Ct, Yh, Xh, REG, num_threads=1)
+
+        gpu_iter()  # one iteration from (X0, Y0) on both sides: parity
+        Xh, Yh = X0.copy(), Y0.copy()
+        cpu_iter(Xh, Yh)
+        ex = float(np.linalg.norm(X.to_numpy() - Xh) / np.linalg.norm(Xh))
+        ey = float(np.linalg.norm(Y.to_numpy() - Yh) / np.linalg.norm(Yh))
+        t_gpu, _ = _time_iterations(gpu, gpu_iter, iters=20, warmup=2)
+        reps, t0 = 0, time.perf_counter()
+        while reps < 3 or time.perf_counter() - t0 < 0.5:
+            cpu_iter(Xh, Yh)
+            reps += 1
+        t_cpu = (time.perf_counter() - t0) / reps
+        out[f"c1_{solver_name}"] = {"workload": "BASELINE configs[0]: MovieLens-100K shape %d x %d, %d nnz, f=16, %s" %
+                                                (C.shape[0], C.shape[1], C.nnz, solver_name),
+                                    "ms_per_iter": 1e3 * t_gpu, "updates_per_s": rows / t_gpu,
+                                    "cpu_1thread_ms_per_iter": 1e3 * t_cpu, "cpu_1thread_updates_per_s": rows / t_cpu,
+                                    "cpu_kind": "reference" if als_ref is not None else "port",
+                                    "rel_frobenius_gpu_vs_cpu": {"users": ex, "items": ey},
+                                    "note": "launch-latency bound on the GPU (a 1 ms problem); listed because it is BASELINE's configs[0]"}
     return out
 
 
@@ -767,12 +944,27 @@ def extra_c4(gpu, SHAPES):
     t, kernels = _time_iterations(gpu, shard_step, iters=2)
     gb = _iteration_bytes(Cui_s, Ciu_s, f) / 1e9
     xgmi_gb = 7.0 / 8.0 * (users + items) * f * 4 / 1e9
+    # modelled 8-GPU iteration (implicit_amd.gpu.sharded.project_iteration_ms): K chunks of falling size per half sweep, the
+    # last chunk's exchange exposed, +15 % compute while RCCL's kernels are resident, one xGMI link per peer
+    from implicit_amd.gpu import sharded as _sh
+
+    half_ms = [1e3 * t / 2.0] * 2   # split evenly: the two half sweeps of rank 0's shard cost about the same
+    recv = [7.0 / 8.0 * users * f * 4, 7.0 / 8.0 * items * f * 4]
+    model = {}
+    for link in (50.0, 75.0):
+        ms, hidden = _sh.project_iteration_ms(half_ms, recv, 8, link_GBps=link)
+        model[f"link_{int(link)}GBps"] = {"ms_per_iter": ms, "updates_per_s": (users + items) / (ms * 1e-3),
+                                          "speedup_over_1gpu": out["c4_full_1gpu"]["ms_per_iter"] / ms}
     out["c4_shard"] = {"workload": "rank 0 of BASELINE configs[3] on 8 GPUs: %d user rows (%d nnz) + %d item rows (%d nnz), f=128, "
                                    "CG cg_steps=%d" % (Cui_s.shape[0], Cui_s.nnz, Ciu_s.shape[0], Ciu_s.nnz, CG_STEPS),
                        "compute_ms_per_iter": 1e3 * t,
                        "roofline": {"bound": "hbm", "achieved": gb / t, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": gb / t / HBM_PEAK_GBS, "algorithmic_GB_per_iter": gb},
                        "projected_8gpu_updates_per_s_if_exchange_hidden": (users + items) / t,
+                       "projected_8gpu_model": model,
+                       "projected_8gpu_model_note": "timeline model: %d chunks of falling size per half sweep (ratio 0.75), exchange of "
+                                                    "chunk k beside the solve of chunk k+1, last chunk exposed, +15 %% compute under "
+                                                    "resident RCCL kernels, one xGMI link per peer at the stated rate" % _sh.default_chunks(8),
                        "exchange_GB_received_per_rank_per_iter": xgmi_gb,
                        "kernels_ms_per_iter": kernels}
     return out
@@ -867,15 +1059,19 @@ def bench_topk(gpu, Cui, X, Y, k=10, queries=20_000, batch=1000):
         rec = queries / (time.perf_counter() - t0)
     except Exception as e:  # noqa: BLE001
         rec = f"{type(e).__name__}: {e}"
-    return {"metric": "top-k recs/sec", "value": queries / t, "unit": "recs/s", "k": k, "queries": queries,
+    # recs/s is quoted through the model-level call; the raw KnnQuery.topk rate (filters already resident) is kept beside it
+    value = rec if isinstance(rec, float) else queries / t
+    return {"metric": "top-k recs/sec", "value": value, "unit": "recs/s", "k": k, "queries": queries,
+            "via": "AlternatingLeastSquares.recommend(userids, user_items[userids], N=10), filter_already_liked_items=True"
+                   if isinstance(rec, float) else "KnnQuery.topk (model.recommend failed: %s)" % rec,
+            "knn_topk_recs_per_s": queries / t, "model_recommend_recs_per_s": rec,
             "kernels_ms_per_batch": kernels, "scoring_TFLOPs": flops / t / 1e12, "roofline": roofline,
-            "model_recommend_recs_per_s": rec,
             "batch": batch, "items": Y.shape[0], "filter_already_liked_items": True,
-            "ids": "identical to the compiled reference's topk outside fp32 near-ties (PARITY.md: 0 of 20 000 positions differ at this "
-                   "workload, 0.02 % at configs[4]'s similar_items k=100, every difference a float64-verified near-tie)",
-            "note": "value: KnnQuery.topk with the liked-items COO filters already on the device, ids/scores returned to host "
-                    "memory per batch (PCIe D2H included); model_recommend_recs_per_s: AlternatingLeastSquares.recommend() for "
-                    "the same users, host COO build + upload per batch included; kernel times from a separate profiled pass"}
+            "ids": "identical to the compiled reference's topk outside fp32 near-ties (PARITY.md)",
+            "note": "value: AlternatingLeastSquares.recommend() for 20 000 users in batches of 1000 -- the caller's scipy row slice "
+                    "user_items[a:b], the host COO pattern + upload, KnnQuery.topk, ids/scores back in host memory; "
+                    "knn_topk_recs_per_s: KnnQuery.topk alone with the liked-items COO filters already on the device; kernel times "
+                    "from a separate profiled pass"}
 
 
 if __name__ == "__main__":

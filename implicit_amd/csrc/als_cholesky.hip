@@ -957,7 +957,8 @@ int64_t least_squares_cholesky(const imp_csr *C, imp_matrix *X, const imp_matrix
   }
   if (n_block > 0) {
     // IMP_CHOL_UNBLOCKED=1: the round-1 column-by-column kernel (A/B, parity)
-    static const bool unblocked = getenv("IMP_CHOL_UNBLOCKED") != nullptr && !use_nm;
+    static const bool unblocked_env = getenv("IMP_CHOL_UNBLOCKED") != nullptr;  // (the switch alone is per process; use_nm is per call)
+    const bool unblocked = unblocked_env && !use_nm;
     if (!unblocked) {
       const int m = f + 1, nbr = (m + 3) / 4, nbc = (f + 3) / 4;
       const size_t a_words = packed ? (size_t)m * (m + 1) / 2 : (size_t)m * lda;

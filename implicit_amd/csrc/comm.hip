@@ -19,6 +19,12 @@
 
 struct imp_comm {
   ncclComm_t comm = nullptr;
+  // A second communicator over the same ranks for the pipelined row exchange.  RCCL serialises the operations of ONE
+  // communicator whatever streams they are queued on (and may add cross-stream dependencies of its own), so the gramian
+  // all-reduce on the library stream and the grouped send / recv on `xchg_stream` must not share one: at best the overlap the
+  // pipeline is built for disappears, at worst two ranks that interleave the two differently wait for each other.  Everything
+  // queued on the library stream uses `comm`, everything on `xchg_stream` uses `xchg_comm`.
+  ncclComm_t xchg_comm = nullptr;
   int nranks = 1, rank = 0;
   // pipelined exchange (allgather_rows_begin / _end): collectives are queued on their own stream behind an event of
   // the compute stream, so the solve of the next row chunk overlaps the exchange of the previous one
@@ -52,6 +58,22 @@ int imp_comm_init_rank(const void *id_bytes, int nranks, int rank, imp_comm **ou
     ncclUniqueId id;
     std::memcpy(&id, id_bytes, sizeof(id));
     IMP_CHECK_NCCL(ncclCommInitRank(&c->comm, nranks, id, rank));
+    // the exchange stream's communicator: a duplicate of the first (same ranks, same order).  ncclCommSplit with one colour is
+    // the library's own way to get one; should this RCCL refuse it, rank 0 draws a second id and hands it round through the
+    // first communicator (a 128-byte broadcast) for a plain ncclCommInitRank.
+    if (ncclCommSplit(c->comm, 0, rank, &c->xchg_comm, nullptr) != ncclSuccess || !c->xchg_comm) {
+      c->xchg_comm = nullptr;
+      ncclUniqueId id2;
+      std::memset(&id2, 0, sizeof(id2));
+      if (rank == 0) IMP_CHECK_NCCL(ncclGetUniqueId(&id2));
+      DeviceArray<unsigned char> buf;
+      buf.alloc(sizeof(id2));
+      IMP_CHECK_HIP(hipMemcpyAsync(buf.data(), &id2, sizeof(id2), hipMemcpyHostToDevice, stream()));
+      IMP_CHECK_NCCL(ncclBroadcast(buf.data(), buf.data(), sizeof(id2), ncclChar, 0, c->comm, stream()));
+      IMP_CHECK_HIP(hipMemcpyAsync(&id2, buf.data(), sizeof(id2), hipMemcpyDeviceToHost, stream()));
+      sync();
+      IMP_CHECK_NCCL(ncclCommInitRank(&c->xchg_comm, nranks, id2, rank));
+    }
     IMP_CHECK_HIP(hipStreamCreateWithFlags(&c->xchg_stream, hipStreamNonBlocking));
     IMP_CHECK_HIP(hipEventCreateWithFlags(&c->solved, hipEventDisableTiming));
     IMP_CHECK_HIP(hipEventCreateWithFlags(&c->exchanged, hipEventDisableTiming));
@@ -62,6 +84,7 @@ int imp_comm_init_rank(const void *id_bytes, int nranks, int rank, imp_comm **ou
 int imp_comm_destroy(imp_comm *c) {
   return guarded([&] {
     if (c && c->xchg_stream) (void)hipStreamSynchronize(c->xchg_stream);
+    if (c && c->xchg_comm) (void)ncclCommDestroy(c->xchg_comm);
     if (c && c->comm) (void)ncclCommDestroy(c->comm);
     if (c && c->solved) (void)hipEventDestroy(c->solved);
     if (c && c->exchanged) (void)hipEventDestroy(c->exchanged);
@@ -74,7 +97,7 @@ int imp_comm_destroy(imp_comm *c) {
 // every peer's rows come in.  xGMI is a full mesh of point-to-point links (7 per GPU), so the direct exchange puts each
 // shard on each link exactly once and all links work at the same time -- a ring would pipe every shard through the
 // neighbours' links instead.
-static void exchange_rows(imp_comm *c, imp_matrix *full, const int64_t *row_lo, const int64_t *row_hi, hipStream_t on) {
+static void exchange_rows(imp_comm *c, ncclComm_t comm, imp_matrix *full, const int64_t *row_lo, const int64_t *row_hi, hipStream_t on) {
   note_device_write(full->data, full->bytes());
   const size_t row_bytes = full->cols * full->itemsize;
   char *base = reinterpret_cast<char *>(full->data);
@@ -83,8 +106,8 @@ static void exchange_rows(imp_comm *c, imp_matrix *full, const int64_t *row_lo, 
   for (int peer = 0; peer < c->nranks; ++peer) {
     if (peer == c->rank) continue;
     const size_t theirs = (size_t)(row_hi[peer] - row_lo[peer]) * row_bytes;
-    if (mine) IMP_CHECK_NCCL(ncclSend(base + (size_t)row_lo[c->rank] * row_bytes, mine, ncclChar, peer, c->comm, on));
-    if (theirs) IMP_CHECK_NCCL(ncclRecv(base + (size_t)row_lo[peer] * row_bytes, theirs, ncclChar, peer, c->comm, on));
+    if (mine) IMP_CHECK_NCCL(ncclSend(base + (size_t)row_lo[c->rank] * row_bytes, mine, ncclChar, peer, comm, on));
+    if (theirs) IMP_CHECK_NCCL(ncclRecv(base + (size_t)row_lo[peer] * row_bytes, theirs, ncclChar, peer, comm, on));
   }
   IMP_CHECK_NCCL(ncclGroupEnd());
 }
@@ -141,7 +164,7 @@ int imp_comm_allgather_rows(imp_comm *c, imp_matrix *full, const int64_t *row_of
     if (row_offsets[0] != 0 || (size_t)row_offsets[c->nranks] != full->rows)
       throw std::invalid_argument("row_offsets must span [0, rows] for allgather_rows");
     IMP_PROF("rccl_allgather_rows");
-    exchange_rows(c, full, row_offsets, row_offsets + 1, stream());  // shards may be ragged
+    exchange_rows(c, c->comm, full, row_offsets, row_offsets + 1, stream());  // shards may be ragged (library stream: first communicator)
     sync();
   });
 }
@@ -155,7 +178,7 @@ int imp_comm_allgather_rows_begin(imp_comm *c, imp_matrix *full, const int64_t *
         throw std::invalid_argument("row range outside the matrix in allgather_rows_begin");
     IMP_CHECK_HIP(hipEventRecord(c->solved, stream()));
     IMP_CHECK_HIP(hipStreamWaitEvent(c->xchg_stream, c->solved, 0));
-    exchange_rows(c, full, row_lo, row_hi, c->xchg_stream);
+    exchange_rows(c, c->xchg_comm, full, row_lo, row_hi, c->xchg_stream);  // its own communicator: never behind the gramian all-reduce
     c->pending = true;
   });
 }
@@ -167,6 +190,25 @@ int imp_comm_allgather_rows_end(imp_comm *c) {
     IMP_CHECK_HIP(hipEventRecord(c->exchanged, c->xchg_stream));
     IMP_CHECK_HIP(hipStreamWaitEvent(stream(), c->exchanged, 0));
     c->pending = false;
+  });
+}
+
+// Number of ranks the communicators actually connect: every rank contributes 1 to a sum all-reduce on each of the two (the
+// benchmark driver asserts it equals the world size it was launched with; a mis-wired rendezvous would otherwise "scale" by
+// running N independent replicas).  out[0]: the library stream's communicator, out[1]: the exchange stream's.
+int imp_comm_ranks_seen(imp_comm *c, int *out) {
+  return guarded([&] {
+    DeviceArray<float> one;
+    one.alloc(2);
+    const float ones[2] = {1.f, 1.f};
+    IMP_CHECK_HIP(hipMemcpyAsync(one.data(), ones, sizeof(ones), hipMemcpyHostToDevice, stream()));
+    IMP_CHECK_NCCL(ncclAllReduce(one.data(), one.data(), 1, ncclFloat, ncclSum, c->comm, stream()));
+    sync();  // (the second communicator's collective is queued only when the first one is done: no two in flight on one stream)
+    IMP_CHECK_NCCL(ncclAllReduce(one.data() + 1, one.data() + 1, 1, ncclFloat, ncclSum, c->xchg_comm, stream()));
+    float back[2];
+    IMP_CHECK_HIP(hipMemcpyAsync(back, one.data(), sizeof(back), hipMemcpyDeviceToHost, stream()));
+    sync();
+    out[0] = (int)(back[0] + 0.5f), out[1] = (int)(back[1] + 0.5f);
   });
 }
 

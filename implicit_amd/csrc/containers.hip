@@ -192,15 +192,16 @@ static void prof_flush() {
 // stream is joined to the ONE library stream before an entry point returns (class streams, exchange stream, occupy stream),
 // and the next user of a block queues its work behind that stream.
 static void flush_small_blocks() {
+  // only the CALLING thread's device: its lists are what a failed allocation on this device can get back, and it is the one
+  // device this thread may synchronise before the blocks go (kernels still in flight on it may touch a recycled block; another
+  // device's lists are left to that device's own out-of-memory path)
   std::vector<void *> blocks;
+  Context &c = ctx();
   {
-    std::lock_guard<std::mutex> lock(g_ctx_mutex);
-    for (auto &kv : g_contexts) {
-      std::lock_guard<std::mutex> g(kv.second->small_mutex);
-      for (auto &list : kv.second->small_free) {
-        blocks.insert(blocks.end(), list.begin(), list.end());
-        list.clear();
-      }
+    std::lock_guard<std::mutex> g(c.small_mutex);
+    for (auto &list : c.small_free) {
+      blocks.insert(blocks.end(), list.begin(), list.end());
+      list.clear();
     }
   }
   if (!blocks.empty()) (void)hipDeviceSynchronize();

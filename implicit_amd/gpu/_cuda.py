@@ -422,6 +422,13 @@ class Comm:
     def barrier(self):
         check(lib().imp_comm_barrier(self._h))
 
+    def ranks_seen(self):
+        """(ranks counted on the library stream's communicator, ranks counted on the exchange stream's): both must equal
+        `nranks`, else the rendezvous wired fewer processes together than were launched."""
+        out = (ctypes.c_int * 2)(0, 0)
+        check(lib().imp_comm_ranks_seen(self._h, out))
+        return int(out[0]), int(out[1])
+
     def __del__(self):
         if getattr(self, "_h", None):
             lib().imp_comm_destroy(self._h)

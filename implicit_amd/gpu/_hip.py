@@ -88,6 +88,7 @@ _SIGNATURES = {
     "imp_comm_alltoall_rows": [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
                                ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)],
     "imp_comm_barrier": [ctypes.c_void_p],
+    "imp_comm_ranks_seen": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)],
     "imp_prof_enable": [ctypes.c_int],
     "imp_prof_filter": [ctypes.c_char_p],
     "imp_prof_reset": [],

@@ -111,6 +111,7 @@ class AlternatingLeastSquares(MatrixFactorizationBase):
         # the four solver calls of an iteration are queued back to back (deferred mode) and waited for once: no host round
         # trip between a gramian and the sweep that uses it (-1 % per iteration at configs[2]; errors surface at that wait)
         gpu.set_deferred_sync(True)
+        fixups_before = gpu.fixup_rows(reset=False)
         try:
             for iteration in range(self.iterations):
                 t0 = time.time()
@@ -130,6 +131,13 @@ class AlternatingLeastSquares(MatrixFactorizationBase):
             if self.factors not in (64, 128, 256):
                 gpu.release_workspaces()  # the zero-padded factor copies: rows x F floats per side, not worth keeping
         progress.close()
+        # rows > 512 nonzeros run fp16-split operands on the matrix cores; an operand that leaves the fp16 range (very large
+        # confidences x alpha on un-normalised factors) sends its row to the one-wavefront fp32 kernel instead: correct, and
+        # ~1 ms per 4096-nonzero row -- a slowdown nobody would otherwise see
+        refits = gpu.fixup_rows(reset=False) - fixups_before
+        if refits > max(64, 0.001 * (users + items) * self.iterations):
+            log.warning("%d long-row solves of this fit were re-done by the fp32 fix-up kernel (operands beyond the fp16 range of "
+                        "the matrix-core path): scale the confidences (alpha) or the factors down, or expect slow iterations", refits)
         if self.calculate_training_loss:
             log.info("Final training loss %s", loss)
         self._check_fit_errors()

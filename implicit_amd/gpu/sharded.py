@@ -103,19 +103,73 @@ class GpuBackend:
         return M[int(start):int(stop)]
 
 
-def chunk_offsets(offsets, chunks):
-    """Cut every rank's row range [offsets[r], offsets[r+1]) into `chunks` pieces by row count; every rank computes
-    the same (nranks, chunks+1) table, which is what keeps the grouped send/recv of a chunk matched across ranks."""
+def default_chunks(nranks):
+    """Row chunks per half sweep of the pipelined exchange.  Only the LAST chunk's exchange is exposed (nothing is left to
+    solve beside it), so more ranks -- more bytes per rank to receive -- get more, smaller chunks; every chunk is a full set
+    of row-class launches (seven kernels), which bounds K from above.  IMP_SHARD_CHUNKS overrides."""
+    import os
+
+    if os.environ.get("IMP_SHARD_CHUNKS"):
+        return max(1, int(os.environ["IMP_SHARD_CHUNKS"]))
+    if nranks <= 1:
+        return 1
+    return 4 if nranks <= 4 else 6
+
+
+def chunk_fractions(chunks, ratio=None):
+    """Cumulative row fractions 0 = c_0 < c_1 < ... < c_K = 1 of the K chunks of a half sweep: sizes fall geometrically
+    (chunk k+1 = ratio x chunk k, default 0.75, IMP_SHARD_CHUNK_RATIO), so the LAST chunk -- the one whose exchange nothing
+    hides -- is the smallest: K = 4 leaves 15 % of the rows in it instead of 25 %, K = 6 leaves 7 % instead of 17 %."""
+    import os
+
+    if ratio is None:
+        ratio = float(os.environ.get("IMP_SHARD_CHUNK_RATIO", "0.75"))
+    ratio = min(1.0, max(0.25, ratio))
+    w = ratio ** np.arange(chunks, dtype=np.float64)
+    return np.concatenate([[0.0], np.cumsum(w) / w.sum()])
+
+
+def chunk_offsets(offsets, chunks, ratio=None):
+    """Cut every rank's row range [offsets[r], offsets[r+1]) into `chunks` pieces by row count (sizes as chunk_fractions);
+    every rank computes the same (nranks, chunks+1) table, which is what keeps the grouped send/recv of a chunk matched
+    across ranks."""
     offsets = np.asarray(offsets, dtype=np.int64)
     lens = np.diff(offsets)
-    k = np.arange(chunks + 1, dtype=np.int64)
-    return offsets[:-1, None] + (lens[:, None] * k[None, :]) // chunks
+    frac = chunk_fractions(chunks, ratio)
+    cuts = np.floor(lens[:, None] * frac[None, :] + 1e-9).astype(np.int64)
+    cuts[:, 0], cuts[:, -1] = 0, lens
+    cuts = np.maximum.accumulate(cuts, axis=1)
+    return offsets[:-1, None] + cuts
 
 
-def split_rows(C_shard, chunks):
+def split_rows(C_shard, chunks, ratio=None):
     """This rank's CSR rows cut the same way (scipy CSR in, list of scipy CSR out)."""
-    cuts = chunk_offsets([0, C_shard.shape[0]], chunks)[0]
+    cuts = chunk_offsets([0, C_shard.shape[0]], chunks, ratio)[0]
     return [C_shard[int(cuts[k]):int(cuts[k + 1])] for k in range(chunks)]
+
+
+def project_iteration_ms(half_sweep_compute_ms, half_sweep_recv_bytes, nranks, chunks=None, ratio=None, link_GBps=50.0,
+                         resident_rccl_cost=0.15):
+    """Model of one sharded iteration's wall time (what bench.py prints beside the optimistic bound): for every half sweep
+    the K chunks are solved one after the other -- compute x (1 + resident_rccl_cost) while RCCL's send / recv kernels hold
+    part of the device (measured +15 % with a stand-in resident kernel) -- and chunk k's rows travel over the mesh
+    while chunk k+1 is solved; an exchange starts when its chunk is solved AND the previous exchange is done; the half sweep
+    ends with the last exchange.  xGMI is a full mesh: a rank receives from its N-1 peers at once, one link each, so an
+    exchange takes (bytes received from ONE peer) / link rate.  `half_sweep_recv_bytes`: bytes a rank receives per half sweep
+    from all peers together.  Returns (modelled ms, ms if every exchange were hidden)."""
+    if chunks is None:
+        chunks = default_chunks(nranks)
+    frac = np.diff(chunk_fractions(chunks, ratio))
+    total = hidden = 0.0
+    for compute_ms, recv_bytes in zip(half_sweep_compute_ms, half_sweep_recv_bytes):
+        per_peer = recv_bytes / max(1, nranks - 1)
+        t = xchg_done = 0.0
+        for k in range(chunks):
+            t += compute_ms * frac[k] * (1.0 + (resident_rccl_cost if k > 0 and nranks > 1 else 0.0))
+            xchg_done = max(t, xchg_done) + 1e3 * per_peer * frac[k] / (link_GBps * 1e9)
+        total += max(t, xchg_done) if nranks > 1 else t
+        hidden += compute_ms
+    return total, hidden
 
 
 def allreduce_ints(comm, backend, values):
@@ -236,6 +290,71 @@ def iteration(backend, comm, Cui_shard, Ciu_shard, X_full, Y_full, u_offsets, i_
     half_sweep(backend, comm, Ciu_shard, Y_full, i_offsets, X_full, u_offsets, gram, reg, cg_steps)
 
 
+# ---- scheme (A): users sharded only, the item half sweep as a replicated-state distributed CG --------------------------------
+#
+# north_star's literal split (scheme A): rank g holds its users' rows and the transpose of THAT block,
+# Ciu_g = (Cui[U_g, :])^T (every item, local users only); Y, r, p live replicated on every rank.  One CG pass = a local
+# SPARSE-PARTIAL product (for every item, the sum over its LOCAL users) followed by an all-reduce of an I x f buffer, then the
+# dense per-row update, identical on every rank (XtX p from the all-reduced gramian, alpha, beta, the oracle's early exits as
+# per-row masks): 1 + cg_steps all-reduces of I x f per iteration instead of one all-gather of X.  What runs on the GPUs is
+# scheme (B) above (DESIGN.md section 6 has the byte counts and why); this is the alternative kept ONE KERNEL AWAY: the
+# driver, the exchange pattern and the row arithmetic below are complete and tested against the oracle over gloo
+# (tests/test_sharded_gloo.py::test_scheme_a_item_half_sweep_matches_the_oracle); `partial` is the one device kernel a GPU
+# version needs (the user kernels' gather-dot-axpy body with the output scattered per item instead of reduced per row).
+
+
+def scheme_a_sparse_partial(Ciu_local, X_mine, V, first):
+    """out[i] = sum over the LOCAL users u of item i of w_iu x_u, float32:
+       first pass : w = c+ - (|c| - 1) (x_u . v_i)      (implicit/cpu/_als.pyx:190-201, v = the iterate)
+       later      : w = (|c| - 1) (x_u . v_i)           (_als.pyx:214-222, v = the search direction)
+    numpy statement of the device kernel scheme (A) would need; rows of `Ciu_local` are items, columns local user ids."""
+    import scipy.sparse as sp
+
+    C = Ciu_local.tocsr()
+    rows = np.repeat(np.arange(C.shape[0]), np.diff(C.indptr))
+    c = C.data.astype(np.float32)
+    d = np.einsum("ij,ij->i", V[rows].astype(np.float32), X_mine[C.indices].astype(np.float32)).astype(np.float32)
+    cm1 = np.abs(c) - np.float32(1.0)
+    w = (np.maximum(c, np.float32(0.0)) - cm1 * d) if first else cm1 * d
+    W = sp.csr_matrix((w.astype(np.float32), C.indices, C.indptr), shape=C.shape)
+    return np.asarray(W @ X_mine, dtype=np.float32)
+
+
+def scheme_a_item_half_sweep(comm, Ciu_local, X_mine, Y_full, gram, cg_steps, item_nnz_global, partial=scheme_a_sparse_partial):
+    """One item half sweep under scheme (A).  `gram` = XtX + reg I, already all-reduced; `item_nnz_global[i]` = nonzeros of
+    item i over ALL ranks (rows without any are zeroed, _als.pyx:182-184); Y_full (numpy float32, replicated) is updated in
+    place and ends identical on every rank.  1 + cg_steps all-reduces of an I x f float32 buffer through
+    `comm.allreduce_sum`."""
+    f32 = np.float32
+    Y = Y_full
+    empty = np.asarray(item_nnz_global) == 0
+    S = np.ascontiguousarray(partial(Ciu_local, X_mine, Y, True), dtype=f32)
+    comm.allreduce_sum(S)
+    r = (S - Y @ gram.T.astype(f32)).astype(f32)          # r = -A0 y + sum (c+ - (|c|-1) y.x) x
+    p = r.copy()
+    rsold = np.einsum("ij,ij->i", r, r).astype(f32)
+    active = (~empty) & (rsold >= f32(1e-20))             # rsold < 1e-20: the row keeps its iterate (_als.pyx:206)
+    x = Y.copy()
+    for _ in range(cg_steps):
+        S = np.ascontiguousarray(partial(Ciu_local, X_mine, p, False), dtype=f32)
+        comm.allreduce_sum(S)                             # every rank takes part in every pass, whatever its rows' state
+        Ap = (p @ gram.T.astype(f32) + S).astype(f32)
+        pAp = np.einsum("ij,ij->i", p, Ap).astype(f32)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            alpha = np.where(active, rsold / pAp, f32(0.0)).astype(f32)
+        x = np.where(active[:, None], x + alpha[:, None] * p, x).astype(f32)
+        r = np.where(active[:, None], r - alpha[:, None] * Ap, r).astype(f32)
+        rsnew = np.einsum("ij,ij->i", r, r).astype(f32)
+        cont = active & (rsnew >= f32(1e-20))             # rsnew < 1e-20: break (_als.pyx:235)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            beta = np.where(cont, rsnew / rsold, f32(0.0)).astype(f32)
+        p = np.where(cont[:, None], r + beta[:, None] * p, p).astype(f32)
+        rsold = np.where(cont, rsnew, rsold).astype(f32)
+        active = cont
+    x[empty] = 0.0
+    Y[...] = x
+
+
 # ---- model-level entry: AlternatingLeastSquares(..., comm=...).fit ------------------------------------------------------
 
 
@@ -261,7 +380,7 @@ def fit_sharded(model, Cui_rows, comm, callback=None, chunks=None, backend=None,
         if X.shape[0] != u_off[-1] or Y.shape[0] != Cui_rows.shape[1]:
             raise ValueError("user_factors / item_factors do not match the global matrix the shards add up to")
         if chunks is None:
-            chunks = 4 if n > 1 else 1
+            chunks = default_chunks(n)
         if chunks > 1:
             Cu = [csr(c) for c in split_rows(Cui_rows, chunks)]
             Ci = [csr(c) for c in split_rows(mine_i, chunks)]
@@ -359,6 +478,11 @@ def bench(args, gpu, shapes, factors, reg, cg_steps, roofline_fn=None):
 
     rank, world, local_rank = rendezvous.env_world()
     comm = rendezvous.init_comm(gpu, rank, world, local_rank)
+    # both communicators (library stream / exchange stream) must connect exactly the ranks the launcher started: N processes
+    # that each found only themselves would "scale" as N independent replicas
+    ranks_seen = comm.ranks_seen() if hasattr(comm, "ranks_seen") else (world, world)
+    if tuple(ranks_seen) != (world, world):
+        raise RuntimeError(f"bench.py --gpus {world}: RCCL connects {ranks_seen} ranks (library / exchange communicator), expected {world}")
     t0 = time.time()
     if args.weak:
         users, items, nnz_target, gamma = shapes[args.shape]
@@ -383,7 +507,7 @@ def bench(args, gpu, shapes, factors, reg, cg_steps, roofline_fn=None):
     no_iter_fence = bool(os.environ.get("IMP_SHARD_NO_ITER_FENCE"))
     # K row chunks per half sweep: chunk k is exchanged over xGMI while chunk k+1 is solved (one chunk = blocking form)
     pipelined = world > 1 or os.environ.get("IMP_FORCE_SHARDED")
-    chunks = max(1, int(os.environ.get("IMP_SHARD_CHUNKS", "4"))) if pipelined else 1
+    chunks = (default_chunks(world) if world > 1 else max(1, int(os.environ.get("IMP_SHARD_CHUNKS", "4")))) if pipelined else 1
     if chunks > 1:
         Cui_d = [gpu.CSRMatrix(c) for c in split_rows(Cui, chunks)]
         Ciu_d = [gpu.CSRMatrix(c) for c in split_rows(Ciu, chunks)]
@@ -433,7 +557,7 @@ def bench(args, gpu, shapes, factors, reg, cg_steps, roofline_fn=None):
     compute_ms = float(sum(ms for name, ms in kernels.items() if not name.startswith("rccl") and name != "als_cg_half_sweep"))
     step_s = elapsed / args.steps
     result = {
-        "metric": "ALS user+item updates/sec per iteration (factors=128)",
+        "metric": "ALS user+item updates/sec per iteration (factors=128); top-k recs/sec",
         "value": (users_total + items_total) / step_s,
         "unit": "updates/s",
         "n_gpus": world,
@@ -452,6 +576,7 @@ def bench(args, gpu, shapes, factors, reg, cg_steps, roofline_fn=None):
             "parallelism": f"row-sharded x{world}, RCCL all-reduce(f x f) + all-gather(factor shards) pipelined in "
                            f"{chunks} row chunk(s) per half sweep",
         },
+        "rccl_ranks_seen": list(ranks_seen),
         "nnz_visits_per_s": 2 * int(total_nnz) / step_s,
         "roofline": roofline_fn(Cui, Ciu, timed, args.steps) if (roofline_fn and rank == 0) else None,
         "kernels_ms_per_step_rank0": kernels,

@@ -205,6 +205,10 @@ int imp_comm_allgather_rows_end(imp_comm *c);
 int imp_comm_alltoall_rows(imp_comm *c, const imp_matrix *send, const int64_t *send_lo, const int64_t *send_hi,
                            imp_matrix *recv, const int64_t *recv_lo, const int64_t *recv_hi);
 int imp_comm_barrier(imp_comm *c);
+/* out[0], out[1]: the number of ranks a one-per-rank sum all-reduce counts on the communicator of the library stream and on the
+ * second communicator the pipelined exchange (allgather_rows_begin) runs on -- RCCL serialises the operations of one
+ * communicator, so the gramian all-reduce and the row exchange never share one.  The benchmark driver asserts both == N. */
+int imp_comm_ranks_seen(imp_comm *c, int *out);
 
 /* ---- NEW: measurement hooks (bench.py's roofline leg) -------------------------------------------- */
 /* When enabled every kernel launch is bracketed by HIP events on the library stream; totals are
