@@ -82,6 +82,49 @@ def test_cg_cold_sweep_vs_fp64(gpu, oracle, f):
     assert e_gpu < max(TOL, 2.0 * e_oracle)
 
 
+# every cut of the row schedule from both sides (and the cuts of round 6's experiment with team widths 3 and 5, 96 and 160
+# nonzeros: measured slower, not kept -- DESIGN 4.1) with several rows per length so that teams of one workgroup get rows of
+# different lengths
+TEAM_EDGE_LENGTHS = [30, 32, 33, 40, 63, 64, 65, 66, 80, 93, 95, 96, 97, 100, 127, 128, 129, 130, 144, 157, 159, 160, 161, 162, 200, 255,
+                     256, 257, 300, 511, 512, 513, 0]
+
+
+def _edge_matrix(lengths, items, seed, neg_frac=0.1):
+    rng = np.random.default_rng(seed)
+    indptr, indices, data = [0], [], []
+    for n in lengths:
+        cols = np.sort(rng.choice(items, size=n, replace=False))
+        c = 1 + 4 * rng.random(n)
+        c[rng.random(n) < neg_frac] *= -1
+        indices.append(cols)
+        data.append(c)
+        indptr.append(indptr[-1] + n)
+    return sp.csr_matrix((np.concatenate(data).astype(np.float32), np.concatenate(indices).astype(np.int32), np.array(indptr)),
+                         shape=(len(lengths), items))
+
+
+@pytest.mark.parametrize("cg_steps", [1, 3])
+@pytest.mark.parametrize("f", [128, 64])
+def test_team_width_boundaries_row_by_row(gpu, oracle, f, cg_steps):
+    """Per-ROW parity (1e-4 each: a wrong share of the gramian rows or of the entries in ONE team would hide in a Frobenius norm)
+    at every cut of the schedule.  Reference: implicit/gpu/als.cu:23-111 == implicit/cpu/_als.pyx:152-248."""
+    items = 3000
+    lengths = TEAM_EDGE_LENGTHS * 7   # 7 rows per length: more rows than teams in a workgroup, a ragged last round
+    C = _edge_matrix(lengths, items, seed=f + cg_steps)
+    rng = np.random.default_rng(11)
+    Y = ((rng.random((items, f), dtype=np.float32) - 0.5) * 0.2).astype(np.float32)
+    X = ((rng.random((C.shape[0], f), dtype=np.float32) - 0.5) * 0.2).astype(np.float32)
+    want = X.copy()
+    oracle.least_squares_cg(C, want, Y, 0.05, cg_steps=cg_steps)
+    got, _ = _gpu_cg(gpu, C, X.copy(), Y, 0.05, cg_steps)
+    num = np.linalg.norm(got.astype(np.float64) - want, axis=1)
+    err = num / np.maximum(np.linalg.norm(want.astype(np.float64), axis=1), 1e-30)
+    print("f", f, "cg", cg_steps, "per-row rel max %.2e" % err.max(), "at length", lengths[int(err.argmax())])
+    assert err.max() < TOL
+    empty = np.asarray(lengths) == 0
+    assert not got[empty].any()
+
+
 def test_cg_long_rows_and_edge_cases(gpu, oracle):
     """Rows long enough for the workgroup-per-row class, empty rows, explicit zeros, negatives."""
     rng = np.random.default_rng(3)
