@@ -74,8 +74,12 @@ def build_variant(tag, defines, sources=("als_cg_qf.hip",)):
 
 
 if __name__ == "__main__":
-    if "--variant" in sys.argv:  # python -m implicit_amd._build --variant TAG DEFINE [DEFINE ...]
+    if "--variant" in sys.argv:  # python -m implicit_amd._build --variant TAG [--sources a.hip,b.hip] DEFINE [DEFINE ...]
         i = sys.argv.index("--variant")
-        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
+        rest = sys.argv[i + 2:]
+        sources = ("als_cg_qf.hip",)
+        if rest and rest[0] == "--sources":
+            sources, rest = tuple(rest[1].split(",")), rest[2:]
+        print(build_variant(sys.argv[i + 1], rest, sources))
     else:
         build(force="--force" in sys.argv)

@@ -118,6 +118,7 @@ struct Storage {
   // stream -- is ordered behind its last.  The lists are a cache: an allocation that fails empties them and retries.
   Context *home = nullptr;
   int size_class = -1;
+  bool exposed = false;  // the address left the library (imp_matrix_device_ptr): writes to it can no longer be tracked
   static constexpr size_t kSmallMax = (size_t)4 << 20;
   Storage(size_t bytes_, bool zero);
   Storage(void *foreign) : ptr(foreign), owned(false) {}
@@ -205,6 +206,16 @@ struct ClassStreams {
 // lives (device addresses are unique across the devices of a process; a Storage may die on a thread whose current device is
 // not the one that made the copy).  containers.hip.
 void note_device_write(const void *dst, size_t bytes);
+// Something derived from device memory the library owns and kept across calls (the fragment-ordered fp16 planes of an item
+// matrix in a KnnQuery handle, topk.hip): `src` / `bytes` name what it was made from; note_device_write clears `src` of every
+// registered cache the written range overlaps.  Holds for memory only the library writes: a Storage whose address was handed
+// out (imp_matrix_device_ptr) or that wraps foreign memory (imp_matrix_wrap_device) is `exposed` and never cached from.
+struct DerivedCache {
+  const void *src = nullptr;
+  size_t bytes = 0;
+};
+void register_derived_cache(DerivedCache *c);
+void unregister_derived_cache(DerivedCache *c);
 
 }  // namespace imp
 

@@ -42,9 +42,23 @@ Context &ctx() {
   return *it->second;
 }
 
+static auto &g_derived = *new std::vector<DerivedCache *>;  // (leaked like the contexts; guarded by g_ctx_mutex)
+void register_derived_cache(DerivedCache *c) {
+  std::lock_guard<std::mutex> lock(g_ctx_mutex);
+  g_derived.push_back(c);
+}
+void unregister_derived_cache(DerivedCache *c) {
+  std::lock_guard<std::mutex> lock(g_ctx_mutex);
+  g_derived.erase(std::remove(g_derived.begin(), g_derived.end(), c), g_derived.end());
+}
+
 void note_device_write(const void *dst, size_t bytes) {
   const char *a = static_cast<const char *>(dst);
   std::lock_guard<std::mutex> lock(g_ctx_mutex);
+  for (DerivedCache *d : g_derived) {
+    const char *b = static_cast<const char *>(d->src);
+    if (b && a < b + d->bytes && b < a + bytes) d->src = nullptr;
+  }
   for (auto &kv : g_contexts) {
     Context &c = *kv.second;
     if (!c.pad_y_src) continue;
@@ -745,7 +759,10 @@ int imp_matrix_shape(const imp_matrix *m, size_t *rows, size_t *cols, size_t *it
 }
 
 int imp_matrix_device_ptr(const imp_matrix *m, void **ptr) {
-  return guarded([&] { *ptr = m->data; });
+  return guarded([&] {
+    *ptr = m->data;
+    if (m->storage) m->storage->exposed = true;  // whoever holds the address may write through it: nothing derived from this memory is cached
+  });
 }
 
 int imp_matrix_destroy(imp_matrix *m) {

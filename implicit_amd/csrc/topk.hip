@@ -281,7 +281,7 @@ struct EmitArgs {
   uint64_t *cand;             // [nq][cap]
   unsigned int *count;        // [nq]
   int cap;
-  const unsigned *maxbits;    // fp16 form only: bits of the largest query / sampled item magnitude (topk_absmax_kernel)
+  float *row_unscale;         // [nq] resident form: the keys carry raw accumulators; factor that turns a row's into scores (else null)
 };
 
 // TQ / TI: storage type of the query / item factors (float or __half).  fp16 factors are read as they are stored and
@@ -333,124 +333,12 @@ __global__ void split_query_rows_kernel(const T *__restrict__ Q, __bf16 *__restr
   }
 }
 
-// H2 (round 5; fp32 factors on the emit path, default): two fp16 terms per operand value instead of three bf16 terms, THREE partial
-// products (l h, h l, h h; the dropped l l is 2^-22 of the product) instead of six on v_mfma_f32_32x32x16_f16 -- the matrix pipe's
-// share of the emit GEMM was 0.17 of its 0.42 ms and did not overlap the operand traffic.  fp16 has 5 exponent bits, so both
-// operands are scaled by a power of two per call (exact, taken out again in the epilogue): the queries by the batch's largest
-// magnitude, the items by the largest magnitude of every 16th row (a full pass over the items would cost 30 us of a 500 us call),
-// both brought to [2^11, 2^12) -- values down to 2^-14 of the largest keep 22 bits, smaller ones an ABSOLUTE error of 2^-25 of
-// the scaled unit.  An item value more than 16 x above the sampled maximum overflows fp16: its high half is an infinity, its
-// low half the opposite one, and every score it takes part in is a NaN (h h and h l are infinities of opposite sign, or 0 x
-// inf) -- the emit epilogue passes NaNs on as +inf candidates, the threshold pass stores them as +inf, and select_candidates
-// hands a row whose best candidate is not finite to the materialising path, which keeps the six-product form.
-// IMP_TOPK_BF16X3=1 keeps the six-product form everywhere (A/B, switch test).
-typedef _Float16 tk_f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 tk_f16x2 __attribute__((ext_vector_type(2)));
-typedef float tk_f32x2 __attribute__((ext_vector_type(2)));
-struct split_f16 {
-  _Float16 v;
-};
 template <typename TQ> struct presplit {
   static constexpr int terms = 0;
 };
 template <> struct presplit<split_bf16> {
   static constexpr int terms = 3;
 };
-template <> struct presplit<split_f16> {
-  static constexpr int terms = 2;
-};
-// 2^k with k = 11 - exponent(largest magnitude), clamped to +-60 (an all-zero or non-finite operand: whatever comes out is
-// what the guard above catches)
-__device__ __forceinline__ int h2_scale_exp(unsigned maxbits) { return max(-60, min(60, 11 - ((int)(maxbits >> 23) - 127))); }
-__device__ __forceinline__ float h2_pow2(int k) { return __uint_as_float((unsigned)(k + 127) << 23); }
-__device__ __forceinline__ void split8_f16(const float4 &v0, const float4 &v1, float s, tk_f16x8 &h, tk_f16x8 &l) {
-  const tk_f32x2 x[4] = {{v0.x * s, v0.y * s}, {v0.z * s, v0.w * s}, {v1.x * s, v1.y * s}, {v1.z * s, v1.w * s}};
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const tk_f16x2 hi = __builtin_convertvector(x[e], tk_f16x2);
-    const tk_f16x2 lo = __builtin_convertvector(x[e] - __builtin_convertvector(hi, tk_f32x2), tk_f16x2);
-    h[2 * e] = hi[0], h[2 * e + 1] = hi[1], l[2 * e] = lo[0], l[2 * e + 1] = lo[1];
-  }
-}
-// largest magnitudes: out[0] of the query values, out[1] of every 16th item row (as the bits of a non-negative float: unsigned
-// order is value order).  One launch, no reset: every workgroup leaves its pair in out[4 + 2 b ..], the last one to arrive at the
-// counter out[2] (zero at rest) folds them and puts the counter back (a memset + per-wavefront atomics cost 55 us of a 500 us call).
-constexpr int kAbsmaxBlocks = 256;
-template <typename TQ, typename TI>
-__global__ __launch_bounds__(1024) void topk_absmax_kernel(const TQ *__restrict__ Q, size_t nq_vals, const TI *__restrict__ I, size_t ni, int f,
-                                                          unsigned *__restrict__ out) {
-  const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
-  float mq = 0.f, mi = 0.f;
-  for (size_t i = tid; i < nq_vals; i += nth) mq = fmaxf(mq, fabsf((float)Q[i]));
-  // a sampled item row per wavefront and turn (a flat index cost a 64-bit division per value)
-  const int lane = threadIdx.x & 63;
-  const size_t nw = nth >> 6;
-  for (size_t r0 = (tid >> 6) * 16; r0 < ni; r0 += nw * 64) {  // four rows in flight: the loop is latency, not bandwidth
-    for (int c = lane; c < f; c += 64) {
-      float v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const size_t row = r0 + j * nw * 16;
-        v[j] = row < ni ? (float)I[row * (size_t)f + c] : 0.f;
-      }
-      mi = fmaxf(fmaxf(mi, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-    }
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    mq = fmaxf(mq, __shfl_xor(mq, off, 64));
-    mi = fmaxf(mi, __shfl_xor(mi, off, 64));
-  }
-  __shared__ float red[2][16];  // (16 wavefronts: the sample is latency, so many of them with few rows each)
-  __shared__ bool last;
-  const int wave = threadIdx.x >> 6;
-  if (lane == 0) red[0][wave] = mq, red[1][wave] = mi;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    mq = mi = 0.f;
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) mq = fmaxf(mq, red[0][w]), mi = fmaxf(mi, red[1][w]);
-    __hip_atomic_store(out + 4 + 2 * blockIdx.x, __float_as_uint(mq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(out + 5 + 2 * blockIdx.x, __float_as_uint(mi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    last = __hip_atomic_fetch_add(out + 2, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
-  }
-  __syncthreads();
-  if (!last) return;
-  unsigned bq = 0, bi = 0;
-  if (threadIdx.x < gridDim.x) {
-    bq = __hip_atomic_load(out + 4 + 2 * threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    bi = __hip_atomic_load(out + 5 + 2 * threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    bq = max(bq, (unsigned)__shfl_xor((int)bq, off, 64));
-    bi = max(bi, (unsigned)__shfl_xor((int)bi, off, 64));
-  }
-  __shared__ unsigned redu[2][16];
-  if (lane == 0) redu[0][wave] = bq, redu[1][wave] = bi;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned fq = 0u, fi = 0u;
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) fq = max(fq, redu[0][w]), fi = max(fi, redu[1][w]);
-    out[0] = fq, out[1] = fi;
-    __hip_atomic_store(out + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-template <typename T>
-__global__ void split_query_rows_f16_kernel(const T *__restrict__ Q, _Float16 *__restrict__ out, size_t rows, size_t rows_pad, int f,
-                                            const unsigned *__restrict__ maxbits) {
-  const size_t n = rows_pad * (size_t)f;
-  const int steps16 = f / 16;
-  const float s = h2_pow2(h2_scale_exp(maxbits[0]));
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t q = i / f;
-    const int c = (int)(i - q * f);
-    const float x = q < rows ? (float)Q[i] * s : 0.f;
-    const _Float16 hi = (_Float16)x;
-    const int lane = (int)(q & 31) + 32 * ((c >> 3) & 1);
-    _Float16 *o = out + ((((q >> 5) * steps16 + (c >> 4)) * 2) * 64 + lane) * 8 + (c & 7);
-    o[0] = hi, o[64 * 8] = (_Float16)(x - (float)hi);
-  }
-}
 
 // four consecutive factors as they are stored, and their fp32 values
 template <typename T> struct raw4 {
@@ -469,9 +357,6 @@ __device__ __forceinline__ float4 widen4(const uint2 &raw) {
   return make_float4(a.x, a.y, b.x, b.y);
 }
 
-#ifndef IMP_TOPK_KO
-#define IMP_TOPK_KO 0  // timing-only knock-outs of the fp16 form (build variants, wrong results): 1 no MFMAs, 2 no item DMA, 4 no query
-#endif                 // DMA, 8 no low halves of the items (one conversion per value), 16 no epilogue (profiles/scripts/r5u_topk_ko.sh)
 #ifndef IMP_TOPK_MIN_WAVES
 #define IMP_TOPK_MIN_WAVES 3  // waves per SIMD the register allocation leaves room for (split-bf16 emit GEMM at C3: 2 waves 0.83 ms, 3: 0.73, 4: 0.80)
 #endif
@@ -486,7 +371,6 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
   const int i_base = (MODE == 1 ? blockIdx.x * block_stride : blockIdx.x) * 128 + 64 * (wave & 1);
   constexpr bool QS = presplit<TQ>::terms > 0;  // query rows already split, in fragment order: 3 bf16 or 2 fp16 terms per value
   constexpr int NT = QS ? presplit<TQ>::terms : 3;
-  constexpr bool H2 = std::is_same<TQ, split_f16>::value;  // the fp16 form: items split here, scaled; three products
   static_assert(!QS || BF3, "split query rows feed the matrix-core forms only");
   f32x16 acc[2][2];
 #pragma unroll
@@ -534,7 +418,6 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
     auto dma = [&](int buf, int s16) {
 #pragma unroll
       for (int i = 0; i < NQ_W; ++i) {
-        if (H2 && (IMP_TOPK_KO & 4)) break;
         const unsigned char *src = reinterpret_cast<const unsigned char *>(qsrc[i]) + (QS ? (size_t)s16 * NT * 1024 : (size_t)s16 * 16 * sizeof(TQ));
         const int slot = QS ? wave * NT + i : wave + 4 * i;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
@@ -542,7 +425,6 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
       }
 #pragma unroll
       for (int i = 0; i < NI_W; ++i)
-        if (!(H2 && (IMP_TOPK_KO & 2)))
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(isrc[i] + 16 * s16),
                                          (__attribute__((address_space(3))) void *)&stage[buf][Q_BYTES + (wave + 4 * i) * 1024], 16, 0, 0);
     };
@@ -572,7 +454,7 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
       float4 ra[2][2], rb[2][2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        if constexpr (QS && !H2) {
+        if constexpr (QS) {
           ah[t] = *reinterpret_cast<const tk_bf16x8 *>(base + q_off[t]);
           am[t] = *reinterpret_cast<const tk_bf16x8 *>(base + q_off[t] + 1024);
           al[t] = *reinterpret_cast<const tk_bf16x8 *>(base + q_off[t] + 2048);
@@ -602,74 +484,14 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
           }
       };
     };
-    float item_scale = 1.f;
-    if constexpr (H2) item_scale = h2_pow2(h2_scale_exp(emit.maxbits[1]));
-    auto multiply16_h2 = [&](int buf) {
-      const unsigned char *base = &stage[buf][0];
-      tk_f16x8 ah[2], al[2], bh[2], bl[2];
-      float4 rb[2][2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        ah[t] = *reinterpret_cast<const tk_f16x8 *>(base + q_off[t]);
-        al[t] = *reinterpret_cast<const tk_f16x8 *>(base + q_off[t] + 1024);
-        read_rows(base, i_off[t], CHI, rb[t][0], rb[t][1]);
-      }
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        split8_f16(rb[t][0], rb[t][1], item_scale, bh[t], bl[t]);
-        if (IMP_TOPK_KO & 8) bl[t] = bh[t];
-      }
-      return [=](auto &accr) {
-        if (IMP_TOPK_KO & 1) {  // operands kept alive, nothing multiplied
-#pragma unroll
-          for (int t = 0; t < 2; ++t) asm volatile("" ::"v"(ah[t]), "v"(al[t]), "v"(bh[t]), "v"(bl[t]));
-          return;
-        }
-#pragma unroll
-        for (int tq = 0; tq < 2; ++tq)
-#pragma unroll
-          for (int ti = 0; ti < 2; ++ti) {
-            f32x16 c = accr[tq][ti];
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tq], bh[ti], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tq], bl[ti], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tq], bh[ti], c, 0, 0, 0);
-            accr[tq][ti] = c;
-          }
-      };
-    };
     const int steps16 = f / 16;
     dma(0, 0);
     for (int s16 = 0; s16 < steps16; ++s16) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of step s16 have landed ...
       __syncthreads();                                   // ... and so have everybody else's
-      if constexpr (H2) {
-        auto products = multiply16_h2(s16 & 1);
-        if (s16 + 1 < steps16) dma((s16 + 1) & 1, s16 + 1);
-        products(acc);
-      } else {
-        auto products = multiply16(s16 & 1);             // fragments out of LDS, splits
-        if (s16 + 1 < steps16) dma((s16 + 1) & 1, s16 + 1);
-        products(acc);
-      }
-    }
-    if constexpr (H2) {  // the operands' scales out again (a power of two: exact); a NaN is an overflowed operand (see H2 above)
-      const float unscale = h2_pow2(-h2_scale_exp(emit.maxbits[0]) - h2_scale_exp(emit.maxbits[1]));
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const float v = acc[a][b][e] * unscale;
-            acc[a][b][e] = MODE == 1 ? (v == v ? v : INFINITY) : v;
-          }
-      if (MODE == 2 && (IMP_TOPK_KO & 16)) {
-        float sink = 0.f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) sink += acc[0][0][e] + acc[0][1][e] + acc[1][0][e] + acc[1][1][e];
-        if (sink == 1.2345e-33f) emit.count[0] = 1u;
-        return;
-      }
+      auto products = multiply16(s16 & 1);             // fragments out of LDS, splits
+      if (s16 + 1 < steps16) dma((s16 + 1) & 1, s16 + 1);
+      products(acc);
     }
   } else {
   // 8 factors per step; the operands of step s + 1 are requested before the 16 MFMAs of step s (two register sets), so
@@ -779,7 +601,7 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
           for (int ti = 0; ti < 2; ++ti) {
             float sc = acc[tq][ti][e];
             if (!(sc < tf)) {
-              if (!(sc == sc)) sc = INFINITY;  // (the fp16 form's overflow guard: select_candidates sends the row to the exact path)
+              if (!(sc == sc)) sc = INFINITY;  // (a NaN operand: select_candidates sends the row to the materialising path)
               const int item = i_base + 32 * ti + r;
               if (q < nq && item < ni && ordered(sc) >= t) {
                 const uint32_t bit = 1u << (item & 31);
@@ -836,6 +658,8 @@ __global__ __launch_bounds__(256, IMP_TOPK_MIN_WAVES) void score_gemm_direct_ker
       if (r == 0 && q < nq && tile < n_tiles) tile_max[(size_t)q * n_tiles + tile] = m;
     }
 }
+
+#include "topk_resident.h"  // the fp16 two-term form: queries resident in registers, cached item planes (round 6)
 
 // After the filter scatters: recompute the maximum of every 64-item tile a filter touched (one thread per filter entry;
 // several entries of one tile write the same value).  Keeps tau = the k-th largest tile maximum a valid AND tight lower
@@ -1134,9 +958,10 @@ template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void select_candidates_kernel(const uint64_t *__restrict__ gcand, const unsigned int *__restrict__ count,
                                                                   int cap, int k, int32_t *__restrict__ out_ids,
                                                                   float *__restrict__ out_dist, int out_stride,
-                                                                  int *__restrict__ fallback) {
+                                                                  int *__restrict__ fallback, const float *__restrict__ row_unscale) {
   __shared__ uint64_t cand[kEmitCap];
   const int tid = threadIdx.x, q = blockIdx.x;
+  const float unscale_q = row_unscale ? row_unscale[q] : 1.f;  // (a power of two: exact)
   const unsigned int n_c = count[q];
   if (n_c > (unsigned)cap || n_c < (unsigned)k) {  // uniform
     if (tid == 0) fallback[q] = 1;
@@ -1172,7 +997,7 @@ __global__ __launch_bounds__(BLOCK) void select_candidates_kernel(const uint64_t
     for (int i = tid; i < k; i += BLOCK) {
       uint64_t key = cand[i];
       out_ids[(size_t)q * out_stride + i] = (int32_t)(uint32_t)key;
-      out_dist[(size_t)q * out_stride + i] = unordered((uint32_t)(key >> 32));
+      out_dist[(size_t)q * out_stride + i] = unordered((uint32_t)(key >> 32)) * unscale_q;
     }
     return;
   }
@@ -1219,7 +1044,7 @@ __global__ __launch_bounds__(BLOCK) void select_candidates_kernel(const uint64_t
     if (slot >= 0 && slot < k) {
       const uint64_t key = cand[i];
       out_ids[(size_t)q * out_stride + slot] = (int32_t)(uint32_t)key;
-      out_dist[(size_t)q * out_stride + slot] = unordered((uint32_t)(key >> 32));
+      out_dist[(size_t)q * out_stride + slot] = unordered((uint32_t)(key >> 32)) * unscale_q;
     }
   }
 }
@@ -1310,8 +1135,22 @@ struct imp_knn {
   DeviceArray<float> sub_scores, fb_query, fb_dist;
   DeviceArray<float> pad_items, pad_query;  // zero-padded fp32 copies for factor counts that are not a multiple of 16
   DeviceArray<split_bf16> query_split;      // [nq][3][f] bf16 (or [nq][2][f] fp16) terms of the query rows (emit path, split forms)
-  DeviceArray<unsigned> h2_max;             // fp16 form: bits of the largest query / sampled item magnitude of the call
-  bool h2_off = false;                      // fp16 form given up for this handle (see the emit path)
+  // fp16 two-term form (topk_resident.h): the item matrix as fragment-ordered planes, made once per catalogue VERSION -- `key`
+  // names the memory they were made from and is cleared by any write to it through the library (note_device_write); memory the
+  // library cannot vouch for (wrapped foreign pointers, matrices whose address was handed out) is split again on every call
+  struct ItemPlanes {
+    DerivedCache key;
+    DeviceArray<_Float16> planes;
+    DeviceArray<int> exp;          // scale exponent of the item matrix (from its exact maximum)
+    DeviceArray<unsigned> maxbits;
+    size_t rows = 0, cols = 0, itemsize = 0;
+    int KS = 0;
+    ItemPlanes() { register_derived_cache(&key); }
+    ~ItemPlanes() { unregister_derived_cache(&key); }
+  } item_planes;
+  DeviceArray<_Float16> query_planes;
+  DeviceArray<int> query_exp;
+  DeviceArray<float> row_unscale;  // per row of an emit batch: what turns the raw accumulators its candidate keys carry into scores
   DeviceArray<uint32_t> tau, row_bits, item_bits;
   DeviceArray<unsigned int> cand_count;
   DeviceArray<uint64_t> cand;
@@ -1488,6 +1327,37 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
       using TQ = std::remove_cv_t<std::remove_pointer_t<decltype(Qb)>>;
       using TI = std::remove_cv_t<std::remove_pointer_t<decltype(Ib)>>;
       constexpr bool BF3 = decltype(Bf3c)::value;
+    // fp16 two-term planes for the resident-query kernels (topk_resident.h): the item matrix once per catalogue version (cached in
+    // the handle), the query rows of this call with one scale per row
+    auto prepare_planes = [&](int KS, const _Float16 *&iplanes, const int *&iexp, const _Float16 *&qplanes, const int *&qexp) {
+        IMP_PROF("split_query_rows");
+        auto &ip = knn->item_planes;
+        const size_t ni_pad = (ni + 127) / 128 * 128, F = (size_t)KS * 16;
+        const bool same = ip.key.src == items_in->data && ip.rows == ni && ip.cols == (size_t)f_in && ip.itemsize == items_in->itemsize && ip.KS == KS;
+        if (!same) {
+          ip.key.src = nullptr;
+          if (ip.planes.size < ni_pad * F * 2) ip.planes.alloc(ni_pad * F * 2);
+          if (ip.exp.size < 1) ip.exp.alloc(1), ip.maxbits.alloc(1);
+          IMP_CHECK_HIP(hipMemsetAsync(ip.maxbits.data(), 0, sizeof(unsigned), stream()));
+          const int g1 = (int)std::max<size_t>(1, std::min<size_t>((ni * (size_t)f + 255) / 256, (size_t)ctx().num_cus * 8));
+          rq_absmax_kernel<TI><<<g1, 256, 0, stream()>>>(Ib, ni * (size_t)f, ip.maxbits.data());
+          rq_item_exp_kernel<<<1, 1, 0, stream()>>>(ip.maxbits.data(), ip.exp.data());
+          const int g2 = (int)std::max<size_t>(1, std::min<size_t>((ni_pad * (F / 8) + 255) / 256, (size_t)ctx().num_cus * 16));
+          rq_split_items_kernel<TI><<<g2, 256, 0, stream()>>>(Ib, ip.planes.data(), ni, ni_pad, f, KS, ip.exp.data());
+          ip.rows = ni, ip.cols = (size_t)f_in, ip.itemsize = items_in->itemsize, ip.KS = KS;
+          const bool trusted = items_in->storage && items_in->storage->owned && !items_in->storage->exposed;
+          if (trusted) ip.key.src = items_in->data, ip.key.bytes = items_in->bytes();
+        }
+        iplanes = ip.planes.data(), iexp = ip.exp.data();
+        const size_t nq_pad = rq_query_pad(nq);
+        _Float16 *qp = imp_knn::ensure(knn->query_planes, nq_pad * F * 2);
+        int *qe = imp_knn::ensure(knn->query_exp, nq_pad);
+        rq_split_queries_kernel<TQ><<<(int)std::min<size_t>((nq_pad + 3) / 4, (size_t)ctx().num_cus * 8), 256, 0, stream()>>>(Qb, qp, qe, nq, nq_pad, f, KS);
+        IMP_CHECK_HIP(hipGetLastError());
+        qplanes = qp, qexp = qe;
+    };
+    static const bool resident_env = !(getenv("IMP_TOPK_RESIDENT") && atoi(getenv("IMP_TOPK_RESIDENT")) == 0);
+    static const bool bf16x3 = getenv("IMP_TOPK_BF16X3") != nullptr;
     // emit path (no score matrix): large item sets, k small against the candidate lists
     static const bool no_emit = getenv("IMP_TOPK_NO_EMIT") != nullptr;
     const bool emit_path = fast && !no_emit && emit_shape;
@@ -1501,6 +1371,7 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
       uint32_t *tau = imp_knn::ensure(knn->tau, (ebatch + 127) / 128 * 128);  // the emit epilogue loads thresholds four rows at a time
       unsigned int *cnt = imp_knn::ensure(knn->cand_count, ebatch);
       uint64_t *cand = imp_knn::ensure(knn->cand, ebatch * (size_t)kEmitCap);
+      float *row_unscale = imp_knn::ensure(knn->row_unscale, rq_query_pad(ebatch));
       int *fallback_e = host_flags;  // one flag per row of the batch, read by the host after the batch's wait
       const bool have_coo = query_filter && query_filter->nnz, have_items = item_filter && item_filter->size;
       uint32_t *row_bits = have_coo ? imp_knn::ensure(knn->row_bits, ebatch * (size_t)words) : nullptr;
@@ -1510,41 +1381,39 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
       const int *flags = host_flags;
       std::vector<int32_t> fb_list;
       static const bool no_qsplit = getenv("IMP_TOPK_NO_QSPLIT") != nullptr;
-      static const bool bf16x3 = getenv("IMP_TOPK_BF16X3") != nullptr;
       constexpr bool kCanSplit = BF3;
-      constexpr bool kCanH2 = BF3;  // (fp16-stored factors too: their values are their own high halves, and the scores stay
-                                    // bit-identical to scoring fp32 copies of them)
       const bool qsplit = kCanSplit && !no_qsplit;
-      // two fp16 terms, three products (see H2 at split8_f16); a handle whose catalogue sent most rows of a batch to the exact path
-      // (item rows far above the sampled magnitude: every query row then sees a NaN) stays on the six-product form from then on
-      const bool h2 = kCanH2 && qsplit && !bf16x3 && !knn->h2_off;
+      // fp16 two-term form with the queries resident in registers and the item planes cached (topk_resident.h): every factor count
+      // that pads to 32 / 64 / 128 / 256; fp16-stored factors too (their values are their own high halves: scores stay bit-identical
+      // to scoring fp32 copies of them).  IMP_TOPK_BF16X3=1 / IMP_TOPK_RESIDENT=0: the six-product 128 x 128 kernel (A/B, parity)
+      const int KS = rq_ks_for(f);
+      const bool resident = kCanSplit && resident_env && !bf16x3 && KS > 0;
       split_bf16 *qs = nullptr;
-      unsigned *maxbits = nullptr;
-      if (qsplit) {
+      const _Float16 *iplanes = nullptr, *qplanes = nullptr;
+      const int *iexp = nullptr, *qexp = nullptr;
+      if (resident) {
+        prepare_planes(KS, iplanes, iexp, qplanes, qexp);
+      } else if (qsplit) {
         IMP_PROF("split_query_rows");
         const size_t nq_pad = (nq + 127) / 128 * 128;  // whole 128-row query blocks: a workgroup reads all four tiles of its block
         qs = imp_knn::ensure(knn->query_split, nq_pad * 3 * (size_t)f);
         const int grid = (int)std::max<size_t>(1, std::min<size_t>((nq_pad * (size_t)f + 255) / 256, (size_t)ctx().num_cus * 16));
-        if (h2) {
-          if (knn->h2_max.size < 4 + 2 * kAbsmaxBlocks) knn->h2_max.alloc(4 + 2 * kAbsmaxBlocks, true);  // (the arrival counter starts at zero)
-          maxbits = knn->h2_max.data();
-          topk_absmax_kernel<TQ, TI><<<std::min(ctx().num_cus, kAbsmaxBlocks), 1024, 0, stream()>>>(Qb, nq * (size_t)f, Ib, ni, f, maxbits);
-          split_query_rows_f16_kernel<TQ><<<grid, 256, 0, stream()>>>(Qb, reinterpret_cast<_Float16 *>(qs), nq, nq_pad, f, maxbits);
-        } else {
-          split_query_rows_kernel<TQ><<<grid, 256, 0, stream()>>>(Qb, reinterpret_cast<__bf16 *>(qs), nq, nq_pad, f);
-        }
+        split_query_rows_kernel<TQ><<<grid, 256, 0, stream()>>>(Qb, reinterpret_cast<__bf16 *>(qs), nq, nq_pad, f);
         IMP_CHECK_HIP(hipGetLastError());
       }
       // the two GEMM launches of a batch: query rows pre-split (default) or in their storage type
       auto gemm = [&](auto mode_c, size_t start, dim3 grid, int rows, float *S_out, int bstride, const EmitArgs &ea) {
         constexpr int M = decltype(mode_c)::value;
         const float *norms_p = item_norms ? item_norms->f32() : nullptr;
-        if constexpr (kCanH2) {
-          if (h2) {
-            EmitArgs eh = ea;
-            eh.maxbits = maxbits;
-            score_gemm_direct_kernel<M, split_f16, TI, true><<<grid, 256, 0, stream()>>>(reinterpret_cast<const split_f16 *>(qs) + start * 2 * (size_t)f,
-                                                                                   rows, Ib, (int)ni, f, norms_p, S_out, nullptr, 0, bstride, eh);
+        if constexpr (kCanSplit) {
+          if (resident) {
+            ResidentArgs ra{};
+            ra.qsplit = qplanes + (start / 32) * (size_t)KS * 2 * 512;
+            ra.isplit = iplanes, ra.qexp = qexp + start, ra.iexp = iexp;
+            ra.nq = rows, ra.ni = (int)ni, ra.norms = norms_p;
+            ra.n_blocks = (int)grid.x, ra.block_stride = bstride;
+            ra.S = S_out, ra.sub_cols = (int)grid.x * 128, ra.emit = ea;
+            launch_score_resident<M>(KS, ra, rows);
             return;
           }
         }
@@ -1592,21 +1461,20 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
         }
         {
           IMP_PROF("score_gemm");
-          EmitArgs ea{tau, row_bits, item_bits, words, cand, cnt, kEmitCap};
+          EmitArgs ea{tau, row_bits, item_bits, words, cand, cnt, kEmitCap, resident ? row_unscale : nullptr};
           gemm(std::integral_constant<int, 2>{}, start, dim3((unsigned)n_blocks, qblocks), (int)rows, nullptr, 1, ea);
           IMP_CHECK_HIP(hipGetLastError());
         }
         {
           IMP_PROF("topk_select_candidates");
           select_candidates_kernel<512><<<(unsigned)rows, 512, 0, stream()>>>(cand, cnt, kEmitCap, k_eff, d_ids + start * k,
-                                                                             d_dist + start * k, k, fallback_e);
+                                                                             d_dist + start * k, k, fallback_e, resident ? row_unscale : nullptr);
           IMP_CHECK_HIP(hipGetLastError());
         }
         sync();
         fb_list.clear();
         for (size_t i = 0; i < rows; ++i)
           if (flags[i]) fb_list.push_back((int32_t)i);
-        if (h2 && IMP_TOPK_KO == 0 && fb_list.size() * 2 > rows) knn->h2_off = true;
         static const bool debug = getenv("IMP_TOPK_DEBUG") != nullptr;
         if (debug && !fb_list.empty()) {
           std::vector<unsigned int> hc(rows);
@@ -1652,10 +1520,24 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
       return;
     }
 
+    const int KS0 = rq_ks_for(f);
+    const bool resident0 = BF3 && fast && resident_env && !bf16x3 && KS0 > 0;
+    const _Float16 *iplanes0 = nullptr, *qplanes0 = nullptr;
+    const int *iexp0 = nullptr, *qexp0 = nullptr;
+    if (resident0) prepare_planes(KS0, iplanes0, iexp0, qplanes0, qexp0);
     for (size_t start = 0; start < nq; start += batch) {
       size_t end = std::min(nq, start + batch), rows = end - start;
       bool filters_applied = false;
-      if (fast) {
+      if (resident0) {
+        IMP_PROF("score_gemm");
+        ResidentArgs ra{};
+        ra.qsplit = qplanes0 + (start / 32) * (size_t)KS0 * 2 * 512;
+        ra.isplit = iplanes0, ra.qexp = qexp0 + start, ra.iexp = iexp0;
+        ra.nq = (int)rows, ra.ni = (int)ni, ra.norms = item_norms ? item_norms->f32() : nullptr;
+        ra.n_blocks = (int)((ni + 127) / 128), ra.block_stride = 1;
+        ra.S = scores, ra.tile_max = tile_max, ra.n_tiles64 = n_tiles;
+        launch_score_resident<0>(KS0, ra, (int)rows);
+      } else if (fast) {
         IMP_PROF("score_gemm");
         dim3 grid((unsigned)((ni + 127) / 128), (unsigned)((rows + 127) / 128));
         score_gemm_direct_kernel<0, TQ, TI, BF3><<<grid, 256, 0, stream()>>>(Qb + start * f, (int)rows, Ib, (int)ni, f,

@@ -273,10 +273,12 @@ def test_fp16_form_follows_the_operands_magnitude(gpu, oracle, item_scale, query
     assert_array_equal(ids[ok], want_ids[ok, :k])
 
 
-def test_fp16_form_hands_overflowing_rows_to_the_exact_path(gpu, oracle):
-    """An item row far above the sampled magnitude (rows 0, 16, 32 ... are sampled; row 7 is 10^4 x the rest) leaves the fp16
-    range after scaling: its scores come out as NaN, travel as +inf candidates, and every query row that saw one is re-scored
-    by the materialising path -- the result is the oracle's, with the outlier first or absent as its sign decides."""
+def test_fp16_form_with_outlier_item_rows(gpu, oracle):
+    """Item rows 10^4 and 3 10^3 x the rest.  Round 5 scaled the items by a SAMPLED maximum: such rows overflowed fp16 and their
+    query rows were re-scored by the six-product path.  Round 6 takes the exact maximum in the (cached) split pass
+    (topk_resident.h): nothing overflows, the outliers are scored in the same form, the ordinary rows keep 22 bits below a scale
+    set by the outlier.  Scores are compared with the float64 product under the fp32 dot product's own error bound (an outlier's
+    score is a cancelling sum of terms 10^4 x larger than the result: rtol on the result alone is not a meaningful bar there)."""
     rng = np.random.default_rng(23)
     ni, nq, f, k = 20_000, 150, 64, 10
     items = (rng.standard_normal((ni, f)) * 0.1).astype(np.float32)
@@ -287,16 +289,63 @@ def test_fp16_form_hands_overflowing_rows_to_the_exact_path(gpu, oracle):
     ids, d = gpu.KnnQuery().topk(gpu.Matrix(items), gpu.Matrix(q), k, query_filter=gpu.COOMatrix(liked.tocoo()))
     assert np.isfinite(d).all()
     want_ids, want_d = oracle.topk(items, q, k + 1, filter_query_items=liked)
-    assert_allclose(d, want_d[:, :k], rtol=3e-5, atol=1e-7)
+    exact = np.einsum("qkf,qf->qk", items[ids].astype(np.float64), q.astype(np.float64))
+    bound = 4 * f * np.finfo(np.float32).eps * np.einsum("qkf,qf->qk", np.abs(items[ids]).astype(np.float64), np.abs(q).astype(np.float64))
+    assert (np.abs(d - exact) <= np.maximum(bound, 3e-5 * np.abs(exact))).all()
+    plain = ~np.isin(ids, (7, 4001))
+    assert_allclose(d[plain], want_d[:, :k][plain], rtol=3e-5, atol=1e-7)
     ok = ~_near_tie_rows(want_d, f)
     assert_array_equal(ids[ok], want_ids[ok, :k])
     assert (ids[:, 0] == 7).sum() > nq // 4      # the outlier leads wherever its score is positive
-    # the same handle again: it has given the fp16 form up (most rows of the batch went to the exact path) -- same answer
+    # the same handle again: the item planes are cached -- same answer, bit for bit
     knn = gpu.KnnQuery()
-    first = knn.topk(gpu.Matrix(items), gpu.Matrix(q), k)
-    second = knn.topk(gpu.Matrix(items), gpu.Matrix(q), k)
+    I, Q = gpu.Matrix(items), gpu.Matrix(q)
+    first = knn.topk(I, Q, k)
+    second = knn.topk(I, Q, k)
     assert_array_equal(first[0], second[0])
-    assert_allclose(first[1], second[1], rtol=3e-5)
+    assert_array_equal(first[1], second[1])
+
+
+def test_item_plane_cache_follows_writes(gpu, oracle):
+    """The fragment-ordered fp16 planes of the item matrix live in the KnnQuery handle across calls (topk_resident.h).  Every write
+    to the matrix through the library must invalidate them: a host upload, assign_rows, a solver sweep over the rows.  A matrix
+    whose device address was handed out is never cached from."""
+    rng = np.random.default_rng(41)
+    ni, nq, f, k = 16_000, 64, 64, 10
+    a = (rng.standard_normal((ni, f)) * 0.1).astype(np.float32)
+    b = (rng.standard_normal((ni, f)) * 0.1).astype(np.float32)
+    q = (rng.standard_normal((nq, f)) * 0.1).astype(np.float32)
+    from implicit_amd.synthetic import synthetic_csr
+
+    def same(got, want):  # a stale plane set would give unrelated ids; fp32 near-ties may move a position or two
+        return (got == want).mean() > 0.99
+
+    knn, I, Q = gpu.KnnQuery(), gpu.Matrix(a), gpu.Matrix(q)
+    ids_a, _ = knn.topk(I, Q, k)
+    assert same(ids_a, oracle.topk(a, q, k)[0])
+    assert_array_equal(knn.topk(I, Q, k)[0], ids_a)                      # cached planes
+    I.copy_from_numpy(b)                                                  # same address, new contents
+    ids_b, _ = knn.topk(I, Q, k)
+    assert same(ids_b, oracle.topk(b, q, k)[0])
+    rows = np.arange(0, ni, 3, dtype=np.int32)
+    I.assign_rows(rows, gpu.Matrix(a[rows]))                              # partial overwrite
+    mixed = b.copy()
+    mixed[rows] = a[rows]
+    assert same(knn.topk(I, Q, k)[0], oracle.topk(mixed, q, k)[0])
+    # a CG sweep rewrites the item factors in place (what fit() does between recommend() calls)
+    C = synthetic_csr(ni, nq, 40_000, seed=4)
+    gram = gpu.Matrix.zeros(f, f)
+    solver = gpu.LeastSquaresSolver()
+    solver.calculate_yty(Q, gram, 0.05)
+    solver.least_squares(gpu.CSRMatrix(C), I, gram, Q, 3)
+    now = I.to_numpy()
+    assert same(knn.topk(I, Q, k)[0], oracle.topk(now, q, k)[0])
+    # an exposed address: nothing is kept (the planes are remade per call), answers stay right after an untracked change is
+    # simulated by a tracked one
+    _ = I.device_ptr
+    assert same(knn.topk(I, Q, k)[0], oracle.topk(now, q, k)[0])
+    I.copy_from_numpy(a)
+    assert_array_equal(knn.topk(I, Q, k)[0], ids_a)
 
 
 def test_fp16_form_on_heavy_tailed_item_norms(gpu, oracle):
