@@ -847,263 +847,6 @@ __global__ __launch_bounds__(1024) void als_cg_qfgroup_kernel(const int32_t *__r
   }
 }
 
-// ---- short rows, round 6 experiment (IMP_SHORT_SERVER=1): INDEPENDENT rows, the gramian product from server wavefronts ------
-// The lock-step kernel above makes 16 rows wait for the slowest of them twice per CG pass (knock-out without barriers: 0.62
-// against 0.92 ms per configs[2] step).  Here 14 wavefronts of a 1024-thread workgroup each solve rows on their own -- no
-// workgroup barrier after the prologue -- and the dense product A0 p is a SERVICE: a row publishes its operand as two fp16 planes
-// (scaled to 2^14 by its own maximum) and a request generation in LDS, does its tile entries, and picks the product up when the
-// done-word shows its generation.  Two server wavefronts (7 clients each) poll the request words, take whatever is pending as the
-// columns of ONE v_mfma_f32_16x16x32_f16 product (column 2 j: high plane of client j, 2 j + 1: low plane; the gramian as H + L fp16
-// fragments in LDS, 64 MFMAs per batch whatever its fill), add the column pair and hand the 128 results back scaled.
-// Arithmetic per row: implicit/cpu/_als.pyx:179-244 as in the kernel above (operands to 2^-22, fp32 accumulation).
-#ifndef SRV_KO
-#define SRV_KO 0  // timing-only knock-outs: 1 the server answers at once (no product), 2 the clients do not wait
-#endif
-typedef _Float16 sv_h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 sv_h2 __attribute__((ext_vector_type(2)));
-constexpr int kSrvClients = 14, kSrvServers = 2, kSrvPerServer = kSrvClients / kSrvServers;
-constexpr unsigned kSrvExit = 0xFFFFFFFFu;
-struct SrvSlot {              // one per client wavefront
-  _Float16 ph[128], pl[128];  // operand planes (natural factor order), scaled by 2^pexp
-  float prow[128];            // the operand itself, for the wavefront's own tile pass
-  float res[128];             // A0 p from the server
-  float cw[64];               // per-entry weights of the resident tile (gather_pair)
-};
-struct SrvCtl {
-  unsigned req[16], done[16];
-  int pexp[16];
-};
-template <typename ST>
-__global__ __launch_bounds__(1024) void als_cg_srv_kernel(const int32_t *__restrict__ order, int first, int count, const int32_t *__restrict__ indptr,
-                                                          const int32_t *__restrict__ indices, const float *__restrict__ data,
-                                                          ST *__restrict__ X, const ST *__restrict__ Y, const float *__restrict__ A0, int cg_steps) {
-  constexpr int F = 128, FC = 2, FE = 8;
-  constexpr bool ROLL = std::is_same<ST, float>::value;
-  extern __shared__ __attribute__((aligned(16))) unsigned char sv_smem[];
-  _Float16 *Gf = reinterpret_cast<_Float16 *>(sv_smem);                       // [2 terms][8 mt x 4 ks][64 lanes][8]  64 KB
-  SrvSlot *slots = reinterpret_cast<SrvSlot *>(sv_smem + 2 * 32 * 64 * 8 * 2);  // [14]
-  SrvCtl *ctl = reinterpret_cast<SrvCtl *>(slots + kSrvClients);
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // gramian -> H + L fp16 fragments, scaled so that its largest entry (a diagonal one: the matrix is positive semi-definite)
-  // sits in [2^13, 2^14)
-  const float dmax = wave_allmax(fmaxf(fabsf(A0[lane * (F + 1)]), fabsf(A0[(lane + 64) * (F + 1)])));
-  const int kg = max(-100, min(100, 13 - ((int)(__float_as_uint(dmax) >> 23) - 127)));
-  const float gs = __uint_as_float((unsigned)(kg + 127) << 23);
-  for (int e = threadIdx.x; e < F * F; e += 1024) {
-    const int r = e >> 7, c = e & 127;
-    const float x = A0[e] * gs;
-    const _Float16 h = (_Float16)x;
-    const int at = ((((r >> 4) * 4 + (c >> 5)) * 64) + (r & 15) + 16 * ((c >> 3) & 3)) * 8 + (c & 7);
-    Gf[at] = h, Gf[32 * 64 * 8 + at] = (_Float16)(x - (float)h);
-  }
-  if (threadIdx.x < 16) ctl->req[threadIdx.x] = 0u, ctl->done[threadIdx.x] = 0u, ctl->pexp[threadIdx.x] = 0;
-  __syncthreads();  // the only workgroup-wide barrier
-  typedef __attribute__((address_space(3))) volatile unsigned lds_word;
-  auto peek = [](const unsigned *p) { return *(lds_word *)(size_t)(unsigned)(size_t)p; };
-
-  if (wave >= kSrvClients) {
-    // ---- server: clients c = 2 j + s ---------------------------------------------------------------------------------------
-    const int sv = wave - kSrvClients;
-    const int n = lane & 15, kq = lane >> 4, j = n >> 1, term = n & 1;
-    const int cj = 2 * min(j, kSrvPerServer - 1) + sv;                 // client of this lane's B column (column pair 7: unused)
-    const int cl = 2 * min(lane, kSrvPerServer - 1) + sv;              // client whose words lane l < 7 watches
-    unsigned served = 0u;
-    const _Float16 *plane = (term ? slots[cj].pl : slots[cj].ph) + 8 * kq;
-    for (;;) {
-      const unsigned r = lane < kSrvPerServer ? peek(&ctl->req[cl]) : 0u;
-      const bool gone = lane < kSrvPerServer && r == kSrvExit;
-      const bool pend = lane < kSrvPerServer && !gone && r != served;
-      const unsigned long long pmask = __builtin_amdgcn_ballot_w64(pend);
-      if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(gone)) == kSrvPerServer) break;
-      if (!pmask) {
-        __builtin_amdgcn_s_sleep(1);
-        continue;
-      }
-      const bool mine = j < kSrvPerServer && ((pmask >> j) & 1ull);   // this lane's column belongs to a pending request
-      asm volatile("" ::: "memory");  // the planes are read AFTER the request word, every round anew
-#if SRV_KO & 1
-      if (pend) ctl->done[cl] = r;
-      if (pend) served = r;
-      continue;
-#endif
-      sv_h8 b[4];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        b[ks] = *reinterpret_cast<const sv_h8 *>(plane + 32 * ks);
-        if (!mine) b[ks] = sv_h8{0, 0, 0, 0, 0, 0, 0, 0};
-      }
-      // 8 groups (k-step x term) of 8 INDEPENDENT MFMAs (one per 16-row output tile); the fragments of group g + 1 are read while
-      // group g multiplies (two register sets of 8 fragments).  Written tile by tile -- read L, read H, two dependent MFMAs --
-      // a batch took ~5 K cycles instead of the ~1 K its 64 MFMAs need
-      f32x4 acc[8];
-#pragma unroll
-      for (int mt = 0; mt < 8; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      sv_h8 fa[8], fb[8];
-      auto load_group = [&](int g, sv_h8(&dst)[8]) {  // g = 2 ks + t: t = 0 the low halves first (smallest first), t = 1 the high
-        const _Float16 *base = Gf + (size_t)((g & 1) ? 0 : 32 * 64 * 8) + (size_t)((g >> 1) * 64 + lane) * 8;
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) dst[mt] = *reinterpret_cast<const sv_h8 *>(base + (size_t)mt * 4 * 64 * 8);
-      };
-      load_group(0, fa);
-      static_for<8>([&](auto Gc) {
-        constexpr int g = decltype(Gc)::value;
-        if constexpr (g + 1 < 8) {
-          if constexpr (g & 1) load_group(g + 1, fa);
-          else load_group(g + 1, fb);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-          if constexpr (g & 1) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[mt], b[g >> 1], acc[mt], 0, 0, 0);
-          else acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[mt], b[g >> 1], acc[mt], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      });
-      // D layout: column n = lane & 15, rows 4 (lane >> 4) .. + 3 of the 16-row tile.  High- and low-plane columns are neighbours
-      const float us = mine ? __uint_as_float((unsigned)max(1, min(254, 127 - kg - ctl->pexp[cj])) << 23) : 0.f;
-#pragma unroll
-      for (int mt = 0; mt < 8; ++mt) {
-        f32x4 v = acc[mt];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (v[e] + dpp_mov<0xB1>(v[e])) * us;  // quad_perm:[1,0,3,2]: the partner column
-        if (mine && term == 0) *reinterpret_cast<f32x4 *>(slots[cj].res + 16 * mt + 4 * kq) = v;
-      }
-      // the results are in place before the done-words move (a wavefront's LDS operations execute in order; the compiler is told)
-      asm volatile("" ::: "memory");
-      if (pend) ctl->done[cl] = r;
-      asm volatile("" ::: "memory");
-      if (pend) served = r;
-    }
-    return;
-  }
-
-  // ---- client: one row at a time, no barriers ------------------------------------------------------------------------------
-  SrvSlot &me = slots[wave];
-  float *prow = me.prow, *cw = me.cw;
-  const unsigned cf = (unsigned)QL<F>::cfactor(lane, 0);
-  unsigned gen = 0u;
-  auto request = [&](const float (&vec)[FC]) {  // operand -> planes + fp32 copy, then the generation word
-    const float m = wave_allmax(fmaxf(fabsf(vec[0]), fabsf(vec[1])));
-    const int e = max(-100, min(100, 14 - ((int)(__float_as_uint(m) >> 23) - 127)));
-    const float sc = __uint_as_float((unsigned)(e + 127) << 23);
-    const float x0 = vec[0] * sc, x1 = vec[1] * sc;
-    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
-    *reinterpret_cast<sv_h2 *>(me.ph + cf) = sv_h2{h0, h1};
-    *reinterpret_cast<sv_h2 *>(me.pl + cf) = sv_h2{(_Float16)(x0 - (float)h0), (_Float16)(x1 - (float)h1)};
-    *reinterpret_cast<float2 *>(prow + cf) = make_float2(vec[0], vec[1]);
-    ++gen;
-    if (lane == 0) {
-      ctl->pexp[wave] = e;
-      asm volatile("ds_write_b32 %0, %1" ::"v"((unsigned)(size_t)&ctl->req[wave]), "v"(gen) : "memory");
-    }
-  };
-  auto collect = [&](float (&out)[FC]) {
-#if !(SRV_KO & 2)
-    while (__builtin_amdgcn_readfirstlane(peek(&ctl->done[wave])) != gen) __builtin_amdgcn_s_sleep(1);
-#endif
-    asm volatile("" ::: "memory");
-    const float2 t = *reinterpret_cast<const float2 *>(me.res + cf);
-    out[0] = t.x, out[1] = t.y;
-  };
-  auto kill = [](float (&v)[FC]) { v[0] = v[1] = 0.f; };
-
-  const int r_step = gridDim.x * kSrvClients;
-  auto row_id = [&](int i) { return order[first + min(i, count - 1)]; };
-  const int i_first = blockIdx.x * kSrvClients + wave;
-  int id0 = row_id(i_first), id1 = row_id(i_first + r_step), id2 = row_id(i_first + 2 * r_step), id3 = row_id(i_first + 3 * r_step);
-  int b0 = indptr[id0], e0 = indptr[id0 + 1], b1 = indptr[id1], e1 = indptr[id1 + 1], b2 = indptr[id2], e2 = indptr[id2 + 1];
-  int ent_col, ent_cnt = i_first < count ? e0 - b0 : 0;
-  float ent_c;
-  fetch_entries(indices, data, opaque(lane), b0, max(e0, b0 + 1), ent_col, ent_c);
-  bool tile_ready = false;
-  int cnt = 0;
-  f32x2 y[8][FE / 2];
-  float x[FC];
-  kill(x);
-  for (int i = i_first; i < count; i += r_step) {
-    ST *xrow = X + (size_t)id0 * F;
-    if (!tile_ready) {
-      cnt = ent_cnt;
-      ent_col = opaque(ent_col);
-      ent_c = __int_as_float(opaque(__float_as_int(ent_c)));
-      static_for<4>([&](auto Pc) {
-        constexpr int P = decltype(Pc)::value;
-        if (8 * P < cnt) gather_pair<F, P>(y, cw, ent_col, ent_c, cnt, Y, lane);
-      });
-      ent_cnt = i + r_step < count ? e1 - b1 : 0;
-      fetch_entries(indices, data, opaque(lane), b1, max(e1, b1 + 1), ent_col, ent_c);
-      load_compact<F>(xrow, opaque(lane), x);
-    }
-    float xc[FC], r[FC], p[FC], Ap[FC], sp[FC];
-    xc[0] = x[0], xc[1] = x[1];
-    // r = -(A0 x) + sum_k (c+ - (|c|-1) y.x) y        (_als.pyx:187-201)
-    request(xc);
-    tile_pass<F, true, false, ST>(y, cw, cnt, prow, sp, lane, 0, ent_col, ent_c, Y);
-    collect(Ap);
-    p[0] = r[0] = sp[0] - Ap[0], p[1] = r[1] = sp[1] - Ap[1];
-    float rsold = dot_compact<F>(r, r);
-    bool active = rsold >= 1e-20f;  // else: x untouched (_als.pyx:206)
-    const bool store = active;
-    for (int it = 0; active && it + 1 < cg_steps; ++it) {
-      request(p);
-      tile_pass<F, false, false, ST>(y, cw, cnt, prow, sp, lane, 0, ent_col, ent_c, Y);
-      collect(Ap);
-      Ap[0] += sp[0], Ap[1] += sp[1];
-      const float alpha = rsold * __builtin_amdgcn_rcpf(dot_compact<F>(p, Ap));
-      xc[0] = fmaf(alpha, p[0], xc[0]), xc[1] = fmaf(alpha, p[1], xc[1]);
-      r[0] = fmaf(-alpha, Ap[0], r[0]), r[1] = fmaf(-alpha, Ap[1], r[1]);
-      const float rsnew = dot_compact<F>(r, r);
-      if (rsnew < 1e-20f) {
-        active = false;  // the oracle breaks here (_als.pyx:235)
-      } else {
-        const float beta = rsnew * __builtin_amdgcn_rcpf(rsold);
-        p[0] = fmaf(beta, p[0], r[0]), p[1] = fmaf(beta, p[1], r[1]);
-        rsold = rsnew;
-      }
-    }
-    // last step: only its x update is evaluated; its tile pass rolls the next row's entries in
-    bool rolled = false;
-    if (cg_steps > 0 && active) {
-      request(p);
-      if constexpr (ROLL) {
-        tile_pass<F, false, true, ST>(y, cw, cnt, prow, sp, lane, ent_cnt, ent_col, ent_c, Y);
-        cnt = ent_cnt;
-        ent_cnt = i + 2 * r_step < count ? e2 - b2 : 0;
-        fetch_entries(indices, data, opaque(lane), b2, max(e2, b2 + 1), ent_col, ent_c);
-        load_compact<F>(X + (size_t)id1 * F, opaque(lane), x);
-        rolled = true;
-      } else {
-        tile_pass<F, false, false, ST>(y, cw, cnt, prow, sp, lane, 0, ent_col, ent_c, Y);
-        kill(x);
-      }
-      collect(Ap);
-      Ap[0] += sp[0], Ap[1] += sp[1];
-      const float alpha = rsold * __builtin_amdgcn_rcpf(dot_compact<F>(p, Ap));
-      xc[0] = fmaf(alpha, p[0], xc[0]), xc[1] = fmaf(alpha, p[1], xc[1]);
-    } else {
-      kill(x);
-    }
-    if (store) store_compact<F>(xrow, opaque(lane), xc);
-    tile_ready = rolled;
-    id0 = id1, id1 = id2, id2 = id3, id3 = row_id(i + 4 * r_step);
-    b0 = b1, e0 = e1, b1 = b2, e1 = e2, b2 = indptr[id2], e2 = indptr[id2 + 1];
-  }
-  if (lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"((unsigned)(size_t)&ctl->req[wave]), "v"(kSrvExit) : "memory");
-}
-
-template <typename T>
-static void launch_srv(const imp_csr *C, int first, int count, T *X, const T *Y, const float *A0, int cg_steps, const char *name) {
-  if (count <= 0) return;
-  const size_t lds = (size_t)2 * 32 * 64 * 8 * 2 + kSrvClients * sizeof(SrvSlot) + sizeof(SrvCtl);
-  auto kern = als_cg_srv_kernel<T>;
-  IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  int grid = std::min((count + kSrvClients - 1) / kSrvClients, ctx().num_cus * std::max(2, ctx().oversub));
-  IMP_PROF(name);
-  kern<<<grid, 1024, lds, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(), C->data.data(), X, Y, A0, cg_steps);
-  IMP_CHECK_HIP(hipGetLastError());
-}
-
 template <int F, typename T>
 static void launch_qfgroup(const imp_csr *C, int first, int count, T *X, const T *Y, const float *A0, int cg_steps, const char *name) {
   if (count <= 0) return;
@@ -1125,9 +868,7 @@ static void launch_qfgroup(const imp_csr *C, int first, int count, T *X, const T
 
 template <typename T>
 void launch_group_fused(const imp_csr *C, int f, int first, int count, T *X, const T *Y, const float *A0, int cg_steps, const char *name) {
-  static const bool server = getenv("IMP_SHORT_SERVER") && atoi(getenv("IMP_SHORT_SERVER")) != 0;
-  if (f == 128 && server) launch_srv<T>(C, first, count, X, Y, A0, cg_steps, name);
-  else if (f == 128) launch_qfgroup<128, T>(C, first, count, X, Y, A0, cg_steps, name);
+  if (f == 128) launch_qfgroup<128, T>(C, first, count, X, Y, A0, cg_steps, name);
   else if (f == 64) launch_qfgroup<64, T>(C, first, count, X, Y, A0, cg_steps, name);
   else throw std::invalid_argument("launch_group_fused: f must be 64 or 128");
 }
