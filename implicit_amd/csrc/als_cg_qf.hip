@@ -847,209 +847,6 @@ __global__ __launch_bounds__(1024) void als_cg_qfgroup_kernel(const int32_t *__r
   }
 }
 
-// ---- short rows, round 6 (f = 128): 8 rows per 512-thread workgroup in lock step, TWO workgroups per CU --------------------
-// The 16-row kernel above owns its CU (96 KB of three-term bf16 gramian): its sixteen wavefronts meet at two barriers per pass
-// and wait there together (knock-out without barriers: 0.62 against 0.92 ms per configs[2] step).  With the gramian as H + L fp16
-// fragments (64 KB) two workgroups of 8 rows fit one CU; each keeps its own barriers, so one's waits run under the other's work,
-// and the product of a pass is cheaper per wavefront: the 8 operands are the 16 columns of ONE v_mfma_f32_16x16x32_f16 product
-// (column 2 j: high fp16 plane of row j, 2 j + 1: low plane, scaled to 2^14 by the row's own maximum), wavefront w owns output
-// tile w: 4 k-steps x (L, H) = 8 MFMAs in two chains (the bf16 form: 12 per wavefront).  Operands to 2^-22, fp32 accumulation;
-// arithmetic per row as above (implicit/cpu/_als.pyx:179-244).
-typedef _Float16 g8_h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 g8_h2 __attribute__((ext_vector_type(2)));
-struct G8Slot {               // one per row wavefront
-  _Float16 ph[128], pl[128];  // operand planes (natural factor order), scaled by 2^pexp
-  float prow[128];            // the operand itself, for the wavefront's own tile pass
-  float res[128];             // A0 p
-  float cw[64];               // per-entry weights of the resident tile (gather_pair)
-};
-template <typename ST>
-__global__ __launch_bounds__(512, 4) void als_cg_g8_kernel(const int32_t *__restrict__ order, int first, int count, const int32_t *__restrict__ indptr,
-                                                            const int32_t *__restrict__ indices, const float *__restrict__ data,
-                                                            ST *__restrict__ X, const ST *__restrict__ Y, const float *__restrict__ A0, int cg_steps) {
-  constexpr int F = 128, FC = 2, FE = 8, ROWS = 8;
-  constexpr bool ROLL = std::is_same<ST, float>::value;
-  extern __shared__ __attribute__((aligned(16))) unsigned char g8_smem[];
-  _Float16 *Gf = reinterpret_cast<_Float16 *>(g8_smem);                        // [2 terms][8 mt x 4 ks][64 lanes][8]  64 KB
-  G8Slot *slots = reinterpret_cast<G8Slot *>(g8_smem + 2 * 32 * 64 * 8 * 2);    // [8]
-  int *pexp = reinterpret_cast<int *>(slots + ROWS);                            // [8]
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // gramian -> H + L fp16 fragments of v_mfma_f32_16x16x32_f16's A operand, its largest entry (a diagonal one) in [2^13, 2^14)
-  const float dmax = wave_allmax(fmaxf(fabsf(A0[lane * (F + 1)]), fabsf(A0[(lane + 64) * (F + 1)])));
-  const int kg = max(-100, min(100, 13 - ((int)(__float_as_uint(dmax) >> 23) - 127)));
-  const float gs = __uint_as_float((unsigned)(kg + 127) << 23);
-  for (int e = threadIdx.x; e < F * F; e += 512) {
-    const int r = e >> 7, c = e & 127;
-    const float x = A0[e] * gs;
-    const _Float16 h = (_Float16)x;
-    const int at = ((((r >> 4) * 4 + (c >> 5)) * 64) + (r & 15) + 16 * ((c >> 3) & 3)) * 8 + (c & 7);
-    Gf[at] = h, Gf[32 * 64 * 8 + at] = (_Float16)(x - (float)h);
-  }
-  __syncthreads();
-  G8Slot &me = slots[wave];
-  float *prow = me.prow, *cw = me.cw;
-  const unsigned cf = (unsigned)QL<F>::cfactor(lane, 0);
-
-  // every wave of the workgroup takes both barriers of a pass (rows that stopped publish zeros)
-  auto publish = [&](const float (&vec)[FC], bool valid) {
-    const float v0 = valid ? vec[0] : 0.f, v1 = valid ? vec[1] : 0.f;
-    const float m = wave_allmax(fmaxf(fabsf(v0), fabsf(v1)));
-    const int e = max(-100, min(100, 14 - ((int)(__float_as_uint(m) >> 23) - 127)));
-    const float sc = __uint_as_float((unsigned)(e + 127) << 23);
-    const float x0 = v0 * sc, x1 = v1 * sc;
-    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
-    *reinterpret_cast<g8_h2 *>(me.ph + cf) = g8_h2{h0, h1};
-    *reinterpret_cast<g8_h2 *>(me.pl + cf) = g8_h2{(_Float16)(x0 - (float)h0), (_Float16)(x1 - (float)h1)};
-    *reinterpret_cast<float2 *>(prow + cf) = make_float2(v0, v1);
-    if (lane == 0) pexp[wave] = e;
-    __syncthreads();
-  };
-  auto product = [&]() {  // output tile `wave` (factors 16 wave .. + 15) of A0 . P for the 8 rows
-    const int ln = opaque(lane);
-    const int n = ln & 15, kq = ln >> 4, j = n >> 1;
-    const _Float16 *plane = ((n & 1) ? slots[j].pl : slots[j].ph) + 8 * kq;
-    const _Float16 *afrag = Gf + (size_t)(wave * 4 * 64 + ln) * 8;
-    f32x4 accl = {0.f, 0.f, 0.f, 0.f}, acch = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const g8_h8 b = *reinterpret_cast<const g8_h8 *>(plane + 32 * ks);
-      const g8_h8 ah = *reinterpret_cast<const g8_h8 *>(afrag + (size_t)ks * 64 * 8);
-      const g8_h8 al = *reinterpret_cast<const g8_h8 *>(afrag + (size_t)32 * 64 * 8 + (size_t)ks * 64 * 8);
-      accl = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b, accl, 0, 0, 0);
-      acch = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b, acch, 0, 0, 0);
-    }
-    // D layout: column n = lane & 15 (row j's high / low plane), rows 4 (lane >> 4) .. + 3 of the tile; scale out per row
-    const float us = __uint_as_float((unsigned)max(1, min(254, 127 - kg - pexp[j])) << 23);
-    f32x4 v = accl + acch;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (v[e] + dpp_mov<0xB1>(v[e])) * us;  // quad_perm:[1,0,3,2]: the partner column
-    if ((n & 1) == 0) *reinterpret_cast<f32x4 *>(slots[j].res + 16 * wave + 4 * kq) = v;
-  };
-  auto collect = [&](float (&out)[FC]) {  // after the barrier that follows the product
-    const float2 t = *reinterpret_cast<const float2 *>(me.res + cf);
-    out[0] = t.x, out[1] = t.y;
-  };
-  // between the two barriers of a pass every wave has a matrix-pipe block (its tile of the product) and a vector-pipe block (its
-  // own row's tile entries): half of the waves of every SIMD take one first, half the other
-  const bool product_first = ((wave >> 2) & 1) == 0;
-
-  const int groups = (count + ROWS - 1) / ROWS, g_step = gridDim.x;
-  auto row_id = [&](int g) { return order[first + min(g * ROWS + wave, count - 1)]; };
-  auto row_valid = [&](int g) { return g < groups && g * ROWS + wave < count; };
-  int id0 = row_id(blockIdx.x), id1 = row_id(blockIdx.x + g_step), id2 = row_id(blockIdx.x + 2 * g_step), id3 = row_id(blockIdx.x + 3 * g_step);
-  int b0 = indptr[id0], e0 = indptr[id0 + 1], b1 = indptr[id1], e1 = indptr[id1 + 1], b2 = indptr[id2], e2 = indptr[id2 + 1];
-  int ent_col, ent_cnt = row_valid(blockIdx.x) ? e0 - b0 : 0;
-  float ent_c;
-  fetch_entries(indices, data, opaque(lane), b0, max(e0, b0 + 1), ent_col, ent_c);
-  bool tile_ready = false;
-  int cnt = 0;
-  f32x2 y[8][FE / 2];
-  float x[FC];
-  auto kill = [](float (&v)[FC]) { v[0] = v[1] = 0.f; };
-  kill(x);
-  for (int g = blockIdx.x; g < groups; g += g_step) {
-    const bool valid = row_valid(g);
-    ST *xrow = X + (size_t)id0 * F;
-    if (!tile_ready) {
-      cnt = ent_cnt;
-      ent_col = opaque(ent_col);
-      ent_c = __int_as_float(opaque(__float_as_int(ent_c)));
-      static_for<4>([&](auto Pc) {
-        constexpr int P = decltype(Pc)::value;
-        if (8 * P < cnt) gather_pair<F, P>(y, cw, ent_col, ent_c, cnt, Y, lane);
-      });
-      ent_cnt = row_valid(g + g_step) ? e1 - b1 : 0;
-      fetch_entries(indices, data, opaque(lane), b1, max(e1, b1 + 1), ent_col, ent_c);
-      load_compact<F>(xrow, opaque(lane), x);
-    }
-    float xc[FC], r[FC], p[FC], Ap[FC], sp[FC];
-    xc[0] = x[0], xc[1] = x[1];
-    // r = -(A0 x) + sum_k (c+ - (|c|-1) y.x) y        (_als.pyx:187-201)
-    publish(xc, valid);
-    if (!product_first) tile_pass<F, true, false, ST>(y, cw, cnt, prow, sp, lane, 0, ent_col, ent_c, Y);
-    product();
-    if (product_first) tile_pass<F, true, false, ST>(y, cw, cnt, prow, sp, lane, 0, ent_col, ent_c, Y);
-    __syncthreads();
-    collect(Ap);
-    p[0] = r[0] = sp[0] - Ap[0], p[1] = r[1] = sp[1] - Ap[1];
-    float rsold = dot_compact<F>(r, r);
-    bool active = valid && rsold >= 1e-20f;  // else: x untouched (_als.pyx:206)
-    const bool store = active;
-    for (int it = 0; it + 1 < cg_steps; ++it) {  // all steps but the last; every wave takes the barriers
-      publish(p, active);
-      if (active && !product_first) tile_pass<F, false, false, ST>(y, cw, cnt, prow, sp, lane, 0, ent_col, ent_c, Y);
-      product();
-      if (active && product_first) tile_pass<F, false, false, ST>(y, cw, cnt, prow, sp, lane, 0, ent_col, ent_c, Y);
-      __syncthreads();
-      collect(Ap);
-      if (active) {
-        Ap[0] += sp[0], Ap[1] += sp[1];
-        const float alpha = rsold * __builtin_amdgcn_rcpf(dot_compact<F>(p, Ap));
-        xc[0] = fmaf(alpha, p[0], xc[0]), xc[1] = fmaf(alpha, p[1], xc[1]);
-        r[0] = fmaf(-alpha, Ap[0], r[0]), r[1] = fmaf(-alpha, Ap[1], r[1]);
-        const float rsnew = dot_compact<F>(r, r);
-        if (rsnew < 1e-20f) {
-          active = false;  // the oracle breaks here (_als.pyx:235); the wave keeps taking the barriers
-        } else {
-          const float beta = rsnew * __builtin_amdgcn_rcpf(rsold);
-          p[0] = fmaf(beta, p[0], r[0]), p[1] = fmaf(beta, p[1], r[1]);
-          rsold = rsnew;
-        }
-      }
-    }
-    // last step: only its x update is evaluated; its tile pass rolls the next group's entries in
-    bool rolled = false;
-    if (cg_steps > 0) {
-      publish(p, active);
-      auto last_tiles = [&]() {
-        if constexpr (ROLL) tile_pass<F, false, true, ST>(y, cw, cnt, prow, sp, lane, ent_cnt, ent_col, ent_c, Y);
-        else tile_pass<F, false, false, ST>(y, cw, cnt, prow, sp, lane, 0, ent_col, ent_c, Y);
-      };
-      if (active && !product_first) last_tiles();
-      product();
-      if (active && product_first) last_tiles();
-      __syncthreads();
-      collect(Ap);
-      if (active) {
-        if constexpr (ROLL) {
-          cnt = ent_cnt;
-          ent_cnt = row_valid(g + 2 * g_step) ? e2 - b2 : 0;
-          fetch_entries(indices, data, opaque(lane), b2, max(e2, b2 + 1), ent_col, ent_c);
-          load_compact<F>(X + (size_t)id1 * F, opaque(lane), x);
-          rolled = true;
-        } else {
-          kill(x);
-        }
-        Ap[0] += sp[0], Ap[1] += sp[1];
-        const float alpha = rsold * __builtin_amdgcn_rcpf(dot_compact<F>(p, Ap));
-        xc[0] = fmaf(alpha, p[0], xc[0]), xc[1] = fmaf(alpha, p[1], xc[1]);
-      } else {
-        kill(x);
-      }
-    } else {
-      kill(x);
-    }
-    if (store) store_compact<F>(xrow, opaque(lane), xc);
-    tile_ready = rolled;
-    id0 = id1, id1 = id2, id2 = id3, id3 = row_id(g + 4 * g_step);
-    b0 = b1, e0 = e1, b1 = b2, e1 = e2, b2 = indptr[id2], e2 = indptr[id2 + 1];
-  }
-}
-
-template <typename T>
-static void launch_g8(const imp_csr *C, int first, int count, T *X, const T *Y, const float *A0, int cg_steps, const char *name) {
-  if (count <= 0) return;
-  const size_t lds = (size_t)2 * 32 * 64 * 8 * 2 + 8 * sizeof(G8Slot) + 8 * sizeof(int);
-  auto kern = als_cg_g8_kernel<T>;
-  IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  static const int per_cu = getenv("IMP_QGROUP_PER_CU") ? std::max(1, atoi(getenv("IMP_QGROUP_PER_CU"))) : 2;
-  int grid = std::min((count + 7) / 8, ctx().num_cus * 2 * std::max(per_cu, ctx().oversub));
-  IMP_PROF(name);
-  kern<<<grid, 512, lds, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(), C->data.data(), X, Y, A0, cg_steps);
-  IMP_CHECK_HIP(hipGetLastError());
-}
-
 template <int F, typename T>
 static void launch_qfgroup(const imp_csr *C, int first, int count, T *X, const T *Y, const float *A0, int cg_steps, const char *name) {
   if (count <= 0) return;
@@ -1071,10 +868,7 @@ static void launch_qfgroup(const imp_csr *C, int first, int count, T *X, const T
 
 template <typename T>
 void launch_group_fused(const imp_csr *C, int f, int first, int count, T *X, const T *Y, const float *A0, int cg_steps, const char *name) {
-  // IMP_SHORT_G8=1 (experiment): 8 rows per 512-thread workgroup, two workgroups per CU, fp16 two-term product
-  static const bool g8 = getenv("IMP_SHORT_G8") && atoi(getenv("IMP_SHORT_G8")) != 0;
-  if (f == 128 && g8) launch_g8<T>(C, first, count, X, Y, A0, cg_steps, name);
-  else if (f == 128) launch_qfgroup<128, T>(C, first, count, X, Y, A0, cg_steps, name);
+  if (f == 128) launch_qfgroup<128, T>(C, first, count, X, Y, A0, cg_steps, name);
   else if (f == 64) launch_qfgroup<64, T>(C, first, count, X, Y, A0, cg_steps, name);
   else throw std::invalid_argument("launch_group_fused: f must be 64 or 128");
 }
