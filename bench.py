@@ -233,6 +233,10 @@ def main():
             sys.exit("bench.py --gpus N (N>1) must be launched with torch.distributed.run, one rank per GPU")
         args.gpus = world
 
+    if os.environ.get("IMP_LIB_PATH"):  # tooling only: A/B of compile-time variants (python -m implicit_amd._build --variant ...)
+        import implicit_amd._libpath as _libpath
+
+        _libpath.OVERRIDE = os.environ["IMP_LIB_PATH"]
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         import implicit_amd.gpu as gpu

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libimplicit_hip.so")
-SOURCES = ["containers.hip", "als_cg.hip", "als_cg_q.hip", "als_cg_qf.hip", "als_cg_qh.hip", "als_cg_cluster.hip", "als_cg_nm.hip", "als_cg_w256.hip", "als_cholesky.hip", "gramian.hip", "solver.hip", "topk.hip",
+SOURCES = ["containers.hip", "als_cg.hip", "als_cg_q.hip", "als_cg_qf.hip", "als_cg_qh.hip", "als_cg_fixup.hip", "als_cg_nm.hip", "als_cg_w256.hip", "als_cholesky.hip", "gramian.hip", "solver.hip", "topk.hip",
            "random.hip", "comm.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

@@ -31,7 +31,6 @@
 namespace imp {
 
 template <typename T> void least_squares_cg_q(const imp_csr *C, T *X, const T *Y, const float *A0, int f, int cg_steps);  // als_cg_q.hip
-template <typename T> void least_squares_cg_cluster(const imp_csr *C, T *X, const T *Y, const float *A0, int f, int cg_steps);  // als_cg_cluster.hip
 void least_squares_cg_w256(const imp_csr *C, float *X, const float *Y, const float *A0, int cg_steps);  // als_cg_w256.hip
 template <typename T> void least_squares_cg_nm(const imp_csr *C, T *X, const T *Y, size_t y_rows, const float *A0, int f, int cg_steps);  // als_cg_nm.hip
 
@@ -640,33 +639,22 @@ static void launch_all(const imp_csr *C, T *X, const T *Y, size_t y_rows, const 
   // schedule classes (imp_csr): 0 long (segment-split), 1..4 mid, 5..6 short, 7 empty
   const int32_t *b = C->bin_start;
   if constexpr (VEC && A_LDS && (VPL == 1 || VPL == 2)) {
-    // f = 64 / 128: rows of 513 .. kClusterRow nonzeros are resident across a cluster of workgroups (als_cg_cluster.hip);
-    // only the rows beyond that are streamed.  IMP_NO_CLUSTER=1: every long row streamed (A/B, parity)
-    static const bool no_cluster = getenv("IMP_NO_CLUSTER") != nullptr;
-    // IMP_CLASS_STREAMS=1: the row classes' kernels on four streams, joined before the call returns (common.h ClassStreams)
-    static const bool class_streams = getenv("IMP_CLASS_STREAMS") && atoi(getenv("IMP_CLASS_STREAMS")) != 0;
-    ClassStreams streams(class_streams);
-    if (nm_enabled() && !no_cluster && !team16_as_cluster()) {
-      least_squares_cg_nm<T>(C, X, Y, y_rows, A0, f, cg_steps);  // round 4: the row's normal matrix on the matrix cores, CG on the LDS image
-    } else {
-      launch_long<VPL, VEC, A_LDS, T>(C, no_cluster ? C->plan_all : C->plan_xl, X, Y, A0, f, cg_steps);
-      if (!no_cluster) least_squares_cg_cluster<T>(C, X, Y, A0, f, cg_steps);
-    }
+    // f = 64 / 128: rows of more than 512 nonzeros through their explicit normal matrix on the matrix cores (als_cg_nm.hip).
+    // IMP_NM=0: one streamed pass per CG step instead (A/B, parity; the workgroup clusters of rounds 2-3 are gone)
+    if (nm_enabled()) least_squares_cg_nm<T>(C, X, Y, y_rows, A0, f, cg_steps);
+    else launch_long<VPL, VEC, A_LDS, T>(C, C->plan_all, X, Y, A0, f, cg_steps);
     least_squares_cg_q<T>(C, X, Y, A0, f, cg_steps);  // quarter-layout register tiles, wave teams (als_cg_q.hip)
   } else if constexpr (std::is_same<T, float>::value) {
     launch_long<VPL, VEC, A_LDS, T>(C, C->plan_all, X, Y, A0, f, cg_steps);
-    if constexpr (VEC && VPL == 4 && !A_LDS) {  // f = 256: workgroup-shared gramian.  IMP_F256_GENERIC=1: the generic kernel (A/B)
-      static const bool generic256 = getenv("IMP_F256_GENERIC") != nullptr;
-      if (!generic256) {
-        if (w256_enabled()) {  // round 5: rows of <= 256 nonzeros resident, 16 / WPR rows per workgroup in lock step (als_cg_w256.hip)
-          launch_f256(C, b[1], b[2] - b[1], X, Y, A0, cg_steps, "als_cg_mid_rows");
-          least_squares_cg_w256(C, X, Y, A0, cg_steps);
-        } else {
-          launch_f256(C, b[1], b[7] - b[1], X, Y, A0, cg_steps, "als_cg_mid_rows");
-        }
-        zero_rows_t<T>(C->order.data(), C->first_empty(), C->n_empty(), X, f);
-        return;
+    if constexpr (VEC && VPL == 4 && !A_LDS) {  // f = 256: workgroup-shared gramian
+      if (w256_enabled()) {  // round 5: rows of <= 256 nonzeros resident, 16 / WPR rows per workgroup in lock step (als_cg_w256.hip)
+        launch_f256(C, b[1], b[2] - b[1], X, Y, A0, cg_steps, "als_cg_mid_rows");
+        least_squares_cg_w256(C, X, Y, A0, cg_steps);
+      } else {  // IMP_F256_OLD=1: every row streamed (A/B, parity)
+        launch_f256(C, b[1], b[7] - b[1], X, Y, A0, cg_steps, "als_cg_mid_rows");
       }
+      zero_rows_t<T>(C->order.data(), C->first_empty(), C->n_empty(), X, f);
+      return;
     }
     bool resident_ok = false;
     if constexpr (VEC) resident_ok = tile_size<VPL>() >= imp_csr::kShortRow;

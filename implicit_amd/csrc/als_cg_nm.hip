@@ -872,10 +872,10 @@ template <int F, typename T> void launch_nm(const imp_csr *C, T *X, const T *Y, 
   IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   {
     IMP_PROF("als_cg_nm_rows");
-    static const int forced_k = getenv("IMP_NM_SCALE") ? atoi(getenv("IMP_NM_SCALE")) : -1;  // A/B and tests: fixed operand scale 2^k
+    constexpr int forced_k = -1;  // (>= 0: a fixed operand scale 2^k instead of the one taken from the gramian's diagonal)
     nm_gram_image_kernel<F><<<(L::IMG + 255) / 256, 256, 0, stream()>>>(A0, gram_img, tk.data(), (float)y_rows, std::min(forced_k, 16));
     const int grid = std::min(lp.n_seg, ctx().num_cus * 2);  // two resident workgroups per CU; the ticket counter balances them
-    static const int ko = getenv("IMP_NM_KO") ? atoi(getenv("IMP_NM_KO")) : 0;
+    constexpr int ko = 0;  // (timing-only knock-outs of the kernel's phases: 1 rounds, 2 image, 4 CG)
     kern<<<grid, 256, lds, stream()>>>(plan, C->indices.data(), C->data.data(), X, Y, gram_img, cg_steps, partial, tk.data(), fix.data(), ko);
     IMP_CHECK_HIP(hipGetLastError());
   }
@@ -916,7 +916,7 @@ CholNmList least_squares_cholesky_nm(const imp_csr *C, float *X, const float *Y,
   auto &fix = ctx().nm_fix_rows;
   const int capacity = C->nonempty();
   if (fix.size < (size_t)std::max(capacity, 1)) fix.alloc((size_t)std::max(capacity, 1));
-  static const int forced_k = getenv("IMP_NM_SCALE") ? atoi(getenv("IMP_NM_SCALE")) : -1;
+  constexpr int forced_k = -1;
   {
     IMP_PROF("als_cholesky_nm_long");
     nm_gram_image_kernel<F><<<(L::IMG + 255) / 256, 256, 0, stream()>>>(YtY, gram_img, tk.data(), (float)y_rows, std::min(forced_k, 16), reg);

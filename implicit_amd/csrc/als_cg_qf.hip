@@ -169,27 +169,13 @@ __device__ __forceinline__ void fused_pass(f32x2 (&y)[8][F / 32], float *cw, int
   }
 }
 
-// STATS (debug, IMP_CG_STATS=1; timings only): shader-clock cycles summed over the waves of the launch --
-//   [0] waiting for the leader's operand  [1] passes (operand read, dense ticks + tile steps, reduce)  [2] partial -> LDS, arrival
-//   [3] leader: waiting for the team's arrivals  [4] leader: sum of the partials, CG update, publish  [5] row start (gathers
-//   of a row that was not rolled in, iterate load)  [6] wave lifetime  [7] wave-rows
-template <int F, int WPR, int BLOCK, typename ST, bool STATS = false>
+template <int F, int WPR, int BLOCK, typename ST>
 __global__ __launch_bounds__(BLOCK, F == 64 ? 8 : 4) void als_cg_qfteam_kernel(const int32_t *__restrict__ order, int first, int count,
                                                                  const int32_t *__restrict__ indptr,
                                                                  const int32_t *__restrict__ indices,
                                                                  const float *__restrict__ data, ST *__restrict__ X,
                                                                  const ST *__restrict__ Y, const float *__restrict__ A0,
-                                                                 int cg_steps, unsigned long long *__restrict__ stats = nullptr) {
-  unsigned long long tk[6] = {0, 0, 0, 0, 0, 0}, t_last = 0, t_begin = 0, n_rows = 0;
-  auto tick = [&](int slot) {  // charge the time since the previous tick to `slot`
-    if constexpr (STATS) {
-      __builtin_amdgcn_sched_barrier(0);
-      const unsigned long long now = __builtin_amdgcn_s_memtime();
-      if (slot >= 0) tk[slot] += now - t_last;
-      t_last = now;
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
+                                                                 int cg_steps) {
   constexpr int FC = F / 64, FE = F / 16, T = 32, WAVES = BLOCK / 64, TEAMS = WAVES / WPR, NJ = F / WPR / 4;
   constexpr bool ROLL = std::is_same<ST, float>::value;  // fp16 storage converts at the load: no rolling gather
   static_assert(WPR <= WAVES && (F / WPR) % 4 == 0, "team width");
@@ -206,8 +192,6 @@ __global__ __launch_bounds__(BLOCK, F == 64 ? 8 : 4) void als_cg_qfteam_kernel(c
   for (int e = threadIdx.x; e < F * F; e += BLOCK) A0s[e] = A0[e];
   if (threadIdx.x < 4 * TEAMS) ctl[threadIdx.x] = 0u;
   __syncthreads();  // the only workgroup-wide barrier: from here on the teams run their rows independently
-  tick(-1);
-  if constexpr (STATS) t_begin = t_last;
   const int j_begin = F * sub / WPR;
   float *vt = vts + (size_t)team * F;
   float *cw = cws + (size_t)wave * 64;
@@ -268,7 +252,6 @@ __global__ __launch_bounds__(BLOCK, F == 64 ? 8 : 4) void als_cg_qfteam_kernel(c
       while (poll(arrivals_off) < arr_target) __builtin_amdgcn_s_sleep(IMP_TEAM_NAP_LEADER);
     }
     if constexpr (IMP_TEAM_LEADER_PRIO > 0) __builtin_amdgcn_s_setprio(IMP_TEAM_LEADER_PRIO);
-    tick(3);
     const float *slot = reinterpret_cast<const float *>(reinterpret_cast<const char *>(parts + (size_t)(team * WPR) * F) + cf4);
 #pragma unroll
     for (int c = 0; c < FC; ++c) acc[c] = 0.f;
@@ -342,8 +325,6 @@ __global__ __launch_bounds__(BLOCK, F == 64 ? 8 : 4) void als_cg_qfteam_kernel(c
       if (leader) load_compact<F>(xrow, opaque(lane), x);  // last: loads complete in order and the row starts with x
       else kill(x);
     }
-    tick(5);
-    if constexpr (STATS) ++n_rows;
     // ent_* now describe row i + i_step
     float xc[FC], r[FC], p[FC], Ap[FC], rsold = 0.f;  // leader state
 #pragma unroll
@@ -354,16 +335,12 @@ __global__ __launch_bounds__(BLOCK, F == 64 ? 8 : 4) void als_cg_qfteam_kernel(c
 #pragma unroll
       for (int cc = 0; cc < FC; ++cc) xc[cc] = x[cc];  // this row's iterate moves on as xc; x is re-loaded for the next row
       publish(kGo);
-      tick(4);
     }
     unsigned w = await_operand();
-    tick(0);
     {
       float acc[FC];
       fused_pass<F, NJ, true, false, ST>(y, cw, cnt, vt, j_begin, A0s, acc, lane, 0, ent_col, ent_c, Y, nullptr, nullptr, 0, 0);
-      tick(1);
       arrive(acc);
-      tick(2);
     }
     if (leader) {
       collect(r);
@@ -377,16 +354,12 @@ __global__ __launch_bounds__(BLOCK, F == 64 ? 8 : 4) void als_cg_qfteam_kernel(c
       } else {
         publish(0u);
       }
-      tick(4);
     }
     w = await_operand();
-    tick(0);
     for (int it = 0; (w & (kGo | kLast)) == kGo; ++it) {  // all steps but the last
       float acc[FC];
       fused_pass<F, NJ, false, false, ST>(y, cw, cnt, vt, j_begin, A0s, acc, lane, 0, ent_col, ent_c, Y, nullptr, nullptr, 0, 0);
-      tick(1);
       arrive(acc);
-      tick(2);
       if (leader) {
         collect(Ap);
         get_operand(p);
@@ -407,10 +380,8 @@ __global__ __launch_bounds__(BLOCK, F == 64 ? 8 : 4) void als_cg_qfteam_kernel(c
           put_operand(p);
           publish(kGo | (it + 2 >= cg_steps ? kLast : 0u));
         }
-        tick(4);
       }
       w = await_operand();
-      tick(0);
     }
     // The last step stands outside the loop (the compiler must see that nothing of the row follows it): its pass rolls
     // the next row's tile in, and only its x update is evaluated -- the oracle's r, rsnew and p of the last step
@@ -432,9 +403,7 @@ __global__ __launch_bounds__(BLOCK, F == 64 ? 8 : 4) void als_cg_qfteam_kernel(c
         kill(x);
         fused_pass<F, NJ, false, false, ST>(y, cw, cnt, vt, j_begin, A0s, acc, lane, 0, ent_col, ent_c, Y, nullptr, nullptr, 0, 0);
       }
-      tick(1);
       arrive(acc);
-      tick(2);
       if (leader) {
         collect(Ap);
         get_operand(p);
@@ -442,10 +411,8 @@ __global__ __launch_bounds__(BLOCK, F == 64 ? 8 : 4) void als_cg_qfteam_kernel(c
 #pragma unroll
         for (int cc = 0; cc < FC; ++cc) xc[cc] = fmaf(alpha, p[cc], xc[cc]);
         publish(0u);
-        tick(4);
       }
       (void)await_operand();  // the stop generation: keeps every wave's count in step with the leader's
-      tick(0);
     } else {
       kill(x);
     }
@@ -453,14 +420,6 @@ __global__ __launch_bounds__(BLOCK, F == 64 ? 8 : 4) void als_cg_qfteam_kernel(c
     tile_ready = rolled;
     id0 = id1, id1 = id2, id2 = id3, id3 = row_id(i + 4 * i_step);
     b0 = b1, e0 = e1, b1 = b2, e1 = e2, b2 = indptr[id2], e2 = indptr[id2 + 1];
-  }
-  if constexpr (STATS) {
-    if (lane == 0) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) atomicAdd(&stats[k], tk[k]);
-      atomicAdd(&stats[6], (unsigned long long)__builtin_amdgcn_s_memtime() - t_begin);
-      atomicAdd(&stats[7], n_rows);
-    }
   }
 }
 
@@ -477,29 +436,9 @@ static void launch_qfteam(const imp_csr *C, int first, int count, T *X, const T 
   // configs[1]-shaped CG 1.47 -> 1.42 ms, and a fixed share on a contended CU is what took seconds once
   constexpr int kBaseOversub = WPR <= 4 ? 4 : (WPR == 8 ? 2 : (F == 64 ? 2 : 1));
   int grid = std::min((count + TEAMS - 1) / TEAMS, ctx().num_cus * per_cu * std::max(kBaseOversub, ctx().oversub));
-  static const bool want_stats = getenv("IMP_CG_STATS") != nullptr;
-  if (want_stats) {  // debug: per-phase cycle sums of this launch on stderr (instrumented instantiation: timings only)
-    static unsigned long long *stats = nullptr;
-    if (!stats) IMP_CHECK_HIP(hipMalloc(&stats, 8 * sizeof(unsigned long long)));
-    IMP_CHECK_HIP(hipMemsetAsync(stats, 0, 8 * sizeof(unsigned long long), stream()));
-    auto skern = als_cg_qfteam_kernel<F, WPR, BLOCK, T, true>;
-    IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(skern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    skern<<<grid, BLOCK, lds, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(), C->data.data(), X, Y, A0,
-                                          cg_steps, stats);
-    unsigned long long h[8];
-    IMP_CHECK_HIP(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, stream()));
-    IMP_CHECK_HIP(hipStreamSynchronize(stream()));
-    const double n = (double)std::max<unsigned long long>(1, h[7]);
-    const double leaders = n / WPR;
-    fprintf(stderr,
-            "[cg-stats] %s rows=%d wave-rows=%.0f  cycles/wave-row: wait-operand %.0f  passes %.0f  arrive %.0f  row-start %.0f  "
-            "lifetime %.0f | per leader-row: wait-arrivals %.0f  update %.0f\n",
-            name, count, n, h[0] / n, h[1] / n, h[2] / n, h[5] / n, h[6] / n, h[3] / leaders, h[4] / leaders);
-    return;
-  }
   IMP_PROF(name);
   kern<<<grid, BLOCK, lds, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(), C->data.data(), X, Y,
-                                      A0, cg_steps, nullptr);
+                                      A0, cg_steps);
   IMP_CHECK_HIP(hipGetLastError());
 }
 
@@ -847,19 +786,17 @@ __global__ __launch_bounds__(1024) void als_cg_qfgroup_kernel(const int32_t *__r
   }
 }
 
-template <int F, typename T>
+template <typename T>
 static void launch_qfgroup(const imp_csr *C, int first, int count, T *X, const T *Y, const float *A0, int cg_steps, const char *name) {
   if (count <= 0) return;
-  // IMP_SHORT_STAGGER=0: every wave runs the product first, then its tile entries (the first round-3 form; A/B)
-  static const bool stagger = !(getenv("IMP_SHORT_STAGGER") && atoi(getenv("IMP_SHORT_STAGGER")) == 0);
-  // IMP_SHORT_BF16X3=0: the gramian product on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains) instead of the split-bf16 form
-  static const bool bf3 = F == 128 && !(getenv("IMP_SHORT_BF16X3") && atoi(getenv("IMP_SHORT_BF16X3")) == 0);
-  size_t lds = bf3 ? QFGroupCfg<F>::lds_bytes_bf3 : QFGroupCfg<F>::lds_floats * sizeof(float);
-  auto kern = bf3 ? (stagger ? als_cg_qfgroup_kernel<F, true, F == 128, T> : als_cg_qfgroup_kernel<F, false, F == 128, T>)
-                  : (stagger ? als_cg_qfgroup_kernel<F, true, false, T> : als_cg_qfgroup_kernel<F, false, false, T>);
+  // the one form kept: staggered pipes, the product on the bf16 matrix cores with three-term operands (f = 128).  The unstaggered
+  // order and the exact-fp32 MFMA product (template arguments STAGGER / BF3 = false; IMP_SHORT_STAGGER, IMP_SHORT_BF16X3 until
+  // round 5) are no longer instantiated.
+  constexpr int F = 128;
+  const size_t lds = QFGroupCfg<F>::lds_bytes_bf3;
+  auto kern = als_cg_qfgroup_kernel<F, true, true, T>;
   IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  static const int per_cu = getenv("IMP_QGROUP_PER_CU") ? std::max(1, atoi(getenv("IMP_QGROUP_PER_CU"))) : 2;
-  int grid = std::min((count + 15) / 16, ctx().num_cus * std::max(per_cu, ctx().oversub));
+  int grid = std::min((count + 15) / 16, ctx().num_cus * std::max(2, ctx().oversub));  // (1 / 2 / 3 per CU measured within 1 %)
   IMP_PROF(name);
   kern<<<grid, 1024, lds, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(), C->data.data(), X, Y, A0,
                                       cg_steps);
@@ -868,9 +805,8 @@ static void launch_qfgroup(const imp_csr *C, int first, int count, T *X, const T
 
 template <typename T>
 void launch_group_fused(const imp_csr *C, int f, int first, int count, T *X, const T *Y, const float *A0, int cg_steps, const char *name) {
-  if (f == 128) launch_qfgroup<128, T>(C, first, count, X, Y, A0, cg_steps, name);
-  else if (f == 64) launch_qfgroup<64, T>(C, first, count, X, Y, A0, cg_steps, name);
-  else throw std::invalid_argument("launch_group_fused: f must be 64 or 128");
+  if (f == 128) launch_qfgroup<T>(C, first, count, X, Y, A0, cg_steps, name);
+  else throw std::invalid_argument("launch_group_fused: f must be 128 (f = 64 short rows run on independent wavefronts)");
 }
 template void launch_group_fused<float>(const imp_csr *, int, int, int, float *, const float *, const float *, int, const char *);
 template void launch_group_fused<__half>(const imp_csr *, int, int, int, __half *, const __half *, const float *, int, const char *);

@@ -70,31 +70,11 @@ __device__ __forceinline__ float mul_mix_hi(unsigned yh, float b) {
   return d;
 }
 
-// One register-resident element of the tile = expanded slots (2 h, 2 h + 1) of an entry: a packed fp32 pair for fp32 storage,
-// two halves in one register for fp16 storage.  The products associate alike in both (and as in als_cg_qf.hip): even slots in
+// One register-resident element of the tile = expanded slots (2 h, 2 h + 1) of an entry: two halves in one register.  (The fp32
+// form of this tile -- a packed fp32 pair per element, two "fat" wavefronts per SIMD -- measured slower than the 32-entry tiles of
+// als_cg_qf.hip in round 4 and was removed in round 6.)  The products associate alike in both (and as in als_cg_qf.hip): even slots in
 // one running sum, odd slots in the other.
 template <typename ST> struct Tile64;
-template <> struct Tile64<float> {
-  typedef f32x2 elem;
-  template <int H> static __device__ __forceinline__ void gather(elem (&yq)[H], const float *p) {
-#pragma unroll
-    for (int h = 0; h < H; h += 2) {  // expanded slots 2 h .. 2 h + 3 = factors 64 (h / 2) + 4 m ..: one 16-byte load
-      const float4 v = load4(p + 32 * h);
-      yq[h] = f32x2{v.x, v.y}, yq[h + 1] = f32x2{v.z, v.w};
-    }
-  }
-  template <int H> static __device__ __forceinline__ float dot(const elem (&yq)[H], const f32x2 (&ve)[H]) {
-    f32x2 s = yq[0] * ve[0];
-#pragma unroll
-    for (int h = 1; h < H; ++h) s = __builtin_elementwise_fma(yq[h], ve[h], s);
-    return s.x + s.y;
-  }
-  template <int H> static __device__ __forceinline__ void axpy(const elem (&yq)[H], float w, f32x2 (&ae)[H]) {
-    const f32x2 w2 = {w, w};
-#pragma unroll
-    for (int h = 0; h < H; ++h) ae[h] = __builtin_elementwise_fma(w2, yq[h], ae[h]);
-  }
-};
 template <> struct Tile64<__half> {
   typedef unsigned elem;
   template <int H> static __device__ __forceinline__ void gather(elem (&yq)[H], const __half *p) {
@@ -501,7 +481,6 @@ void launch_team_tile64(const imp_csr *C, int f, int width, int first, int count
   else if (f == 64) run(idx_t<64>{});
   else throw std::invalid_argument("launch_team_tile64: f must be 64 or 128");
 }
-template void launch_team_tile64<float>(const imp_csr *, int, int, int, int, float *, const float *, const float *, int, const char *);
 template void launch_team_tile64<__half>(const imp_csr *, int, int, int, int, __half *, const __half *, const float *, int, const char *);
 
 }  // namespace imp

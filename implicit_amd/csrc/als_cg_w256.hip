@@ -557,7 +557,7 @@ void launch_w256_class(const imp_csr *C, int first, int count, float *X, const f
   const int groups = (count + R - 1) / R;
   // one workgroup per CU is resident; four times as many with proportionally smaller shares even out the end of the launch
   const int grid = std::min(groups, ctx().num_cus * std::max(4, ctx().oversub));
-  static const int ko = getenv("IMP_W256_KO") ? atoi(getenv("IMP_W256_KO")) : 0;
+  constexpr int ko = 0;  // (timing-only knock-outs: 1 product, 2 tile entries, 4 gathers, 8 leader update)
   IMP_PROF(name);
   kern<<<grid, 1024, lds_bytes, stream()>>>(C->order.data(), first, count, C->indptr.data(), C->indices.data(), C->data.data(), X, Y,
                                               gfrag, hdr, cg_steps, ko);

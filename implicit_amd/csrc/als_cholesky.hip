@@ -24,119 +24,6 @@ __device__ __forceinline__ float bcast_lane(float v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 
-// PACKED: the augmented lower triangle stored row after row without padding (row i at i (i + 1) / 2): 133 KB at f = 256,
-// where the square image (264 KB) does not fit the 160 KB of LDS -- the form the factor counts above 160 run in
-template <bool PACKED>
-__global__ __launch_bounds__(256) void als_cholesky_kernel(const int32_t *__restrict__ order, int first, int count,
-                                                           const int32_t *__restrict__ indptr,
-                                                           const int32_t *__restrict__ indices,
-                                                           const float *__restrict__ data, float *__restrict__ X,
-                                                           const float *__restrict__ Y, const float *__restrict__ YtY,
-                                                           int f, float reg, int lda, unsigned long long *failed_row) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *A = smem;                              // [(f+1)][lda] lower triangle used, row f = b^T -> z^T
-  auto at = [&](int i, int j) { return PACKED ? i * (i + 1) / 2 + j : i * lda + j; };  // j <= i
-  float *yt = A + (PACKED ? (size_t)(f + 1) * (f + 2) / 2 : (size_t)(f + 1) * lda);  // [TILE][f]   gathered rows
-  float *ut = yt + (size_t)kCholTile * f;       // [TILE][f+1] (|c|-1) * y, last = c+
-  const int tid = threadIdx.x;
-  const int ti = tid >> 4, tj = tid & 15;
-
-  for (int ri = blockIdx.x; ri < count; ri += gridDim.x) {
-    const int u = order[first + ri];
-    const int row_begin = indptr[u], row_end = indptr[u + 1];
-
-    // A = YtY + reg I (lower triangle), b = 0
-    for (int i = ti; i <= f; i += 16)
-      for (int j = tj; j <= i && j < f; j += 16)
-        A[at(i, j)] = i < f ? YtY[(size_t)i * f + j] + (i == j ? reg : 0.f) : 0.f;
-    __syncthreads();
-
-    for (int k0 = row_begin; k0 < row_end; k0 += kCholTile) {
-      const int cnt = min(kCholTile, row_end - k0);
-      // stage the tile: one wave per gathered row -> coalesced
-      for (int e = tid; e < kCholTile * f; e += 256) {
-        int t = e / f, c = e - t * f;
-        float yv = 0.f, uv = 0.f;
-        if (t < cnt) {
-          float conf = data[k0 + t];
-          float a = conf > 0.f ? conf : -conf;
-          yv = Y[(size_t)indices[k0 + t] * f + c];
-          uv = (a - 1.f) * yv;
-        }
-        yt[t * f + c] = yv;
-        ut[t * (f + 1) + c] = uv;
-      }
-      if (tid < kCholTile) {
-        float conf = tid < cnt ? data[k0 + tid] : 0.f;
-        ut[tid * (f + 1) + f] = conf > 0.f ? conf : 0.f;
-      }
-      __syncthreads();
-      for (int i = ti; i <= f; i += 16)
-        for (int j = tj; j <= i && j < f; j += 16) {
-          float s = A[at(i, j)];
-#pragma unroll
-          for (int t = 0; t < kCholTile; ++t) s = fmaf(ut[t * (f + 1) + i], yt[t * f + j], s);
-          A[at(i, j)] = s;
-        }
-      __syncthreads();
-    }
-
-    // right-looking Cholesky of the first f columns of the augmented triangle
-    bool ok = true;
-    for (int k = 0; k < f; ++k) {
-      float d = A[at(k, k)];
-      if (!(d > 0.f)) {  // uniform: every thread reads the same LDS word
-        ok = false;
-        break;
-      }
-      float inv = 1.0f / sqrtf(d);
-      __syncthreads();  // everyone has read the pivot
-      for (int i = k + tid; i <= f; i += 256) A[at(i, k)] = i == k ? sqrtf(d) : A[at(i, k)] * inv;
-      __syncthreads();
-      for (int i = k + 1 + ti; i <= f; i += 16) {
-        float lik = A[at(i, k)];
-        for (int j = k + 1 + tj; j <= i && j < f; j += 16) A[at(i, j)] = fmaf(-lik, A[at(j, k)], A[at(i, j)]);
-      }
-      __syncthreads();
-    }
-    if (!ok) {
-      if (tid == 0) atomicMin(failed_row, (unsigned long long)u);
-      __syncthreads();
-      continue;
-    }
-    // back substitution L^T x = z with one wavefront; lane l owns z[l + 64 m]
-    if (tid < 64) {
-      constexpr int MAXV = 4;  // f <= 256
-      float z[MAXV];
-#pragma unroll
-      for (int m = 0; m < MAXV; ++m) {
-        int i = tid + 64 * m;
-        z[m] = i < f ? A[at(f, i)] : 0.f;
-      }
-      for (int k = f - 1; k >= 0; --k) {
-        float zk = 0.f;
-#pragma unroll
-        for (int m = 0; m < MAXV; ++m)
-          if ((k >> 6) == m) zk = bcast_lane(z[m], k & 63);
-        float xk = zk / A[at(k, k)];
-#pragma unroll
-        for (int m = 0; m < MAXV; ++m) {
-          int i = tid + 64 * m;
-          if (i < k) z[m] = fmaf(-A[at(k, i)], xk, z[m]);
-          if (i == k) z[m] = xk;
-        }
-      }
-#pragma unroll
-      for (int m = 0; m < MAXV; ++m) {
-        int i = tid + 64 * m;
-        if (i < f) X[(size_t)u * f + i] = z[m];
-      }
-    }
-    __syncthreads();
-  }
-}
-
-
 // ---- round 4: the same workgroup-per-row scheme with REGISTER BLOCKS and PANELS -------------------------------------------------
 // The kernel above meets a workgroup barrier three times per column and pays 16 LDS reads for 8 FMAs in its A-build: 546 ms per
 // configs[2]-shaped iteration at f = 128, 0.02 of the fp32 peak -- 400 barrier phases of ~2 K cycles per row.  Here:
@@ -831,7 +718,7 @@ int64_t least_squares_cholesky(const imp_csr *C, imp_matrix *X, const imp_matrix
   // blocks factorise in the same order; the padded block rows never touch the others).  125 -> about 62 ms per configs[2]-shaped
   // iteration at f = 100 against the workgroup kernel.  IMP_CHOL_PAD=0 (and the switches that ask for the workgroup kernels) keep it.
   static const bool chol_pad = !(getenv("IMP_CHOL_PAD") && atoi(getenv("IMP_CHOL_PAD")) == 0) &&
-                               !(getenv("IMP_CHOL_NM") && atoi(getenv("IMP_CHOL_NM")) == 0) && getenv("IMP_CHOL_UNBLOCKED") == nullptr;
+                               !(getenv("IMP_CHOL_NM") && atoi(getenv("IMP_CHOL_NM")) == 0);
   // (not for a handful of rows against a large Y -- fold-in calls: the padded copy of Y would cost more than the solve)
   if (f > 64 && f < 128 && chol_pad && C->nonempty() > 0 && (size_t)C->nnz * 4 >= Y->rows && X->itemsize == 4 && Y->itemsize == 4) {
     constexpr int F = 128;
@@ -850,10 +737,8 @@ int64_t least_squares_cholesky(const imp_csr *C, imp_matrix *X, const imp_matrix
   int lda = (f + 1) | 1;  // odd
   // Packed rows of the augmented triangle (i (i + 1) / 2 + j): a must beyond f = 160, where the square image no longer fits the
   // LDS, and a gain well below that -- at f = 128 the packed image lets THREE workgroups share a CU instead of two (measured
-  // 248 -> 174 ms per configs[2]-shaped iteration for one multiplication more per address).  IMP_CHOL_PACKED=<f0> moves the
-  // switch-over (A/B; 1000: never below the LDS limit)
-  static const int packed_from = getenv("IMP_CHOL_PACKED") ? atoi(getenv("IMP_CHOL_PACKED")) : 96;
-  const bool packed = f > 160 || f >= packed_from;
+  // 248 -> 174 ms per configs[2]-shaped iteration for one multiplication more per address)
+  const bool packed = f >= 96;
   size_t lds = ((packed ? (size_t)(f + 1) * (f + 2) / 2 : (size_t)(f + 1) * lda) + (size_t)kCholTile * f + (size_t)kCholTile * (f + 1)) *
                sizeof(float);
   auto &failb = ctx().chol_failed;
@@ -861,19 +746,14 @@ int64_t least_squares_cholesky(const imp_csr *C, imp_matrix *X, const imp_matrix
   unsigned long long *g_failed = failb.data();
   IMP_CHECK_HIP(hipMemsetAsync(g_failed, 0xFF, sizeof(unsigned long long), stream()));
   int nonempty = C->nonempty();
-  static const bool no_wave = getenv("IMP_CHOL_NO_WAVE") != nullptr;
-  static const bool no_mfma = getenv("IMP_CHOL_NO_MFMA") != nullptr;
-  if (nonempty > 0 && f == 64 && !no_mfma && !no_wave) {
+  if (nonempty > 0 && f == 64) {
     // every non-empty row: MFMA A-build + left-looking Cholesky, one wavefront per row
     const size_t lds_m = ((size_t)64 * 68 + 4 * kCholTri) * sizeof(float);  // 52 KB: 3 workgroups per CU
     // 159 VGPRs, 52 KB LDS: 3 workgroups per CU resident; 8x that many are launched -- smaller fixed shares of the length-sorted
     // schedule, dealt by the hardware dispatcher as slots free up, even out the end of the launch (configs[1]: 14.8 -> 13.8 ms)
     const int grid = std::min((nonempty + 3) / 4, ctx().num_cus * 3 * std::max(8, ctx().oversub));
-    // long rows: segment partials of the A-build first (see als_cholesky_f64_partial_kernel).  IMP_CHOL_NO_SPLIT=1: every row
-    // walked by its own wavefront (A/B)
-    static const bool no_split = getenv("IMP_CHOL_NO_SPLIT") != nullptr;
+    // long rows: segment partials of the A-build first (see als_cholesky_f64_partial_kernel)
     LongPlanDev plan = C->plan_chol.dev(C->order.data());
-    if (no_split) plan.n_long = 0, plan.n_seg = 0;
     const float *partials = nullptr;
     if (plan.n_seg > 0) {
       auto &ws = ctx().long_ws;
@@ -885,38 +765,7 @@ int64_t least_squares_cholesky(const imp_csr *C, imp_matrix *X, const imp_matrix
       als_cholesky_f64_partial_kernel<<<pgrid, 256, 0, stream()>>>(plan, C->indices.data(), C->data.data(), Y->f32(), ws.data());
       IMP_CHECK_HIP(hipGetLastError());
     }
-    static const bool want_stats = getenv("IMP_CHOL_STATS") != nullptr;
-    if (want_stats) {  // debug: per-phase tick sums of this launch, printed to stderr
-      IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(als_cholesky_f64_kernel<true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
-      DeviceArray<unsigned long long> st;
-      st.alloc(8, true);
-      int occ_stats = 0, occ = 0;
-      IMP_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_stats, als_cholesky_f64_kernel<true>, 256, lds_m));
-      IMP_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, als_cholesky_f64_kernel<false>, 256, lds_m));
-      hipEvent_t e0, e1;
-      IMP_CHECK_HIP(hipEventCreate(&e0));
-      IMP_CHECK_HIP(hipEventCreate(&e1));
-      IMP_CHECK_HIP(hipEventRecord(e0, stream()));
-      als_cholesky_f64_kernel<true><<<grid, 256, lds_m, stream()>>>(C->order.data(), 0, nonempty, C->indptr.data(), C->indices.data(),
-                                                                    C->data.data(), X->f32(), Y->f32(), YtY->f32(), (float)reg,
-                                                                    g_failed, st.data(), plan, partials);
-      IMP_CHECK_HIP(hipEventRecord(e1, stream()));
-      unsigned long long h[8];
-      IMP_CHECK_HIP(hipMemcpyAsync(h, st.data(), sizeof(h), hipMemcpyDeviceToHost, stream()));
-      sync();
-      float ms = 0.f;
-      IMP_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
-      IMP_CHECK_HIP(hipEventDestroy(e0));
-      IMP_CHECK_HIP(hipEventDestroy(e1));
-      const double n = h[7] ? (double)h[7] : 1.0;
-      const double ticks = (double)(h[1] + h[2] + h[3] + h[4]);
-      const double slots = (double)std::min(grid, ctx().num_cus * occ_stats) * 4.0;  // resident wavefronts
-      fprintf(stderr,
-              "[chol-stats] rows=%d cycles/row: SYRK %.0f  image+rows %.0f  factorise %.0f  back-subst %.0f | this launch %.2f ms, "
-              "workgroups per CU (occupancy query) %d (instrumented) / %d, ticks per resident wavefront / time = %.2f GHz\n",
-              nonempty, h[1] / n, h[2] / n, h[3] / n, h[4] / n, ms, occ_stats, occ, ticks / slots / (ms * 1e6));
-    } else {
+    {
       IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(als_cholesky_f64_kernel<false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
       IMP_PROF("als_cholesky_mfma_rows");
@@ -940,7 +789,7 @@ int64_t least_squares_cholesky(const imp_csr *C, imp_matrix *X, const imp_matrix
   if (use_nm) nm_list = least_squares_cholesky_nm(C, X->f32(), Y->f32(), Y->rows, YtY->f32(), (float)reg);
   // other f <= 64: rows up to 256 nnz go to the register-resident wave kernel; longer rows (and any larger f) to the
   // workgroup kernel, whose 256 threads share the A-build of one row
-  const int n_block = (f <= 64 && !no_wave) ? C->bin_start[2] : nonempty;
+  const int n_block = f <= 64 ? C->bin_start[2] : nonempty;
   const int n_wave = nonempty - n_block;
   if (n_wave > 0) {
     int grid = std::min((n_wave + 3) / 4, ctx().num_cus * 8);
@@ -956,34 +805,24 @@ int64_t least_squares_cholesky(const imp_csr *C, imp_matrix *X, const imp_matrix
     IMP_CHECK_HIP(hipGetLastError());
   }
   if (n_block > 0) {
-    // IMP_CHOL_UNBLOCKED=1: the round-1 column-by-column kernel (A/B, parity)
-    static const bool unblocked_env = getenv("IMP_CHOL_UNBLOCKED") != nullptr;  // (the switch alone is per process; use_nm is per call)
-    const bool unblocked = unblocked_env && !use_nm;
-    if (!unblocked) {
+    {
       const int m = f + 1, nbr = (m + 3) / 4, nbc = (f + 3) / 4;
       const size_t a_words = packed ? (size_t)m * (m + 1) / 2 : (size_t)m * lda;
       lds = (((a_words + 3) & ~(size_t)3) + (size_t)kCholTile * 4 * (nbc + nbr) + (size_t)m * kCholPanel + 4) * sizeof(float);
     }
     int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
-    int grid = std::min(n_block, ctx().num_cus * per_cu * (unblocked ? 1 : 4));  // smaller fixed shares of the length-sorted schedule
+    int grid = std::min(n_block, ctx().num_cus * per_cu * 4);  // smaller fixed shares of the length-sorted schedule
     IMP_PROF("als_cholesky_rows");
-    if (unblocked) {
-      auto kern = packed ? als_cholesky_kernel<true> : als_cholesky_kernel<false>;
-      IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    constexpr int ko = 0;  // (timing-only knock-outs of the phases: 1 A-build, 2 panel, 4 trailing update, 8 back substitution)
+    auto kern = packed ? als_cholesky_blocked_kernel<true> : als_cholesky_blocked_kernel<false>;
+    IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (use_nm)  // the listed rows only (the list stands in for the schedule; a zero count makes every workgroup return at once)
+      kern<<<std::min(nm_list.capacity, ctx().num_cus * per_cu), 256, lds, stream()>>>(
+          reinterpret_cast<const int32_t *>(nm_list.rows), 0, nm_list.capacity, C->indptr.data(), C->indices.data(), C->data.data(),
+          X->f32(), Y->f32(), YtY->f32(), f, (float)reg, lda, g_failed, ko, nm_list.count);
+    else
       kern<<<grid, 256, lds, stream()>>>(C->order.data(), 0, n_block, C->indptr.data(), C->indices.data(), C->data.data(), X->f32(),
-                                         Y->f32(), YtY->f32(), f, (float)reg, lda, g_failed);
-    } else {
-      static const int ko = getenv("IMP_CHOL_KO") ? atoi(getenv("IMP_CHOL_KO")) : 0;  // timing-only knock-outs of the phases
-      auto kern = packed ? als_cholesky_blocked_kernel<true> : als_cholesky_blocked_kernel<false>;
-      IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      if (use_nm)  // the listed rows only (the list stands in for the schedule; a zero count makes every workgroup return at once)
-        kern<<<std::min(nm_list.capacity, ctx().num_cus * per_cu), 256, lds, stream()>>>(
-            reinterpret_cast<const int32_t *>(nm_list.rows), 0, nm_list.capacity, C->indptr.data(), C->indices.data(), C->data.data(),
-            X->f32(), Y->f32(), YtY->f32(), f, (float)reg, lda, g_failed, ko, nm_list.count);
-      else
-        kern<<<grid, 256, lds, stream()>>>(C->order.data(), 0, n_block, C->indptr.data(), C->indices.data(), C->data.data(), X->f32(),
-                                           Y->f32(), YtY->f32(), f, (float)reg, lda, g_failed, ko, nullptr);
-    }
+                                         Y->f32(), YtY->f32(), f, (float)reg, lda, g_failed, ko, nullptr);
     IMP_CHECK_HIP(hipGetLastError());
   }
   zero_rows(C->order.data(), C->first_empty(), C->n_empty(), X->f32(), f);

@@ -89,11 +89,9 @@ void sync();  // hipStreamSynchronize on the library stream
 // end of a C-ABI call that only queues device work (solver sweeps, gramian, all-reduce): host wait unless the device is in
 // deferred mode (imp_set_deferred_sync), where the caller orders a whole iteration with ONE imp_device_synchronize
 void sync_call();
-bool team16_as_cluster();    // als_cg_cluster.hip: rows of (256,512] nnz on clusters of two workgroups instead of team16
-unsigned long long *fixup_total();  // als_cg_cluster.hip: host-mapped count of the rows the fix-up kernel re-solved on this device
-bool cluster_fault_pending();  // als_cg_cluster.hip: a cluster exchange timed out since the last check (clears the flag)
+unsigned long long *fixup_total();  // als_cg_fixup.hip: host-mapped count of the rows the fix-up kernel re-solved on this device
 bool w256_enabled();         // als_cg_w256.hip: resident lock-step kernels for the rows of <= 256 nonzeros at f = 256 (IMP_F256_OLD=1: round-2 kernel)
-bool nm_enabled();           // als_cg_nm.hip: long rows of the f = 64 / 128 path through their explicit normal matrix (IMP_NM=0: clusters + streamed)
+bool nm_enabled();           // als_cg_nm.hip: long rows of the f = 64 / 128 path through their explicit normal matrix (IMP_NM=0: streamed)
 
 // ---- launch-time profiler (HIP events on the library stream) ------------------------------------
 struct ProfScope {
@@ -156,13 +154,6 @@ struct Context {
   // iteration -- K solve chunks, their exchanges, two all-reduces -- and waits once)
   bool deferred = false;
   hipStream_t occupy_stream = nullptr;  // imp_debug_occupy
-  // Row-class streams (als_cg.hip launch_all, IMP_CLASS_STREAMS): the row classes of a half sweep solve disjoint rows, so their
-  // kernels may run side by side -- each persistent kernel's tail (workgroups finishing at different times) is then filled by
-  // the next class's workgroups instead of idling until the launch ends.  `cur` is what stream() hands out: the library stream
-  // except between ClassStreams::next() and ClassStreams::join().
-  hipStream_t side[3] = {nullptr, nullptr, nullptr};
-  hipEvent_t fork_event = nullptr, join_event[3] = {nullptr, nullptr, nullptr};
-  hipStream_t cur = nullptr;
   std::recursive_mutex mutex;
   std::mutex small_mutex;                  // the free lists below (a Storage may die on a thread that holds another device's lock)
   std::vector<void *> small_free[24];      // [log2 size]: recycled device blocks of 256 B .. 4 MB (Storage)
@@ -178,29 +169,12 @@ struct Context {
   DeviceArray<double> loss_buf;   // 4 accumulators of the loss kernel (solver.hip)
   DeviceArray<unsigned long long> chol_failed;  // smallest failing row of a Cholesky sweep (als_cholesky.hip)
   DeviceArray<float> barrier_word;              // operand of the RCCL barrier (comm.hip)
-  DeviceArray<unsigned long long> cluster_xchg;  // partial-vector exchange slots of the cluster kernels (als_cg_cluster.hip)
-  unsigned *cluster_fault = nullptr;             // host-mapped word: set by a cluster kernel whose exchange timed out
   unsigned long long *fixup_total = nullptr;     // host-mapped: rows re-solved by the fp32 fix-up kernel since the last imp_solver_fixup_rows(reset)
   DeviceArray<float> w256_ws;                    // fp16-split gramian in fragment order + header (als_cg_w256.hip)
   DeviceArray<unsigned> nm_fix_rows;             // rows the normal-matrix kernels left to the fix-up kernel (operands beyond the fp16 range)
   DeviceArray<int> nm_ticket;                    // work counter of the normal-matrix kernel (als_cg_nm.hip), reset by every launch
-  DeviceArray<unsigned> cluster_fault_rows;      // rows a faulted cluster left to the fix-up kernel; their count sits behind the exchange slots (als_cg_cluster.hip)
 };
-inline hipStream_t stream() {
-  auto &c = ctx();
-  return c.cur ? c.cur : c.stream;
-}
-void class_stream_next();  // next() of the ClassStreams object alive on this thread, if any
-bool prof_per_kernel();  // the profiler records every kernel scope (no name filter): launches stay on one stream, one after the other
-// Deals the launches of one half sweep to the library stream and three side streams, and joins them again (RAII).
-struct ClassStreams {
-  explicit ClassStreams(bool enable);
-  ~ClassStreams();
-  void next();  // the launches that follow go to the next stream of the rotation (class_stream_next() for code further down the call chain)
-  bool on = false;
-  int turn = 0;
-  bool used[3] = {false, false, false};
-};
+inline hipStream_t stream() { return ctx().stream; }
 // a C-ABI entry point is about to write `bytes` at `dst` through the library (or the memory is being freed): a padded copy of Y
 // made from memory it overlaps (least_squares_cg_padded) is no longer to be trusted -- on WHICHEVER device's context the copy
 // lives (device addresses are unique across the devices of a process; a Storage may die on a thread whose current device is
@@ -285,18 +259,13 @@ struct imp_csr {
   imp::DeviceArray<int32_t> order;
   int32_t bin_start[kBins + 1] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   int32_t max_row = 0;
-  // long-row plans: `plan_all` covers every row of class 0 (> kLongRow nonzeros) and is what the generic kernels stream;
-  // `plan_xl` covers only the rows beyond the reach of the cluster-resident kernels (> kClusterRow nonzeros; the first
-  // cluster_cut[0] entries of `order`), which is what the f = 64 / 128 path streams.  cluster_cut[i] = number of rows
-  // longer than kClusterRow >> i (i = 0, 1, 2), cluster_cut[3] = number of long rows: the cluster classes are
-  // order[cluster_cut[i] .. cluster_cut[i + 1]).
-  static constexpr int kClusterRow = 4096;
-  LongPlan plan_all, plan_xl;
-  // rows of more than kCholLongRow nonzeros (the first cluster_cut[2] entries of `order`) cut into plain runs of
-  // kCholSegment: the A-build of the f = 64 Cholesky kernel is segment-parallel for them (als_cholesky.hip)
+  // long-row plans: `plan_all` covers every row of class 0 (> kLongRow nonzeros) and is what the generic kernels (and the f = 64 /
+  // 128 path under IMP_NM=0) stream.  Rows of more than kCholLongRow nonzeros (the first n_chol_long entries of `order`) cut into
+  // plain runs of kCholSegment: the A-build of the f = 64 Cholesky kernel is segment-parallel for them (als_cholesky.hip)
+  LongPlan plan_all;
   static constexpr int kCholLongRow = 1024, kCholSegment = 1024;
   LongPlan plan_chol;
-  int32_t cluster_cut[4] = {0, 0, 0, 0};
+  int32_t n_chol_long = 0;
   // every row of class 0 cut into plain runs of `nm_segment` nonzeros (2048 .. 16384: about eight segments per CU and launch, so
   // that neither the tail of the launch nor the partial matrices of the cut rows weigh): the work list of the normal-matrix
   // kernels (als_cg_nm.hip).  The first nm_multi_rows rows (those longer than one segment) own the first nm_multi_segs segments.
@@ -330,7 +299,7 @@ struct CholNmList {
   int capacity;
 };
 CholNmList least_squares_cholesky_nm(const imp_csr *C, float *X, const float *Y, size_t y_rows, const float *YtY, float reg);
-// als_cg_cluster.hip: the fp32 one-wavefront-per-row solver for the rows listed in rows[0 .. *count) (F = 64 / 128, float / __half)
+// als_cg_fixup.hip: the fp32 one-wavefront-per-row solver for the rows listed in rows[0 .. *count) (F = 64 / 128, float / __half)
 template <int F, typename T>
 void launch_cg_fixup(const unsigned *count, const unsigned *rows, int capacity, const imp_csr *C, T *X, const T *Y, const float *A0,
                      int cg_steps);

@@ -98,52 +98,6 @@ static std::vector<ProfPending> g_prof_pending;
 static std::vector<hipEvent_t> g_event_pool;
 
 bool prof_enabled() { return g_prof_on; }
-bool prof_per_kernel() { return g_prof_on && g_prof_filter.empty(); }
-
-static thread_local ClassStreams *t_class_streams = nullptr;
-void class_stream_next() {
-  if (t_class_streams) t_class_streams->next();
-}
-ClassStreams::ClassStreams(bool enable) {
-  auto &c = ctx();
-  on = enable && !c.cur && !prof_per_kernel() && !t_class_streams;
-  if (!on) return;
-  t_class_streams = this;
-  if (!c.fork_event) {
-    IMP_CHECK_HIP(hipEventCreateWithFlags(&c.fork_event, hipEventDisableTiming));
-    for (int i = 0; i < 3; ++i) {
-      IMP_CHECK_HIP(hipStreamCreateWithFlags(&c.side[i], hipStreamNonBlocking));
-      IMP_CHECK_HIP(hipEventCreateWithFlags(&c.join_event[i], hipEventDisableTiming));
-    }
-  }
-  IMP_CHECK_HIP(hipEventRecord(c.fork_event, c.stream));  // everything queued so far (gramian, exchanges) is ordered before the classes
-}
-void ClassStreams::next() {
-  if (!on) return;
-  auto &c = ctx();
-  turn = (turn + 1) & 3;
-  if (turn == 0) {
-    c.cur = nullptr;
-    return;
-  }
-  const int i = turn - 1;
-  if (!used[i]) {
-    (void)hipStreamWaitEvent(c.side[i], c.fork_event, 0);
-    used[i] = true;
-  }
-  c.cur = c.side[i];
-}
-ClassStreams::~ClassStreams() {
-  if (!on) return;
-  t_class_streams = nullptr;
-  auto &c = ctx();
-  c.cur = nullptr;
-  for (int i = 0; i < 3; ++i)
-    if (used[i]) {
-      (void)hipEventRecord(c.join_event[i], c.side[i]);
-      (void)hipStreamWaitEvent(c.stream, c.join_event[i], 0);
-    }
-}
 
 static hipEvent_t get_event() {
   if (!g_event_pool.empty()) {
@@ -404,7 +358,6 @@ int imp_set_deferred_sync(int on) {
   return guarded([&] {
     if (!on) {
       sync();  // leaving the mode: everything queued so far is complete on return
-      (void)cluster_fault_pending();
     }
     ctx().deferred = on != 0;
   });
@@ -452,8 +405,6 @@ int imp_device_synchronize(void) {
   return guarded([&] {
     sync();
     IMP_CHECK_HIP(hipDeviceSynchronize());
-    (void)cluster_fault_pending();  // deferred mode: a lost cluster exchange since the last synchronisation is reported here (a warning:
-                                    // its rows were re-solved on the device)
   });
 }
 int imp_release_workspaces(void) {
@@ -468,8 +419,6 @@ int imp_release_workspaces(void) {
     c.pad_y = {};
     c.pad_y_src = nullptr;
     c.pad_gram = {};
-    c.cluster_xchg = {};
-    c.cluster_fault_rows = {};
     c.nm_fix_rows = {};
     c.w256_ws = {};
     std::lock_guard<std::mutex> g(c.small_mutex);
@@ -787,7 +736,7 @@ int imp_intvector_destroy(imp_intvector *v) {
 int imp_csr_create(int32_t rows, int32_t cols, int64_t nnz, const int32_t *indptr, const int32_t *indices,
                    const float *data, imp_csr **out) {
   return guarded([&] {
-    static const bool timing = getenv("IMP_CSR_TIMING") != nullptr;  // debug: where the construction time goes, on stderr
+    constexpr bool timing = false;  // (debug: where the construction time goes, on stderr)
     auto t_mark = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
       if (!timing) return;
@@ -867,7 +816,6 @@ int imp_csr_create(int32_t rows, int32_t cols, int64_t nnz, const int32_t *indpt
     int32_t stripe = std::min(12288, std::max(4096, (cols / 24 + 1023) / 1024 * 1024));
     if (const char *e = getenv("IMP_STRIPE")) stripe = std::max(0, atoi(e));
     double stripe_reuse = 4.0;  // minimum gathers per column of the gathered matrix for the striped plan
-    if (const char *e = getenv("IMP_STRIPE_REUSE")) stripe_reuse = atof(e);
     auto build_plan = [&](int32_t n_plan, LongPlan &lp, double stripe_reuse, int32_t segment) {
       int64_t long_nnz = 0;
       bool sorted = true;
@@ -962,18 +910,13 @@ int imp_csr_create(int32_t rows, int32_t cols, int64_t nnz, const int32_t *indpt
     };
     build_plan(n_long, m->plan_all, stripe_reuse, segment);
     lap("long-row plan (all)");
-    // rows within reach of the cluster-resident kernels (als_cg_cluster.hip) leave the streamed plan of the f = 64 / 128 path
-    for (int i = 0; i < 3; ++i) {
-      int32_t longer = 0;  // rows strictly longer than kClusterRow >> i (order is sorted by descending length)
-      for (int32_t len = max_len; len > (imp_csr::kClusterRow >> i); --len) longer += count[len];
-      m->cluster_cut[i] = longer;
+    // rows of more than kCholLongRow nonzeros: the first n_chol_long entries of `order` (sorted by descending length)
+    {
+      int32_t longer = 0;
+      for (int32_t len = max_len; len > imp_csr::kCholLongRow; --len) longer += count[len];
+      m->n_chol_long = longer;
     }
-    m->cluster_cut[3] = n_long;
-    // the few very long rows that remain streamed re-use the gathered matrix less often, yet their segments stay long
-    // enough for the striped plan to pay from 2 gathers per column on (C3 item side: partial kernel 0.36 -> 0.28 ms)
-    build_plan(m->cluster_cut[0], m->plan_xl, std::min(stripe_reuse, 2.0), segment);
-    static_assert(imp_csr::kCholLongRow == imp_csr::kClusterRow >> 2, "plan_chol covers order[0 .. cluster_cut[2])");
-    build_plan(m->cluster_cut[2], m->plan_chol, 1e30, imp_csr::kCholSegment);  // never striped
+    build_plan(m->n_chol_long, m->plan_chol, 1e30, imp_csr::kCholSegment);  // never striped
     {
       int64_t long_nnz = 0;
       for (int32_t li = 0; li < n_long; ++li) long_nnz += indptr[order[li] + 1] - indptr[order[li]];

@@ -265,120 +265,9 @@ __global__ __launch_bounds__(256) void gramian_partial_vec_kernel(const T *__res
   else gramian_wave_vec<VW, 3, T>(Y, n_rows, r_begin, r_end, out, lane);
 }
 
-// ---- f = 128, split-bf16 form (round 5) ---------------------------------------------------------------------------------------
-// The fp32 matrix instruction runs at the vector rate: the kernel above is matrix-pipe bound at 2.6 TB/s of operand traffic.  Here
-// every value is three bf16 terms (hi + mid + lo = the fp32 value to 2^-24, no range to guard: bf16 has fp32's exponent) and a tile
-// pair is six partial products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, smallest first -- the form of the top-k GEMM and
-// of the short-row CG kernel's gramian product (measured against float64 BELOW an fp32 FMA chain: 2.6e-8 vs 2e-7 relative).  A trip
-// is 16 rows: lane (i, kh) loads the four factors 4 i .. 4 i + 3 of rows r0 + 8 kh + j, j = 0 .. 7 (eight 1 KB wavefront loads, two
-// whole rows each) and its j-th element of "tile c" is factor 4 i + c of that row -- exactly the A and the B fragment of the
-// instruction, K index = row, with the same column permutation as the vector kernel above (undone by the reduce).  A wavefront is
-// its own row chunk; the two wavefronts of a chunk split the ten tile pairs five / five (30 MFMAs per trip each; the second one
-// needs three of the four tiles), so a value is split 1.75 times instead of 4 and the accumulators (80 registers) leave room for
-// two trips of loads.  Three-term products are not bitwise symmetric: the reduce takes the diagonal tiles' lower triangle from
-// the upper one.  Opt-in (IMP_GRAM_BF16X3=1): see gramian_t for what it did to the rest of the step.
-typedef __bf16 g_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 g_bf16x2 __attribute__((ext_vector_type(2)));
-typedef float g_f32x2 __attribute__((ext_vector_type(2)));
+// (The split-bf16 form of the f = 128 gramian -- three bf16 terms per operand on v_mfma_f32_32x32x16_bf16, round 5: the launch
+// 12-20 % shorter, every CG kernel behind it 4-8 % slower on some boxes -- was opt-in and is removed)
 
-template <int PART, typename T>
-__device__ __forceinline__ void gramian_wave_bf3(const T *__restrict__ Y, long n_rows, long r_begin, long r_end, float *__restrict__ out,
-                                                 int lane) {
-  constexpr int F = 128, VW = 4, NV = 5, P0 = 5 * PART;
-  constexpr int T0 = PART == 0 ? 0 : 1;  // first tile this wavefront needs
-  using Vec = typename FactorVec<T, VW>::type;
-  const int kh = lane >> 5;
-  f32x16 acc[NV];
-#pragma unroll
-  for (int t = 0; t < NV; ++t)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-  Vec v[2][8];
-  const unsigned lane_off = (unsigned)(VW * (lane & 31) * sizeof(T));
-  auto fetch = [&](int buf, long r0) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const long row = min(r0 + 8 * kh + j, n_rows - 1);  // clamped: rows past r_end are zeroed when consumed
-      v[buf][j] = *reinterpret_cast<const Vec *>(reinterpret_cast<const char *>(Y + row * (long)F) + lane_off);
-    }
-  };
-  auto multiply = [&](auto tail_tag, int buf, long r0) {
-    constexpr bool TAIL = decltype(tail_tag)::value;
-    g_bf16x8 h[VW], m[VW], l[VW];
-#pragma unroll
-    for (int jp = 0; jp < 4; ++jp) {  // rows in pairs: the conversions are packed
-      float o0[VW], o1[VW];
-      unpack<VW>(v[buf][2 * jp], o0);
-      unpack<VW>(v[buf][2 * jp + 1], o1);
-      if constexpr (TAIL) {
-        const int m0 = -(int)(r0 + 8 * kh + 2 * jp < r_end), m1 = -(int)(r0 + 8 * kh + 2 * jp + 1 < r_end);
-#pragma unroll
-        for (int c = 0; c < VW; ++c) o0[c] = __int_as_float(__float_as_int(o0[c]) & m0), o1[c] = __int_as_float(__float_as_int(o1[c]) & m1);
-      }
-#pragma unroll
-      for (int c = T0; c < VW; ++c) {
-        const g_f32x2 x = {o0[c], o1[c]};
-        const g_bf16x2 hi = __builtin_convertvector(x, g_bf16x2);
-        const g_f32x2 r1 = x - __builtin_convertvector(hi, g_f32x2);
-        const g_bf16x2 mid = __builtin_convertvector(r1, g_bf16x2);
-        const g_bf16x2 lo = __builtin_convertvector(r1 - __builtin_convertvector(mid, g_f32x2), g_bf16x2);
-        h[c][2 * jp] = hi[0], h[c][2 * jp + 1] = hi[1];
-        m[c][2 * jp] = mid[0], m[c][2 * jp + 1] = mid[1];
-        l[c][2 * jp] = lo[0], l[c][2 * jp + 1] = lo[1];
-      }
-    }
-    static_for<NV>([&](auto tc) {
-      constexpr int t = decltype(tc)::value, ci = tri_row(VW, P0 + t), cj = tri_col(VW, P0 + t);
-      f32x16 c = acc[t];
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l[ci], h[cj], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h[ci], l[cj], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m[ci], m[cj], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(m[ci], h[cj], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h[ci], m[cj], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h[ci], h[cj], c, 0, 0, 0);
-      acc[t] = c;
-    });
-  };
-  fetch(0, r_begin);
-  long r0 = r_begin;
-  for (; r0 + 32 <= r_end; r0 += 32) {
-    fetch(1, r0 + 16);
-    __builtin_amdgcn_sched_barrier(0);  // (keeps the loads from sinking to their uses)
-    multiply(std::false_type{}, 0, r0);
-    __builtin_amdgcn_sched_barrier(0);
-    fetch(0, r0 + 32);
-    __builtin_amdgcn_sched_barrier(0);
-    multiply(std::false_type{}, 1, r0 + 16);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (r0 < r_end) {  // at most 31 rows left; buffer 0 holds the trip at r0
-    fetch(1, r0 + 16);
-    multiply(std::true_type{}, 0, r0);
-    multiply(std::true_type{}, 1, r0 + 16);
-  }
-#pragma unroll
-  for (int t = 0; t < NV; ++t) {
-    float *tile = out + (size_t)(P0 + t) * 1024;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int rr = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-      tile[rr * 32 + (lane & 31)] = acc[t][e];
-    }
-  }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256, 2) void gramian_partial_bf3_kernel(const T *__restrict__ Y, long n_rows, long rows_per_chunk,
-                                                                     float *__restrict__ ws) {
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const long chunk = 2 * (long)blockIdx.x + (wave >> 1);
-  const long r_begin = min(n_rows, chunk * rows_per_chunk);
-  const long r_end = min(n_rows, r_begin + rows_per_chunk);
-  float *out = ws + (size_t)chunk * 10 * 1024;
-  if (wave & 1) gramian_wave_bf3<1, T>(Y, n_rows, r_begin, r_end, out, lane);
-  else gramian_wave_bf3<0, T>(Y, n_rows, r_begin, r_end, out, lane);
-}
 
 // out = sum over chunks (fixed order) + reg on the diagonal, mirrored.  Block = 64 elements of one tile pair x 16 chunk
 // groups: group g walks chunks g, g + 16, ... with 4 independent accumulators, the 16 group sums are then added in a fixed
@@ -423,31 +312,7 @@ __global__ __launch_bounds__(1024) void gramian_reduce_kernel(const float *__res
 
 // out (f x f) = Y^T Y + reg I over rows [0, n_rows) of Y
 template <typename T> static void gramian_t(const T *Y, long n_rows, int f, float reg, float *out) {
-  static const bool no_vec = getenv("IMP_GRAM_NO_VEC") != nullptr;  // A/B: the general kernel at f = 64 / 128 too
-  // IMP_GRAM_BF16X3=1: the split-bf16 form at f = 128.  Opt-in: the launch itself is 12 % shorter (63 against 70 us), but every CG
-  // kernel of the step then runs 7 - 8 % slower (4.06 -> 4.22 ms per step, alternating runs on one box) -- see DESIGN 4.3
-  static const bool bf3_form = getenv("IMP_GRAM_BF16X3") != nullptr;
-  const int vw = no_vec ? 1 : (f == 128 ? 4 : (f == 64 ? 2 : 1));
-  if (vw == 4 && bf3_form) {
-    // split-bf16 form: a chunk per wavefront PAIR, two pairs per workgroup, two workgroups per CU; whole 16-row trips
-    const long target_chunks = (long)ctx().num_cus * 4;
-    long rows_per_chunk = std::max<long>(64, (n_rows + target_chunks - 1) / target_chunks);
-    rows_per_chunk = (rows_per_chunk + 15) / 16 * 16;
-    const int chunks = n_rows <= 0 ? 0 : (int)((n_rows + rows_per_chunk - 1) / rows_per_chunk);
-    const int chunks_pad = (chunks + 1) / 2 * 2;  // (an odd count: the last pair of the last workgroup writes zeros)
-    const size_t need = (size_t)std::max(chunks_pad, 2) * 10 * 1024;
-    auto &wsbuf = ctx().gram_ws;
-    if (wsbuf.size < need) wsbuf.alloc(need);
-    if (chunks > 0) {
-      IMP_PROF("gramian_partial");
-      gramian_partial_bf3_kernel<T><<<chunks_pad / 2, 256, 0, stream()>>>(Y, n_rows, rows_per_chunk, wsbuf.data());
-      IMP_CHECK_HIP(hipGetLastError());
-    }
-    IMP_PROF("gramian_reduce");
-    gramian_reduce_kernel<<<10 * 16, 1024, 0, stream()>>>(wsbuf.data(), chunks_pad * (chunks > 0), f, reg, out, vw);
-    IMP_CHECK_HIP(hipGetLastError());
-    return;
-  }
+  const int vw = f == 128 ? 4 : (f == 64 ? 2 : 1);
   const int n_tiles = vw > 1 ? vw : (f + 31) / 32, n_pairs = n_tiles * (n_tiles + 1) / 2;
   const int tpw = std::min(kMaxPairsPerWave, (n_pairs + 3) / 4);
   const int gy = vw > 1 ? 1 : (n_pairs + 4 * tpw - 1) / (4 * tpw);

@@ -220,13 +220,10 @@ int imp_solver_least_squares(imp_solver *, const imp_csr *cui, imp_matrix *X, co
       });
       if (ctx().deferred) return;
       sync();
-      // a lost cluster exchange costs time, not correctness: its rows were re-solved on the device (als_cg_cluster.hip)
-      (void)cluster_fault_pending();
     };
     // fp16 factor storage: the f = 64 / 128 kernels load and store it directly (half the gather bytes, fp32 arithmetic, as
-    // als.cu:41,55,109); other factor counts go through an fp32 copy.  IMP_FP16_CONVERT=1 forces the copy (A/B, parity)
-    static const bool force_convert = getenv("IMP_FP16_CONVERT") != nullptr;
-    if (X->itemsize == 2 && cg_native_half((int)X->cols) && !force_convert) body(X, Y);
+    // als.cu:41,55,109); other factor counts go through an fp32 copy
+    if (X->itemsize == 2 && cg_native_half((int)X->cols)) body(X, Y);
     else run_with_f32(cui, X, Y, body);
   });
 }

@@ -1216,14 +1216,13 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
     // fast path: direct-operand MFMA GEMM (+ emit path, or tile maxima + single-pass pruned select)
     static const bool no_fast = getenv("IMP_TOPK_NO_FAST") != nullptr;
     // factor counts off the 16-grid ride the fast path on zero-padded fp32 copies (272 K -> 1.1 M recs/s at f = 100, configs[2]
-    // items; the copies cost ~0.1 ms per call at that size); IMP_TOPK_NO_PAD=1 keeps the general LDS-staged path
-    static const bool no_pad = getenv("IMP_TOPK_NO_PAD") != nullptr;
-    const bool padded = !no_fast && !no_pad && f_in % 16 != 0 && f_in >= 1 && k_eff <= kCandCap;
+    // items; the copies cost ~0.1 ms per call at that size)
+    const bool padded = !no_fast && f_in % 16 != 0 && f_in >= 1 && k_eff <= kCandCap;
     const int f = padded ? (f_in + 15) / 16 * 16 : f_in;
     const bool fast = !no_fast && (f % 8 == 0) && k_eff <= kCandCap;
     // fp16 factors (reference: SgemmEx on fp16 operands with fp32 accumulation, knn.cu:117-128): the direct-operand kernels
     // read them as stored and convert in registers; only the general path (any f, LDS-staged GEMM) scores an fp32 copy
-    const bool half_direct = items_in->itemsize == 2 && fast && !padded && getenv("IMP_FP16_CONVERT") == nullptr;
+    const bool half_direct = items_in->itemsize == 2 && fast && !padded;
     std::unique_ptr<imp_matrix> items_conv, query_conv;
     const imp_matrix *items = items_in, *query = query_in;
     imp_matrix items_pad, query_pad;  // views of the padded workspaces (no ownership)
@@ -1357,7 +1356,7 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
         qplanes = qp, qexp = qe;
     };
     static const bool resident_env = !(getenv("IMP_TOPK_RESIDENT") && atoi(getenv("IMP_TOPK_RESIDENT")) == 0);
-    static const bool bf16x3 = getenv("IMP_TOPK_BF16X3") != nullptr;
+    constexpr bool bf16x3 = false;
     // emit path (no score matrix): large item sets, k small against the candidate lists
     static const bool no_emit = getenv("IMP_TOPK_NO_EMIT") != nullptr;
     const bool emit_path = fast && !no_emit && emit_shape;
@@ -1380,12 +1379,12 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
       static_assert(kFlagSlots >= 2048, "one flag per row of an emit batch");
       const int *flags = host_flags;
       std::vector<int32_t> fb_list;
-      static const bool no_qsplit = getenv("IMP_TOPK_NO_QSPLIT") != nullptr;
+      constexpr bool no_qsplit = false;
       constexpr bool kCanSplit = BF3;
       const bool qsplit = kCanSplit && !no_qsplit;
       // fp16 two-term form with the queries resident in registers and the item planes cached (topk_resident.h): every factor count
       // that pads to 32 / 64 / 128 / 256; fp16-stored factors too (their values are their own high halves: scores stay bit-identical
-      // to scoring fp32 copies of them).  IMP_TOPK_BF16X3=1 / IMP_TOPK_RESIDENT=0: the six-product 128 x 128 kernel (A/B, parity)
+      // to scoring fp32 copies of them).  IMP_TOPK_RESIDENT=0: the six-product 128 x 128 kernel of rounds 3-4 (A/B, parity)
       const int KS = rq_ks_for(f);
       const bool resident = kCanSplit && resident_env && !bf16x3 && KS > 0;
       split_bf16 *qs = nullptr;

@@ -6,8 +6,11 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# IMP_LIB_PATH: an alternative build of the same library (A/B of compile-time variants, profiles/scripts/*.sh)
-LIB_PATH = os.environ.get("IMP_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "libimplicit_hip.so")
+# The product loads the in-tree library: no environment variable redirects it.  Measurement tooling that wants a compile-time
+# variant of the same library sets implicit_amd._libpath.OVERRIDE before importing this package (bench.py does, from IMP_LIB_PATH).
+from .. import _libpath  # noqa: E402
+
+LIB_PATH = _libpath.OVERRIDE or os.path.join(os.path.dirname(_HERE), "libimplicit_hip.so")
 
 c_void_pp = ctypes.POINTER(ctypes.c_void_p)
 c_i32_p = ctypes.POINTER(ctypes.c_int32)

@@ -231,7 +231,7 @@ def test_fp16_factor_storage(gpu, oracle, f):
 
 
 def test_old_long_row_kernels_still_agree():
-    """IMP_NM=0 (cluster + streamed kernels) and the default give the same rows within the parity bar."""
+    """IMP_NM=0 (one streamed pass per CG step) and the default give the same rows within the parity bar."""
     code = r"""
 import sys, numpy as np
 sys.path.insert(0, %r)

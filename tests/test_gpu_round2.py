@@ -163,7 +163,7 @@ for f in (64, 128, 50, 100):   # 50 / 100: zero-padded onto the f = 64 / 128 ker
         want = X0.copy()
         oracle.least_squares_cg(M, want, Y0, 0.05, cg_steps=3, YtY=gram.to_numpy())
         assert rel(Xd.to_numpy(), want) < 1e-4, ("cg", f, rel(Xd.to_numpy(), want))
-        if f in (64, 128):   # float16 storage: packed 64-entry tiles (IMP_HALF_TILE64=0: the fp32-tile kernels)
+        if f in (64, 128):   # float16 storage: packed 64-entry tiles 
             X16, Y16 = X0.astype(np.float16), Y0.astype(np.float16)
             Xh, Yh = gpu.Matrix(X16), gpu.Matrix(Y16)
             solver.calculate_yty(Yh, gram, 0.05)
@@ -193,7 +193,7 @@ solver.least_squares_cholesky(gpu.CSRMatrix(Cc), Xd, gram, Yd, 0.05)
 want = np.zeros((2000, 64), dtype=np.float32)
 oracle.least_squares(Cc, want, Y0, 0.05)
 assert rel(Xd.to_numpy(), want) < 1e-4, ("cholesky", rel(Xd.to_numpy(), want))
-Y1 = rng.random((500, 100), dtype=np.float32) * 0.2 - 0.1   # f = 100: the workgroup-per-row kernel (blocked / IMP_CHOL_UNBLOCKED=1)
+Y1 = rng.random((500, 100), dtype=np.float32) * 0.2 - 0.1   # f = 100: the workgroup-per-row kernel 
 Yd, gram, Xd = gpu.Matrix(Y1), gpu.Matrix.zeros(100, 100), gpu.Matrix.zeros(2000, 100)
 solver.calculate_yty(Yd, gram, 0.0)
 solver.least_squares_cholesky(gpu.CSRMatrix(Cc), Xd, gram, Yd, 0.05)
@@ -212,7 +212,7 @@ q = (rng.standard_normal((40, 64)) * 0.1).astype(np.float32)
 ids, d = gpu.KnnQuery().topk(gpu.Matrix(items), gpu.Matrix(q), 10)
 wi, wd = oracle.topk(items, q, 10)
 assert (ids == wi).mean() > 0.99
-items = (rng.standard_normal((12000, 64)) * 0.1).astype(np.float32)   # enough items for the emit path (fp16 / IMP_TOPK_BF16X3=1 forms)
+items = (rng.standard_normal((12000, 64)) * 0.1).astype(np.float32)   # enough items for the emit path (resident fp16 form / IMP_TOPK_RESIDENT=0: the six-product kernel)
 ids, d = gpu.KnnQuery().topk(gpu.Matrix(items), gpu.Matrix(q), 10)
 wi, wd = oracle.topk(items, q, 10)
 assert (ids == wi).mean() > 0.99 and np.allclose(d, wd, rtol=3e-5)
@@ -220,11 +220,9 @@ print("switch ok")
 """
 
 
-@pytest.mark.parametrize("switch", ["IMP_SHORT_TEAM1=1", "IMP_SHORT_TEAM1=0", "IMP_STRIPE=0", "IMP_SEGMENT=128",
-                                    "IMP_CHOL_NO_MFMA=1", "IMP_CHOL_NO_WAVE=1", "IMP_TOPK_NO_FAST=1", "IMP_NO_CLUSTER=1", "IMP_CLUSTER_SC1=1",
-                                    "IMP_GRAM_NO_VEC=1", "IMP_CHOL_NO_SPLIT=1", "IMP_TEAM16_CLUSTER=1", "IMP_F256_GENERIC=1",
-                                    "IMP_OVERSUB=3", "IMP_STRIPE_REUSE=1", "IMP_QGROUP_PER_CU=1", "IMP_TEAM_FUSED=0", "IMP_TEAM_FUSED=31", "IMP_SHORT_STAGGER=0", "IMP_SHORT_BF16X3=0",
-                                    "IMP_TOPK_FP32_MFMA=1", "IMP_NO_PAD=1", "IMP_TOPK_NO_PAD=1", "IMP_TOPK_NO_QSPLIT=1", "IMP_HALF_TILE64=0", "IMP_TILE64=15", "IMP_CHOL_UNBLOCKED=1", "IMP_NM=0", "IMP_NM_SEGMENT=128", "IMP_CHOL_PACKED=1000", "IMP_CLASS_STREAMS=1", "IMP_F256_OLD=1", "IMP_NM_SCALE=0", "IMP_CHOL_NM=0", "IMP_TOPK_BF16X3=1", "IMP_GRAM_BF16X3=1", "IMP_CHOL_PAD=0"])
+@pytest.mark.parametrize("switch", ["IMP_STRIPE=0", "IMP_SEGMENT=128", "IMP_TOPK_NO_FAST=1", "IMP_TOPK_NO_EMIT=1", "IMP_TOPK_RESIDENT=0",
+                                    "IMP_TOPK_FP32_MFMA=1", "IMP_OVERSUB=3", "IMP_NO_PAD=1", "IMP_NM=0", "IMP_NM_SEGMENT=128", "IMP_F256_OLD=1",
+                                    "IMP_CHOL_NM=0", "IMP_CHOL_PAD=0"])
 def test_ab_switch_paths_keep_parity(gpu, switch):
     """Every debug / A-B environment switch selects kernels the default run does not take (they are read once per
     process, hence the subprocess): CG both orientations at f = 64 / 128, Cholesky f = 64 and top-k against the oracle."""
@@ -361,7 +359,7 @@ def test_topk_emit_path_and_its_fallbacks(gpu, oracle):
 def test_native_fp16_factor_storage(gpu, oracle, f):
     """fp16 factor storage is read and written by the f = 64 / 128 kernels themselves (half2 / 8-byte loads converted in
     registers or inside the FMA, fp32 arithmetic and CG state, as implicit/gpu/als.cu:41,55,109): equal to solving an fp32
-    copy of the fp16 matrices and rounding the result (the IMP_FP16_CONVERT=1 path) -- bit for bit where both storages share
+    copy of the fp16 matrices and rounding the result -- bit for bit where both storages share
     a kernel, to the last fp16 place elsewhere -- and within 1e-3 of the oracle run on the fp16-rounded inputs (the result is
     stored in fp16)."""
     C = synthetic_csr(4000, 1500, 200_000, seed=2, neg_frac=0.05, empty_frac=0.01)   # item side has rows > 512 nnz
@@ -535,59 +533,5 @@ def test_cholesky_long_rows_are_segment_parallel(gpu, oracle):
     assert not got[lens == 0].any()
 
 
-_FAULT_SCRIPT = """
-import sys, warnings
-sys.path.insert(0, {root!r})
-warnings.simplefilter("ignore")
-import numpy as np, scipy.sparse as sp
-import implicit_amd.gpu as gpu
-from oracle import oracle
-oracle.build()
-rng = np.random.default_rng(11)
-lens = np.concatenate([rng.integers(513, 1025, 150), rng.integers(1025, 2049, 90), rng.integers(2049, 4097, 70), rng.integers(1, 400, 300)])
-rng.shuffle(lens)
-cols, f = 12_000, {f}
-indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
-indices = np.concatenate([np.sort(rng.choice(cols, int(n), replace=False)) for n in lens]).astype(np.int32)
-data = (1.0 + 4.0 * rng.random(len(indices), dtype=np.float32)).astype(np.float32)
-C = sp.csr_matrix((data, indices, indptr), shape=(len(lens), cols))
-X0 = rng.random((C.shape[0], f), dtype=np.float32) * 0.2 - 0.1
-Y0 = rng.random((cols, f), dtype=np.float32) * 0.2 - 0.1
-solver, Cd = gpu.LeastSquaresSolver(), gpu.CSRMatrix(C)
-Yd, gram = gpu.Matrix(Y0), gpu.Matrix.zeros(f, f)
-solver.calculate_yty(Yd, gram, 0.05)
-want = X0.copy()
-oracle.least_squares_cg(C, want, Y0, 0.05, cg_steps=3, YtY=gram.to_numpy())
-rel = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b))
-for deferred in (False, True):
-    Xd = gpu.Matrix(X0)
-    gpu.set_deferred_sync(deferred)
-    solver.least_squares(Cd, Xd, gram, Yd, 3)   # no exception: the lost exchange is repaired on the device
-    gpu.synchronize()
-    gpu.set_deferred_sync(False)
-    got = Xd.to_numpy()
-    per_row = np.linalg.norm(got - want, axis=1) / np.maximum(np.linalg.norm(want, axis=1), 1e-30)
-    print("deferred", deferred, "rel", rel(got, want), "worst row", per_row.max(), flush=True)
-    assert rel(got, want) < 1e-4 and per_row.max() < 1e-3
-print("FAULT-PATH-OK")
-"""
 
 
-@pytest.mark.parametrize("f", [64, 128])
-def test_a_lost_cluster_exchange_is_repaired_not_raised(gpu, f):
-    """IMP_DEBUG_CLUSTER_DROP=2: member 1 of cluster 0 of every cluster launch withholds its second exchange.  The members
-    waiting for it give up after IMP_CLUSTER_WAIT_MS, the fault spreads through poisoned granules, the cluster stores nothing
-    from then on and lists its rows; the fix-up kernel queued behind the clusters re-solves them -- in synchronous and in
-    deferred mode alike the sweep returns the oracle's factors, a warning on stderr is all that tells."""
-    import os
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    # IMP_NM=0: the cluster kernels are the long rows' alternative path since the normal-matrix kernels (als_cg_nm.hip), which
-    # have no exchange between workgroups to lose
-    env = dict(os.environ, IMP_DEBUG_CLUSTER_DROP="2", IMP_CLUSTER_WAIT_MS="30", IMP_NM="0")
-    p = subprocess.run([sys.executable, "-c", _FAULT_SCRIPT.format(root=root, f=f)], env=env, capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
-    assert "FAULT-PATH-OK" in p.stdout
-    assert "cluster exchange of the CG sweep timed out" in p.stderr
