@@ -69,12 +69,11 @@ def cg_algorithmic_bytes(lengths, f):
 
 
 SHORT_ROW, LONG_ROW = 32, 512  # imp_csr::kShortRow / kLongRow
-# schedule class -> the kernels that execute it (long rows: the normal-matrix kernels; with IMP_NM=0 up to 4096 nnz resident
-# across workgroup clusters and beyond that one partial + one combine launch per CG pass)
-CLASS_KERNELS = {"short": ["als_cg_short_rows", "als_cg_short16_rows"],
+# schedule class -> the kernels that execute it (long rows: the normal-matrix kernels; with IMP_NM=0 one partial + one combine launch
+# per CG pass)
+CLASS_KERNELS = {"short": ["als_cg_short_rows"],
                  "mid": ["als_cg_team2_rows", "als_cg_team4_rows", "als_cg_team8_rows", "als_cg_team16_rows"],
-                 "long": ["als_cg_cluster16_rows", "als_cg_cluster8_rows", "als_cg_cluster4_rows", "als_cg_cluster_reset",
-                          "als_cg_long_partial", "als_cg_long_combine", "als_cg_nm_rows", "als_cg_nm_finish", "als_cg_fixup"]}
+                 "long": ["als_cg_long_partial", "als_cg_long_combine", "als_cg_nm_rows", "als_cg_nm_finish", "als_cg_fixup"]}
 
 
 def class_bytes_per_iteration(Cui, Ciu, f):
@@ -90,13 +89,10 @@ def class_bytes_per_iteration(Cui, Ciu, f):
 
 
 # substring of the kernel function name -> (schedule class, dispatches per half sweep as a function of cg_steps)
-PMC_KERNELS = {"als_cg_group_kernel": ("short", lambda s: 1), "als_cg_team_kernel": ("mid", lambda s: 1),
-               "als_cg_qgroup_kernel": ("short", lambda s: 1), "als_cg_qteam_kernel": ("mid", lambda s: 1),
-               "als_cg_qfgroup_kernel": ("short", lambda s: 1), "als_cg_qfteam_kernel": ("mid", lambda s: 1),
+PMC_KERNELS = {"als_cg_qfgroup_kernel": ("short", lambda s: 1), "als_cg_qfteam_kernel": ("mid", lambda s: 1),
                "cg_long_partial": ("long", lambda s: 1 + s), "cg_long_combine_kernel": ("long", lambda s: 1 + s),
-               "als_cg_cluster_kernel": ("long", lambda s: 1), "als_cg_nm_kernel": ("long", lambda s: 1),
-               "als_cg_nm_finish_kernel": ("long", lambda s: 1), "als_cg_nm_reduce_kernel": ("long", lambda s: 1),
-               "als_cg_fault_fixup_kernel": ("long", lambda s: 1)}
+               "als_cg_nm_kernel": ("long", lambda s: 1), "als_cg_nm_finish_kernel": ("long", lambda s: 1),
+               "als_cg_nm_reduce_kernel": ("long", lambda s: 1), "als_cg_fault_fixup_kernel": ("long", lambda s: 1)}
 
 
 def pmc_traffic_per_half_sweep(cg_steps):
@@ -876,11 +872,16 @@ def extra_c5(gpu, SHAPES):
     sim_flops = 2.0 * batch * Y.shape[0] * f
     sim_roofline = None
     if gemm_ms > 0:
-        sim_peak = BF16_PEAK_TFLOPS / 6.0 if os.environ.get("IMP_TOPK_FP32_MFMA") is None else FP32_PEAK_TFLOPS
-        sim_roofline = {"bound": "mfma", "kernel": "score_gemm_direct_kernel", "achieved": sim_flops / (gemm_ms * 1e-3) / 1e12,
+        exact = os.environ.get("IMP_TOPK_FP32_MFMA") is not None
+        resident = os.environ.get("IMP_TOPK_RESIDENT", "1") != "0" and not exact
+        sim_peak = FP32_PEAK_TFLOPS if exact else BF16_PEAK_TFLOPS / (3.0 if resident else 6.0)
+        sim_roofline = {"bound": "mfma", "kernel": "score_resident_kernel<16, 1, 0>" if resident else "score_gemm_direct_kernel<0",
+                        "achieved": sim_flops / (gemm_ms * 1e-3) / 1e12,
                         "peak": sim_peak, "unit": "TFLOP/s", "frac": sim_flops / (gemm_ms * 1e-3) / 1e12 / sim_peak,
                         "avg_launch_ms": gemm_ms, "flops_per_launch": sim_flops, "traffic": None,
-                        "note": "fp32-equivalent flops; peak = dense bf16 MFMA / 6 partial products of the split-bf16 form"}
+                        "note": "fp32-equivalent flops; peak = dense fp16 MFMA / 3 partial products of the two-term form (a 1000 x 26 744 x 256 "
+                                "product is 16 us of matrix time: the launch is latency, the two select kernels beside it weigh more)"
+                                if resident else "fp32-equivalent flops; peak = dense bf16 MFMA / 6 partial products"}
     return {"cg_c5": {"workload": "BASELINE configs[4]: 138,493 x 26,744, %d nnz, f=256 fp32, CG cg_steps=%d" % (C.nnz, CG_STEPS),
                       "ms_per_iter": 1e3 * t_cg, "updates_per_s": rows / t_cg,
                       "roofline": {"bound": "hbm", "achieved": gb / t_cg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -1030,22 +1031,21 @@ def bench_topk(gpu, Cui, X, Y, k=10, queries=20_000, batch=1000):
     roofline = None
     if gemm_ms > 0:
         tf = per_batch_flops / (gemm_ms * 1e-3) / 1e12
-        split = os.environ.get("IMP_TOPK_FP32_MFMA") is None and Y.shape[1] % 16 == 0
-        six = os.environ.get("IMP_TOPK_BF16X3") is not None   # the round-3 form: three bf16 terms, six products
-        peak = (BF16_PEAK_TFLOPS / (6.0 if six else 3.0)) if split else FP32_PEAK_TFLOPS
-        roofline = {"bound": "mfma", "kernel": "score_gemm_direct_kernel<2> (emit epilogue)", "achieved": tf, "peak": peak,
+        exact = os.environ.get("IMP_TOPK_FP32_MFMA") is not None
+        resident = os.environ.get("IMP_TOPK_RESIDENT", "1") != "0" and not exact and Y.shape[1] <= 256
+        products = 3.0 if resident else 6.0
+        peak = FP32_PEAK_TFLOPS if exact else BF16_PEAK_TFLOPS / products
+        kernel = "score_resident_kernel<8, 2, 2>" if resident else "score_gemm_direct_kernel<2"
+        roofline = {"bound": "mfma", "kernel": kernel + " (emit pass)", "achieved": tf, "peak": peak,
                     "unit": "TFLOP/s", "frac": tf / peak, "avg_launch_ms": gemm_ms,
-                    "flops_per_launch": per_batch_flops, "traffic": _pmc_kernel_traffic("score_gemm_direct_kernel<2"),
+                    "flops_per_launch": per_batch_flops, "traffic": _pmc_kernel_traffic(kernel),
                     "traffic_note": "HBM bytes per launch of the emit GEMM from the committed rocprofv3 PMC summary "
                                     "(FETCH_SIZE corrected for gfx950); algorithmic operand bytes = items x f x 4 once per launch",
-                    "note": (("fp32-equivalent flops (2 x batch x items x f per launch); the product runs as 6 bf16 partial products "
-                              "of three-way split operands on v_mfma_f32_32x32x16_bf16 (fp32 accumulation, error below an fp32 FMA "
-                              "chain's): peak = 2500 TFLOP/s dense bf16 / 6") if six else
-                             ("fp32-equivalent flops (2 x batch x items x f per launch); the product runs as 3 fp16 partial products "
-                              "(l h, h l, h h) of two-way split operands, scaled per call by a power of two, on "
-                              "v_mfma_f32_32x32x16_f16 with fp32 accumulation (operands to 2^-22; overflowing rows re-scored by the "
-                              "six-product bf16 form): peak = 2500 TFLOP/s dense fp16 / 3")) if split else
-                            "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32); 2 x batch x items x f flops per launch"}
+                    "note": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32); 2 x batch x items x f flops per launch" if exact else
+                            ("fp32-equivalent flops (2 x batch x items x f per launch); the product runs as %d partial products of %s on "
+                             "the fp16 / bf16 matrix cores with fp32 accumulation: peak = 2500 TFLOP/s dense / %d" %
+                             (int(products), "two-term fp16 operands (l h, h l, h h; per-row query scales, exact item maximum)" if resident
+                              else "three-term bf16 operands", int(products)))}
     # the model-level call a user makes (recommend(): host COO build of the liked items + upload + KnnQuery.topk per batch)
     rec = None
     try:

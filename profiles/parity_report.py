@@ -154,7 +154,50 @@ def fmt(v):
     return "—" if v is None else f"{v:.1e}"
 
 
+TOPK_FORMS = (("fp16 x 2, three products (default, topk_resident.h)", {}),
+              ("bf16 x 3, six products (IMP_TOPK_RESIDENT=0)", {"IMP_TOPK_RESIDENT": "0"}),
+              ("exact fp32 MFMA (IMP_TOPK_FP32_MFMA=1)", {"IMP_TOPK_FP32_MFMA": "1", "IMP_TOPK_RESIDENT": "0"}))
+
+
+def topk_forms(out_dir, cases):
+    """The same top-k workloads under each form of the scoring GEMM: the form is chosen once per process, so every form runs in
+    a child process (`--topk-only`) on factors saved by the parent; returns {form label: [records]}."""
+    import subprocess
+
+    path = os.path.join(out_dir, "topk_cases.npz")
+    np.savez(path, **{f"{i}_{k}": v for i, c in enumerate(cases) for k, v in c.items() if isinstance(v, np.ndarray)},
+             meta=json.dumps([{k: v for k, v in c.items() if not isinstance(v, np.ndarray)} for c in cases]))
+    out = {}
+    for label, env in TOPK_FORMS:
+        res = os.path.join(out_dir, "topk_form.json")
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--topk-only", path, res], env={**os.environ, **env},
+                           capture_output=True, text=True, timeout=1800)
+        if p.returncode != 0:
+            out[label] = {"error": p.stderr[-500:]}
+            continue
+        out[label] = json.load(open(res))
+    os.remove(path)
+    return out
+
+
+def topk_only(case_path, res_path):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        import implicit_amd.gpu as gpu
+    from oracle import oracle
+
+    oracle.build()
+    z = np.load(case_path, allow_pickle=False)
+    meta = json.loads(str(z["meta"]))
+    recs = []
+    for i, m in enumerate(meta):
+        recs.append(topk_record(gpu, oracle, m["name"], z[f"{i}_items"], z[f"{i}_queries"], m["k"], norms=m["norms"]))
+    json.dump(recs, open(res_path, "w"))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--topk-only":
+        return topk_only(sys.argv[2], sys.argv[3])
     out_dir = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "parity")
     os.makedirs(out_dir, exist_ok=True)
     with warnings.catch_warnings():
@@ -199,7 +242,7 @@ def main():
     cg.append(r)
     # top-k k = 10 over the trained item factors, 2000 user queries
     q = np.arange(0, X2.shape[0], X2.shape[0] // 2000)[:2000]
-    topk.append(topk_record(gpu, oracle, "configs[2] recommend k=10 (trained factors)", Y2, np.ascontiguousarray(X2[q]), 10))
+    topk_cases = [{"name": "configs[2] recommend k=10 (trained factors)", "items": Y2, "queries": np.ascontiguousarray(X2[q]), "k": 10, "norms": False}]
     del C, Ct
 
     # ---- configs[1]: 1M x 100K, f = 64 -- Cholesky (user side) and CG both sides -------------------------------------------
@@ -228,8 +271,71 @@ def main():
     r, Y1 = cg_side(gpu, oracle, "configs[4]", "item rows", C.T.tocsr(), Y0, X1, reg, n_uniform=1000)
     cg.append(r)
     qi = np.arange(0, Y1.shape[0], Y1.shape[0] // 500)[:500]
-    topk.append(topk_record(gpu, oracle, "configs[4] similar_items k=100", Y1, np.ascontiguousarray(Y1[qi]), 100, norms=True))
+    topk_cases.append({"name": "configs[4] similar_items k=100", "items": Y1, "queries": np.ascontiguousarray(Y1[qi]), "k": 100, "norms": True})
     del C
+
+    # ---- configs[0]: MovieLens-100K shape, f = 16 (the reference's own CPU-runnable case): every row, CG and Cholesky, and the
+    # compiled reference timed on ONE thread ------------------------------------------------------------------------------------
+    C = named("ml100k")
+    Ct = C.T.tocsr()
+    f = 16
+    rng = np.random.default_rng(5)
+    X0 = rng.random((C.shape[0], f), dtype=np.float32) * 0.2 - 0.1
+    Y0 = rng.random((C.shape[1], f), dtype=np.float32) * 0.2 - 0.1
+    r, X1 = cg_side(gpu, oracle, "configs[0]", "user rows", C, X0, Y0, reg, n_uniform=C.shape[0], n_longest=1, n_fp64=C.shape[0])
+    cg.append(r)
+    r, _ = cg_side(gpu, oracle, "configs[0]", "item rows", Ct, Y0, X1, reg, n_uniform=Ct.shape[0], n_longest=1, n_fp64=Ct.shape[0])
+    cg.append(r)
+    cg.append(cholesky_side(gpu, oracle, "configs[0]", "user rows", C, Y0, reg, n_uniform=C.shape[0], n_longest=1))
+    config0 = None
+    als_ref, _ = ref.load()
+    if als_ref is not None:
+        from threadpoolctl import threadpool_limits
+
+        with threadpool_limits(1, "blas"):
+            Xh, Yh = X0.copy(), Y0.copy()
+            t0, reps = time.perf_counter(), 0
+            while reps < 5 or time.perf_counter() - t0 < 1.0:
+                als_ref.least_squares_cg(C, Xh, Yh, reg, num_threads=1, cg_steps=3)
+                als_ref.least_squares_cg(Ct, Yh, Xh, reg, num_threads=1, cg_steps=3)
+                reps += 1
+            t_cg = (time.perf_counter() - t0) / reps
+            t0, reps = time.perf_counter(), 0
+            while reps < 5 or time.perf_counter() - t0 < 1.0:
+                als_ref.least_squares(C, Xh, Yh, reg, num_threads=1)
+                als_ref.least_squares(Ct, Yh, Xh, reg, num_threads=1)
+                reps += 1
+            t_ch = (time.perf_counter() - t0) / reps
+        config0 = {"users": int(C.shape[0]), "items": int(C.shape[1]), "nnz": int(C.nnz), "factors": f,
+                   "reference_1thread_ms_per_iteration": {"cg_3": 1e3 * t_cg, "cholesky": 1e3 * t_ch},
+                   "reference_1thread_updates_per_s": {"cg_3": (C.shape[0] + C.shape[1]) / t_cg, "cholesky": (C.shape[0] + C.shape[1]) / t_ch}}
+    del C, Ct
+
+    # ---- configs[3] from a TRAINED state: three ALS iterations over the whole matrix on this one GPU, then rank 0's rows -------
+    trained3 = os.environ.get("IMP_PARITY_SKIP_C4_TRAINED") is None
+    if trained3:
+        users, items, nnz, gamma = SHAPES["c4"]
+        Cui_all, Ciu_all, _, _ = grid_shards(0, 1, users, items, nnz, 8, gamma=gamma, seed=42)
+        f = 128
+        Xd = gpu.RandomState(7).uniform(users, f, 0.0, 0.01)
+        Yd = gpu.RandomState(8).uniform(items, f, 0.0, 0.01)
+        solver, gram = gpu.LeastSquaresSolver(), gpu.Matrix.zeros(f, f)
+        Cd, Ctd = gpu.CSRMatrix(Cui_all), gpu.CSRMatrix(Ciu_all)
+        for _ in range(3):
+            solver.calculate_yty(Yd, gram, reg)
+            solver.least_squares(Cd, Xd, gram, Yd, 3)
+            solver.calculate_yty(Xd, gram, reg)
+            solver.least_squares(Ctd, Yd, gram, Xd, 3)
+        del Cd, Ctd
+        Xh, Yh = Xd.to_numpy(), Yd.to_numpy()
+        nu, ni = users // 8, items // 8
+        r, _ = cg_side(gpu, oracle, "configs[3] (rank 0 of 8, after 3 iterations)", "user rows", Cui_all[:nu], np.ascontiguousarray(Xh[:nu]), Yh, reg,
+                       n_uniform=500, n_longest=16, n_fp64=200, Yd=Yd)
+        cg.append(r)
+        r, _ = cg_side(gpu, oracle, "configs[3] (rank 0 of 8, after 3 iterations)", "item rows", Ciu_all[:ni], np.ascontiguousarray(Yh[:ni]), Xh, reg,
+                       n_uniform=500, n_longest=16, n_fp64=200, Yd=Xd)
+        cg.append(r)
+        del Cui_all, Ciu_all, Xd, Yd, Xh, Yh
 
     # ---- configs[3]: rank 0's eighth of 10M x 1M x 500M ---------------------------------------------------------------------
     users, items, nnz, gamma = SHAPES["c4"]
@@ -245,7 +351,10 @@ def main():
                    n_longest=16, n_fp64=200, Yd=X)
     cg.append(r)
 
-    result = {"solver_rows": cg, "topk": topk, "compiled_reference_present": have_ref, "seconds": time.time() - t_start}
+    forms = topk_forms(out_dir, topk_cases)
+    topk = forms.get(TOPK_FORMS[0][0]) if isinstance(forms.get(TOPK_FORMS[0][0]), list) else []
+    result = {"solver_rows": cg, "topk": topk, "topk_by_gemm_form": forms, "configs0": config0, "compiled_reference_present": have_ref,
+              "seconds": time.time() - t_start}
     json.dump(result, open(os.path.join(out_dir, "parity.json"), "w"), indent=1)
     lines = ["# PARITY — measured distances of the HIP path (generated by `profiles/parity_report.py` on an MI355X box)", "",
              "Relative Frobenius distance over the sampled rows of ONE half sweep from identical inputs (uniform row sample + the longest "
@@ -276,6 +385,26 @@ def main():
                 continue
             lines.append(f"| {r['config']} | {r['items']:,} | {r['queries']:,} | {r['k']} | {label} | {v['id_positions_differing']} of {v['of']} "
                          f"({100 * v['fraction']:.3f} %) | {v['rows_with_a_difference']} | {v['near_ties_fp64']} | {v['real_disagreements']} |")
+    lines += ["", "### By form of the scoring GEMM (same factors, same queries; differences against the COMPILED REFERENCE)", "",
+              "| workload | GEMM form | positions differing | near-ties (fp64) | real disagreements | max score rel. diff vs oracle |",
+              "|---|---|---|---|---|---|"]
+    for label, recs in forms.items():
+        if not isinstance(recs, list):
+            lines.append(f"| — | {label} | failed: {recs.get('error', '')[:80]} | | | |")
+            continue
+        for r in recs:
+            v = r.get("vs_reference") or r.get("vs_oracle")
+            lines.append(f"| {r['config']} | {label} | {v['id_positions_differing']} of {v['of']} | {v['near_ties_fp64']} | "
+                         f"{v['real_disagreements']} | {r['score_rel_max']:.1e} |")
+    if config0:
+        c0 = config0
+        lines += ["", "## configs[0] (MovieLens-100K shape, f = 16): the reference on ONE CPU thread", "",
+                  f"{c0['users']} x {c0['items']}, {c0['nnz']:,} nnz.  Compiled reference, `num_threads=1`, BLAS threads = 1: CG (3 steps) "
+                  f"{c0['reference_1thread_ms_per_iteration']['cg_3']:.2f} ms per iteration = "
+                  f"{c0['reference_1thread_updates_per_s']['cg_3']:,.0f} updates/s; Cholesky "
+                  f"{c0['reference_1thread_ms_per_iteration']['cholesky']:.2f} ms = {c0['reference_1thread_updates_per_s']['cholesky']:,.0f} "
+                  "updates/s.  GPU parity for every row of both sides is in the table above (rows `configs[0]`); its GPU timing is "
+                  "`bench.py`'s `c1_cg` / `c1_cholesky` (launch-latency bound: a 1 ms problem)."]
     lines += ["", f"Generated in {result['seconds']:.0f} s; compiled reference present: {have_ref}."]
     open(os.path.join(out_dir, "PARITY.md"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
