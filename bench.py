@@ -474,6 +474,7 @@ def compact_line(full, args):
         # recs/s is quoted through model.recommend(userids, user_items[userids], N=k) with the liked-items filter
         line["topk_recs_per_s"] = _r(topk.get("value"))
         line["knn_topk_recs_per_s"] = _r(topk.get("knn_topk_recs_per_s"))
+        line["recommend_presliced_recs_per_s"] = _r(topk.get("model_recommend_presliced_recs_per_s"))
     c = full["config"]
     line["config"] = {"workload": c["workload"], "users": c["users"], "items": c["items"], "nnz": c["nnz"], "factors": c["factors"],
                       "solver": c["solver"], "cg_steps": c["cg_steps"], "topk": "recommend() k=10, 20000 users in batches of 1000, liked-items filter on"
@@ -1024,6 +1025,13 @@ def bench_topk(gpu, Cui, X, Y, k=10, queries=20_000, batch=1000):
     gpu.synchronize()
     gpu.Profiler.enable(False)
     kernels = {name: gpu.Profiler.get(name)[0] / len(views) for name in gpu.Profiler.names()}
+    # the shader clock behind a run of scoring launches (a one-wavefront probe queued right behind them): the matrix-core peak is
+    # quoted at 2.4 GHz, a power-limited box runs an MFMA-heavy kernel below that
+    topk_clock = []
+    for _ in range(2):
+        for v, fl in zip(views[:8], filt[:8]):
+            knn.topk(Y, v, k, query_filter=fl)
+        topk_clock.append(round(gpu.core_clock_mhz(50), 1))
     flops = 2.0 * queries * Y.shape[0] * Y.shape[1]
     # the dominant kernel: the full scoring GEMM (emit epilogue), HIP events of the profiled pass
     gemm_ms = kernels.get("score_gemm", 0.0)
@@ -1047,7 +1055,7 @@ def bench_topk(gpu, Cui, X, Y, k=10, queries=20_000, batch=1000):
                              (int(products), "two-term fp16 operands (l h, h l, h h; per-row query scales, exact item maximum)" if resident
                               else "three-term bf16 operands", int(products)))}
     # the model-level call a user makes (recommend(): host COO build of the liked items + upload + KnnQuery.topk per batch)
-    rec = None
+    rec, rec_presliced = None, None
     try:
         from implicit_amd.als import AlternatingLeastSquares
 
@@ -1061,6 +1069,15 @@ def bench_topk(gpu, Cui, X, Y, k=10, queries=20_000, batch=1000):
             model.recommend(ids[s0:s0 + batch], Cui[s0:s0 + batch], N=k)
         gpu.synchronize()
         rec = queries / (time.perf_counter() - t0)
+        # the same calls with the caller's row slices prepared beforehand: user_items[a:b] is scipy's row slice in the CALLER
+        # (0.13 ms per 1000-row batch of this matrix: four fifths of everything recommend() costs on the host)
+        slices = [Cui[s0:s0 + batch] for s0 in range(0, queries, batch)]
+        gpu.synchronize()
+        t0 = time.perf_counter()
+        for j, s0 in enumerate(range(0, queries, batch)):
+            model.recommend(ids[s0:s0 + batch], slices[j], N=k)
+        gpu.synchronize()
+        rec_presliced = queries / (time.perf_counter() - t0)
     except Exception as e:  # noqa: BLE001
         rec = f"{type(e).__name__}: {e}"
     # recs/s is quoted through the model-level call; the raw KnnQuery.topk rate (filters already resident) is kept beside it
@@ -1069,6 +1086,7 @@ def bench_topk(gpu, Cui, X, Y, k=10, queries=20_000, batch=1000):
             "via": "AlternatingLeastSquares.recommend(userids, user_items[userids], N=10), filter_already_liked_items=True"
                    if isinstance(rec, float) else "KnnQuery.topk (model.recommend failed: %s)" % rec,
             "knn_topk_recs_per_s": queries / t, "model_recommend_recs_per_s": rec,
+            "model_recommend_presliced_recs_per_s": rec_presliced, "core_clock_mhz_behind_scoring": topk_clock,
             "kernels_ms_per_batch": kernels, "scoring_TFLOPs": flops / t / 1e12, "roofline": roofline,
             "batch": batch, "items": Y.shape[0], "filter_already_liked_items": True,
             "ids": "identical to the compiled reference's topk outside fp32 near-ties (PARITY.md)",

@@ -21,6 +21,12 @@
 #define IMPLICIT_AMD_CSRC_TOPK_RESIDENT_H_
 
 typedef _Float16 rq_f16x8 __attribute__((ext_vector_type(8)));
+template <int N, int I = 0, typename Fn> __device__ __forceinline__ void rq_static_for(Fn &&fn) {
+  if constexpr (I < N) {
+    fn(std::integral_constant<int, I>{});
+    rq_static_for<N, I + 1>(fn);
+  }
+}
 #ifndef RQ_KO
 #define RQ_KO 0  // timing-only knock-outs (build variants, wrong results): 1 no MFMAs, 2 no item DMA in the loop, 4 no epilogue, 8 no barrier, 16 tests but no survivor work
 #endif
@@ -271,20 +277,14 @@ __global__ __launch_bounds__(256, 2) void score_resident_kernel(ResidentArgs a) 
   for (int s = 0; s < NSTAGE - 1; ++s) dma(s);
 
   if constexpr (MODE == 2) {
-    // ---- emit pass.  The row thresholds (scaled domain, tau_s) stay resident as 16 x TQ registers `negts` = -tau in the
-    // accumulator layout: d = acc + negts is one packed add per pair, "does anything in this lane pass" five v_max3 and one compare
-    // per query tile, and the per-element work (which element, the exact test on the ordered key, the LDS staging) is left to the
+    // ---- emit pass.  d = acc - tau_s (the row thresholds in the scaled domain, four rows per LDS read), "does anything in this lane
+    // pass" five v_max3 and one compare per query tile, and the per-element work (which element, the exact test on the ordered key, the LDS staging) is left to the
     // lanes that have a survivor.  A compare per accumulator element against thresholds read from LDS cost ~1.4 K vector cycles per
     // step beside 1.5 K matrix cycles, and the two did not overlap (profiles/r06_topk_resident_knockouts.txt).  (Starting the
     // accumulators AT -tau -- the first MFMA's C operand -- would save the adds, but a survivor's score would then be rebuilt as
     // d + tau, an ulp or two off the threshold pass's value of the same dot product: a row whose k best all sit in the sampled
     // subset then finds k - 1 candidates -- measured: 6-13 rows per 1000 sent to the exact path.)  With item norms (cosine
     // scores) the finished score is what has to be compared: that form converts first and tests second.
-    f32x16 negts[TQ];
-#pragma unroll
-    for (int tq = 0; tq < TQ; ++tq)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) negts[tq][e] = -tau_s[wave * 32 * TQ + 32 * tq + 4 * kh + (e & 3) + 8 * (e >> 2)];
     for (int s = 0; s < steps; ++s) {
       if (!(RQ_KO & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * PER_WAVE) : "memory");
       if (!(RQ_KO & 8)) __builtin_amdgcn_s_barrier();
@@ -295,21 +295,34 @@ __global__ __launch_bounds__(256, 2) void score_resident_kernel(ResidentArgs a) 
       for (int tq = 0; tq < TQ; ++tq)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[tq][e] = 0.f;
+      // item fragments TWO k-steps ahead of the MFMAs that use them (three register sets): with the reads of k-step ks + 1 issued
+      // only after the MFMAs of ks, an LDS round trip under load (eight wavefronts reading, the DMA writing) outlasted the 192
+      // cycles those MFMAs cover, and the matrix pipe idled a third of the loop (SQ_VALU_MFMA_BUSY: 0.50 of the launch)
+      rq_f16x8 bh[3], bl[3];
+      auto ldb = [&](int ks, int set) {
+        bh[set] = *reinterpret_cast<const rq_f16x8 *>(slot + (ks * 2) * 1024 + lane * 16);
+        bl[set] = *reinterpret_cast<const rq_f16x8 *>(slot + (ks * 2 + 1) * 1024 + lane * 16);
+      };
+      ldb(0, 0);
+      if constexpr (KS > 1) ldb(1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      rq_static_for<KS>([&](auto Kc) {
+        constexpr int ks = decltype(Kc)::value;
+        if constexpr (ks + 2 < KS) ldb(ks + 2, (ks + 2) % 3);
+        __builtin_amdgcn_sched_barrier(0);  // (left alone, the scheduler sinks every read to just before its first use)
+        if (RQ_KO & 1) {
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const rq_f16x8 bh = *reinterpret_cast<const rq_f16x8 *>(slot + (ks * 2) * 1024 + lane * 16);
-        const rq_f16x8 bl = *reinterpret_cast<const rq_f16x8 *>(slot + (ks * 2 + 1) * 1024 + lane * 16);
+          for (int tq = 0; tq < TQ; ++tq) asm volatile("" ::"v"(bh[ks % 3]), "v"(bl[ks % 3]), "v"(ah[tq][ks]), "v"(al[tq][ks]));
+        } else {  // the query tiles' chains in turn: a dependent MFMA directly behind its predecessor waits for the result
 #pragma unroll
-        for (int tq = 0; tq < TQ; ++tq) {
-          if (RQ_KO & 1) {
-            asm volatile("" ::"v"(bh), "v"(bl), "v"(ah[tq][ks]), "v"(al[tq][ks]));
-          } else {
-            acc[tq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tq][ks], bh, acc[tq], 0, 0, 0);
-            acc[tq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tq][ks], bl, acc[tq], 0, 0, 0);
-            acc[tq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tq][ks], bh, acc[tq], 0, 0, 0);
-          }
+          for (int tq = 0; tq < TQ; ++tq) acc[tq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tq][ks], bh[ks % 3], acc[tq], 0, 0, 0);
+#pragma unroll
+          for (int tq = 0; tq < TQ; ++tq) acc[tq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tq][ks], bl[ks % 3], acc[tq], 0, 0, 0);
+#pragma unroll
+          for (int tq = 0; tq < TQ; ++tq) acc[tq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tq][ks], bh[ks % 3], acc[tq], 0, 0, 0);
         }
-      }
+        __builtin_amdgcn_sched_barrier(0);
+      });
       if (RQ_KO & 4) {
         float sink = 0.f;
 #pragma unroll
@@ -335,7 +348,12 @@ __global__ __launch_bounds__(256, 2) void score_resident_kernel(ResidentArgs a) 
         }
         // d = score - threshold: its sign is exact.  A NaN (a non-finite operand) is dropped by the maxima while a number stands
         // beside it: its row then collects fewer than k candidates and goes to the exact path, as it should
-        const f32x16 d = c + negts[tq];
+        f32x16 d;
+#pragma unroll
+        for (int eg = 0; eg < 4; ++eg) {
+          const float4 ts = *reinterpret_cast<const float4 *>(tau_s + r_base + 8 * eg);
+          d[4 * eg] = c[4 * eg] - ts.x, d[4 * eg + 1] = c[4 * eg + 1] - ts.y, d[4 * eg + 2] = c[4 * eg + 2] - ts.z, d[4 * eg + 3] = c[4 * eg + 3] - ts.w;
+        }
         const float m = fmaxf(fmaxf(fmaxf(fmaxf(d[0], d[1]), fmaxf(d[2], d[3])), fmaxf(fmaxf(d[4], d[5]), fmaxf(d[6], d[7]))),
                               fmaxf(fmaxf(fmaxf(d[8], d[9]), fmaxf(d[10], d[11])), fmaxf(fmaxf(d[12], d[13]), fmaxf(d[14], d[15]))));
         const bool hit = !(m < 0.f);
