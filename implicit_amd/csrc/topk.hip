@@ -691,12 +691,76 @@ __global__ void coo_filter_refresh_kernel(const float *__restrict__ S, float *__
   }
 }
 
+// The best k of a candidate list sorted by (score desc, column desc) that holds EVERY surviving entry >= the k-th score
+// (both callers guarantee it: their thresholds are lower bounds of the k-th score), ties at the k-th score included.
+template <int BLOCK>
+__device__ void write_best_k(const uint64_t *cand, unsigned int n_c, int k, int q, int32_t *__restrict__ out_ids,
+                             float *__restrict__ out_dist, int out_stride, int *__restrict__ fallback, float unscale_q) {
+  const int tid = threadIdx.x;
+  const uint32_t t32 = (uint32_t)(cand[k - 1] >> 32);
+  const bool tie = (int)n_c > k && t32 == (uint32_t)(cand[k] >> 32);
+  if (!tie) {
+    if (tid == 0) fallback[q] = 0;
+    for (int i = tid; i < k; i += BLOCK) {
+      uint64_t key = cand[i];
+      out_ids[(size_t)q * out_stride + i] = (int32_t)(uint32_t)key;
+      out_dist[(size_t)q * out_stride + i] = unordered((uint32_t)(key >> 32)) * unscale_q;
+    }
+    return;
+  }
+  // Exact tie at the k-th score t.  The reference's heap (implicit/cpu/select.h:12-40) keeps, of the entries tied at t,
+  // those that arrived before the heap was full of entries >= t (saturation column s = column of the k-th entry >= t in
+  // column order) minus the e lowest columns, e = #{column > s : score > t} (closed form derived in select_kernel).  Every
+  // entry >= t is in the candidate list (t >= tau), so the rule can be evaluated right here: the list is sorted by
+  // (score desc, column desc), i.e. [0, g) are the entries > t and [g, g + m) the ties, highest column first.
+  __shared__ unsigned int sh_g, sh_m, sh_e, sh_above;
+  __shared__ int sh_s;
+  if (tid == 0) sh_g = sh_m = sh_e = sh_above = 0;
+  __syncthreads();
+  for (int i = tid; i < (int)n_c; i += BLOCK) {
+    const uint32_t key32 = (uint32_t)(cand[i] >> 32);
+    if (key32 > t32) atomicAdd(&sh_g, 1u);
+    else if (key32 == t32) atomicAdd(&sh_m, 1u);
+  }
+  __syncthreads();
+  const int g = (int)sh_g, m = (int)sh_m, ng = g + m;
+  if (ng > 1024) {  // thousands of tied entries: the quadratic rank below is not worth it, the materialising path takes the row
+    if (tid == 0) fallback[q] = 1;
+    return;
+  }
+  for (int i = tid; i < ng; i += BLOCK) {  // rank in ascending column order; rank k-1 is the saturation column
+    const uint32_t col = (uint32_t)cand[i];
+    int rank = 0;
+    for (int j = 0; j < ng; ++j) rank += (uint32_t)cand[j] < col;
+    if (rank == k - 1) sh_s = (int)col;
+  }
+  __syncthreads();
+  const uint32_t s_col = (uint32_t)sh_s;
+  for (int i = tid; i < ng; i += BLOCK) {
+    const uint32_t col = (uint32_t)cand[i];
+    if (i < g && col > s_col) atomicAdd(&sh_e, 1u);      // later arrivals above t: each evicts the lowest tied column
+    if (i >= g && col > s_col) atomicAdd(&sh_above, 1u);  // ties that arrived after saturation never entered
+  }
+  __syncthreads();
+  const int i0 = g + (int)sh_above, i1 = g + m - (int)sh_e;  // surviving ties: [i0, i1) -- columns <= s minus the e lowest
+  if (tid == 0) fallback[q] = (g + (i1 - i0) == k) ? 0 : 1;   // always k by construction; anything else -> the exact path
+  for (int i = tid; i < ng; i += BLOCK) {
+    int slot = -1;
+    if (i < g) slot = i;
+    else if (i >= i0 && i < i1) slot = g + (i - i0);
+    if (slot >= 0 && slot < k) {
+      const uint64_t key = cand[i];
+      out_ids[(size_t)q * out_stride + slot] = (int32_t)(uint32_t)key;
+      out_dist[(size_t)q * out_stride + slot] = unordered((uint32_t)(key >> 32)) * unscale_q;
+    }
+  }
+}
+
 // Pruned select: tau = the k-th largest tile maximum (maxima refreshed after the filters) is a lower bound of the k-th
 // best surviving score: k distinct tiles each hold a surviving score >= tau.
 // The tiles whose maximum reaches tau (about m of them) are scanned for scores >= tau (tens to a few hundred), which
-// go to LDS; a bitonic sort orders them and the best k are written.  Rows that overflow the candidate buffer, have too few tiles, or show an exact tie at the k-th score
-// (the reference heap's arrival-order rule then needs the whole row) raise `fallback[row]` and are redone by
-// select_kernel.
+// go to LDS; a bitonic sort orders them and the best k are written.  Rows that overflow the candidate buffer or have too few tiles raise `fallback[row]` and are redone by
+// select_kernel; an exact tie at the k-th score is resolved inside the list (write_best_k: every entry >= the k-th score is in it).
 constexpr int kCandCap = 4096;  // 32 KiB of LDS; heavy users (many liked items lower tau) need the headroom
 
 template <int BLOCK>
@@ -795,18 +859,7 @@ __global__ __launch_bounds__(BLOCK) void select_pruned_kernel(const float *__res
       __syncthreads();
     }
   }
-  // exact tie at the k-th score -> the heap rule needs the full row
-  const bool tie = (int)n_c > k && (uint32_t)(cand[k - 1] >> 32) == (uint32_t)(cand[k] >> 32);
-  if (tie) {
-    if (tid == 0) fallback[q] = 1;
-    return;
-  }
-  if (tid == 0) fallback[q] = 0;
-  for (int i = tid; i < k; i += BLOCK) {
-    uint64_t key = cand[i];
-    out_ids[(size_t)q * out_stride + i] = (int32_t)(uint32_t)key;
-    out_dist[(size_t)q * out_stride + i] = unordered((uint32_t)(key >> 32));
-  }
+  write_best_k<BLOCK>(cand, n_c, k, q, out_ids, out_dist, out_stride, fallback, 1.0f);
 }
 
 // ---- emit path: top-k without the score matrix -----------------------------------------------------------------------
@@ -990,63 +1043,7 @@ __global__ __launch_bounds__(BLOCK) void select_candidates_kernel(const uint64_t
     if (tid == 0) fallback[q] = 1;                 // (or the scores really are infinite) -- the exact path decides
     return;
   }
-  const uint32_t t32 = (uint32_t)(cand[k - 1] >> 32);
-  const bool tie = (int)n_c > k && t32 == (uint32_t)(cand[k] >> 32);
-  if (!tie) {
-    if (tid == 0) fallback[q] = 0;
-    for (int i = tid; i < k; i += BLOCK) {
-      uint64_t key = cand[i];
-      out_ids[(size_t)q * out_stride + i] = (int32_t)(uint32_t)key;
-      out_dist[(size_t)q * out_stride + i] = unordered((uint32_t)(key >> 32)) * unscale_q;
-    }
-    return;
-  }
-  // Exact tie at the k-th score t.  The reference's heap (implicit/cpu/select.h:12-40) keeps, of the entries tied at t,
-  // those that arrived before the heap was full of entries >= t (saturation column s = column of the k-th entry >= t in
-  // column order) minus the e lowest columns, e = #{column > s : score > t} (closed form derived in select_kernel).  Every
-  // entry >= t is in the candidate list (t >= tau), so the rule can be evaluated right here: the list is sorted by
-  // (score desc, column desc), i.e. [0, g) are the entries > t and [g, g + m) the ties, highest column first.
-  __shared__ unsigned int sh_g, sh_m, sh_e, sh_above;
-  __shared__ int sh_s;
-  if (tid == 0) sh_g = sh_m = sh_e = sh_above = 0;
-  __syncthreads();
-  for (int i = tid; i < (int)n_c; i += BLOCK) {
-    const uint32_t key32 = (uint32_t)(cand[i] >> 32);
-    if (key32 > t32) atomicAdd(&sh_g, 1u);
-    else if (key32 == t32) atomicAdd(&sh_m, 1u);
-  }
-  __syncthreads();
-  const int g = (int)sh_g, m = (int)sh_m, ng = g + m;
-  if (ng > 1024) {  // thousands of tied entries: the quadratic rank below is not worth it, the materialising path takes the row
-    if (tid == 0) fallback[q] = 1;
-    return;
-  }
-  for (int i = tid; i < ng; i += BLOCK) {  // rank in ascending column order; rank k-1 is the saturation column
-    const uint32_t col = (uint32_t)cand[i];
-    int rank = 0;
-    for (int j = 0; j < ng; ++j) rank += (uint32_t)cand[j] < col;
-    if (rank == k - 1) sh_s = (int)col;
-  }
-  __syncthreads();
-  const uint32_t s_col = (uint32_t)sh_s;
-  for (int i = tid; i < ng; i += BLOCK) {
-    const uint32_t col = (uint32_t)cand[i];
-    if (i < g && col > s_col) atomicAdd(&sh_e, 1u);      // later arrivals above t: each evicts the lowest tied column
-    if (i >= g && col > s_col) atomicAdd(&sh_above, 1u);  // ties that arrived after saturation never entered
-  }
-  __syncthreads();
-  const int i0 = g + (int)sh_above, i1 = g + m - (int)sh_e;  // surviving ties: [i0, i1) -- columns <= s minus the e lowest
-  if (tid == 0) fallback[q] = (g + (i1 - i0) == k) ? 0 : 1;   // always k by construction; anything else -> the exact path
-  for (int i = tid; i < ng; i += BLOCK) {
-    int slot = -1;
-    if (i < g) slot = i;
-    else if (i >= i0 && i < i1) slot = g + (i - i0);
-    if (slot >= 0 && slot < k) {
-      const uint64_t key = cand[i];
-      out_ids[(size_t)q * out_stride + slot] = (int32_t)(uint32_t)key;
-      out_dist[(size_t)q * out_stride + slot] = unordered((uint32_t)(key >> 32)) * unscale_q;
-    }
-  }
+  write_best_k<BLOCK>(cand, n_c, k, q, out_ids, out_dist, out_stride, fallback, unscale_q);
 }
 
 // factor counts that are not a multiple of 16 (the reference's CPU default is 100): rows zero-padded to the next multiple, fp16
@@ -1600,6 +1597,19 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
         kern<<<(unsigned)rows, 512, lds, stream()>>>(scores, (int)ni, k_eff, kpad, d_ids + start * k, d_dist + start * k, k, gcand,
                                                      use_lds ? 1 : 0, fast ? fallback : nullptr);
         IMP_CHECK_HIP(hipGetLastError());
+      }
+      static const bool debug_m = getenv("IMP_TOPK_DEBUG") != nullptr;
+      if (debug_m && fast) {  // how many rows the pruned select handed to the exact select
+        std::vector<int> hf(rows);
+        IMP_CHECK_HIP(hipMemcpy(hf.data(), fallback, rows * sizeof(int), hipMemcpyDeviceToHost));
+        size_t nfb = 0, first_fb = 0;
+        for (size_t i = 0; i < rows; ++i)
+          if (hf[i]) {
+            if (!nfb) first_fb = i;
+            ++nfb;
+          }
+        fprintf(stderr, "[topk-debug] materialising batch at %zu: %zu of %zu rows re-done by the exact select (first: row %zu)\n", start, nfb,
+                rows, first_fb);
       }
     }
     deliver();

@@ -111,6 +111,32 @@ def test_topk_ties_match_select_h_exactly(gpu, oracle):
         assert_array_equal(d, want_d)
 
 
+@pytest.mark.parametrize("k", [37, 99, 100])
+def test_pruned_select_resolves_ties_at_the_kth_score(gpu, oracle, k):
+    """Catalogues too small for the emit path (items < 512 k) take the materialising path, whose pruned select now
+    applies the heap's arrival-order rule (select.h:12-40) inside its candidate list instead of sending tie rows to
+    the whole-row select.  Small-integer factors: every arithmetic form gives the same exact scores, so ids AND
+    distances must equal the oracle's bit for bit -- with tie groups of every size at the k-th score, and filters."""
+    rng = np.random.default_rng(31)
+    ni, f, nq = 20_000, 32, 96
+    items = rng.integers(-7, 8, size=(ni, f)).astype(np.float32)
+    items[ni // 2:] = items[: ni // 2]             # every score appears at least twice: odd k splits a pair
+    queries = rng.integers(-7, 8, size=(nq, f)).astype(np.float32)
+    queries[3] = 0.0                               # all scores tie
+    want_ids, want_d = oracle.topk(items, queries, k)
+    knn = gpu.KnnQuery()
+    ids, d = knn.topk(gpu.Matrix(items), gpu.Matrix(queries), k)
+    assert_array_equal(ids, want_ids)
+    assert_array_equal(d, want_d)
+    filt = np.unique(rng.integers(0, ni, size=3000)).astype(np.int32)
+    liked = sp.random(nq, ni, density=0.003, format="csr", dtype=np.float32, random_state=5)
+    want_ids, want_d = oracle.topk(items, queries, k, filter_query_items=liked, filter_items=filt)
+    ids, d = knn.topk(gpu.Matrix(items), gpu.Matrix(queries), k, query_filter=gpu.COOMatrix(liked.tocoo()),
+                      item_filter=gpu.IntVector(filt))
+    assert_array_equal(ids, want_ids)
+    assert_array_equal(d, want_d)
+
+
 def test_topk_zero_queries_and_all_filtered_tail(gpu, oracle):
     """Users without interactions (zero factors) and N larger than the unfiltered items
     (recommender_base_test.py:54-57): ids identical to the CPU path, filtered entries score -FLT_MAX."""
