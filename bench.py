@@ -193,7 +193,7 @@ def cpu_baseline(Cui, Ciu, X0, Y0, seconds):
         "unit": "updates/s",
         "cores": cores,
         "kind": kind,
-        "sample_short": f"CG(3) f={X0.shape[1]} half sweeps over {su}+{si} rows ({nnz} nnz), {t:.1f}s, {cores} of {os.cpu_count()} cores",
+        "sample_short": f"CG(3) f={X0.shape[1]} half sweeps, {su}+{si} rows, {t:.1f}s, {cores} threads",
         "sample": f"one CG(cg_steps=3,f={X0.shape[1]}) half-sweep over {su} users + {si} items taken at a uniform stride "
                   f"({nnz} nnz) of the same matrix, {t:.1f}s, OpenMP num_threads={cores} of {os.cpu_count()} logical cores, "
                   f"BLAS threads=1",
@@ -473,21 +473,17 @@ def compact_line(full, args):
     if topk:
         # recs/s is quoted through model.recommend(userids, user_items[userids], N=k) with the liked-items filter
         line["topk_recs_per_s"] = _r(topk.get("value"))
-        line["knn_topk_recs_per_s"] = _r(topk.get("knn_topk_recs_per_s"))
-        line["recommend_presliced_recs_per_s"] = _r(topk.get("model_recommend_presliced_recs_per_s"))
     c = full["config"]
     line["config"] = {"workload": c["workload"], "users": c["users"], "items": c["items"], "nnz": c["nnz"], "factors": c["factors"],
-                      "solver": c["solver"], "cg_steps": c["cg_steps"], "topk": "recommend() k=10, 20000 users in batches of 1000, liked-items filter on"
-                      if topk else None}
+                      "solver": c["solver"], "cg_steps": c["cg_steps"], "topk": "recommend() k=10, 20000 users, batches of 1000, liked-items filter" if topk else None}
     r = full.get("roofline")
     if r:
         line["roofline"] = {"bound": r["bound"], "achieved": _r(r["achieved"]), "peak": r["peak"], "unit": r["unit"], "frac": _r(r["frac"], 4),
-                            "traffic": _r(r["traffic"]), "kernel": "CG half sweep (all row-class launches of least_squares)",
+                            "traffic": _r(r["traffic"]), "kernel": "CG half sweep (all row-class launches)",
                             "avg_launch_ms": _r(r["avg_launch_ms"], 4), "frac_half_sweep_events": _r(r["frac_half_sweep_events"], 4),
                             "bytes_per_step": r["algorithmic_bytes_per_step"],
                             "classes_frac": {k: _r(v["frac"], 3) for k, v in full.get("row_classes", {}).items()},
-                            "split_precision": "rows>512 nnz: fp16x2 MFMA normal matrix (22-bit operands, fp32 accumulate, fp32 "
-                                               "fix-up); rows<=32: bf16x3 gramian product; else fp32"}
+                            "split_precision": "rows>512 nnz: fp16x2 MFMA normal matrix + fp32 fix-up; <=32: bf16x3 gramian; else fp32"}
     cb = full.get("cpu_baseline")
     if cb:
         line["cpu_baseline"] = {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "cores_total": os.cpu_count(),
@@ -498,11 +494,14 @@ def compact_line(full, args):
             line["cpu_baseline"]["topk_cores"] = tcb["cores"]
     if topk:
         tr = topk.get("roofline") or {}
-        line["topk"] = {"value": _r(topk.get("value")), "unit": "recs/s", "k": topk.get("k"), "via": "model.recommend()",
+        line["topk"] = {"k": topk.get("k"), "via": "model.recommend()", "knn_topk_recs_per_s": _r(topk.get("knn_topk_recs_per_s")),
+                        "presliced_recs_per_s": _r(topk.get("model_recommend_presliced_recs_per_s")),
                         "gemm_ms": _r(tr.get("avg_launch_ms"), 4), "gemm_frac_of_mfma_peak": _r(tr.get("frac"), 3),
                         "gemm_traffic": _r(tr.get("traffic"))}
     extras = {}
     for key, v in full.items():
+        if key in ("cg_c3_f32", "cg_c3_f192", "cholesky_c3_f100"):  # side file only: the line must stay under 2000 characters
+            continue
         if isinstance(v, dict) and "roofline" in v and key not in ("topk",) and isinstance(v.get("roofline"), dict):
             ms = v.get("ms_per_iter", v.get("compute_ms_per_iter", v.get("ms_per_batch")))
             extras[key] = [_r(ms, 3), _r(v["roofline"].get("frac"), 3)]
@@ -515,6 +514,9 @@ def compact_line(full, args):
     if errs:
         line["extras_errors"] = errs
     line["detail"] = os.path.relpath(detail_path, ROOT) if detail_path else None
+    line["value"], line["ms_per_step"] = _r(line["value"]), _r(line["ms_per_step"], 4)
+    while len(json.dumps(line)) > 1950 and line.get("extras_ms_frac"):  # never longer than the driver's 2000-character tail
+        line["extras_ms_frac"].popitem()
     return line
 
 
