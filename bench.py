@@ -813,7 +813,7 @@ def extra_c2(gpu, SHAPES):
 
     rows = C.shape[0] + C.shape[1]
     t_chol, k_chol = _time_iterations(gpu, chol)
-    flops = 2.0 * C.nnz * 2 * f * f + rows * (f ** 3 / 3.0 + 2.0 * f * f)  # nnz 2f^2 (SYRK) + R (f^3/3 + 2f^2), both sides
+    flops = 2.0 * C.nnz * 2 * f * f + rows * (f ** 3 / 3.0 + 2.0 * f * f)  # DESIGN 4 (kernel table): nnz 2f^2 (SYRK) + R (f^3/3 + 2f^2), both sides
     X.copy_from_numpy(rng.random((C.shape[0], f), dtype=np.float32) * 0.01)
     Y.copy_from_numpy(rng.random((C.shape[1], f), dtype=np.float32) * 0.01)
     t_cg, k_cg = _time_iterations(gpu, cg)

@@ -3,7 +3,7 @@
 //
 // Arithmetic contract: the oracle's CG (implicit/cpu/_als.pyx:152-248).
 //
-// What the round-2 team kernels spent (profiles/micro/valu_rate.hip, profiles/r04_micro_valu_rate.txt; DESIGN.md section 4.1 has
+// What the round-2 team kernels spent (profiles/micro/valu_rate.hip, profiles/r04_micro_valu_rate.txt; HISTORY.md section 4.1 has
 // the full picture): saturated, a SIMD retires a plain vector instruction every 2.3 cycles and a packed FMA, a DPP form or an
 // SGPR-operand form every 4.1-4.4; one wave alone issues only every 5.5-6 cycles.  The round-2 kernels executed 1.03 G vector
 // instructions per C3 iteration for the mid-row classes, and only ~55 % of them were the FMAs of the dense part and of the tile;
@@ -433,7 +433,7 @@ static void launch_qfteam(const imp_csr *C, int first, int count, T *X, const T 
   IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / BLOCK, (160 * 1024) / lds));
   // als_cg_q.hip launch_qteam; the 16-wave team at f = 64 (16 KB of gramian to stage, two workgroups per CU) takes 2 as well:
-  // configs[1]-shaped CG 1.47 -> 1.42 ms, and a fixed share on a contended CU is what took seconds once
+  // configs[1]-shaped CG 1.47 -> 1.42 ms, and a fixed share on a contended CU is what took seconds once (HISTORY.md section 6)
   constexpr int kBaseOversub = WPR <= 4 ? 4 : (WPR == 8 ? 2 : (F == 64 ? 2 : 1));
   int grid = std::min((count + TEAMS - 1) / TEAMS, ctx().num_cus * per_cu * std::max(kBaseOversub, ctx().oversub));
   IMP_PROF(name);

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void gramian_partial_vec_kernel(const T *__res
 }
 
 // (The split-bf16 form of the f = 128 gramian -- three bf16 terms per operand on v_mfma_f32_32x32x16_bf16, round 5: the launch
-// 12-20 % shorter, every CG kernel behind it 4-8 % slower on some boxes -- was opt-in and is removed)
+// 12-20 % shorter, every CG kernel behind it 4-8 % slower on some boxes -- was opt-in and is removed; HISTORY.md section 4.3.)
 
 
 // out = sum over chunks (fixed order) + reg on the diagonal, mirrored.  Block = 64 elements of one tile pair x 16 chunk

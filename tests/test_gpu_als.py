@@ -83,7 +83,7 @@ def test_cg_cold_sweep_vs_fp64(gpu, oracle, f):
 
 
 # every cut of the row schedule from both sides (and the cuts of round 6's experiment with team widths 3 and 5, 96 and 160
-# nonzeros: measured slower, not kept -- DESIGN 4.1) with several rows per length so that teams of one workgroup get rows of
+# nonzeros: measured slower, not kept -- DESIGN 4.1, profiles/r06_team_widths.txt) with several rows per length so that teams of one workgroup get rows of
 # different lengths
 TEAM_EDGE_LENGTHS = [30, 32, 33, 40, 63, 64, 65, 66, 80, 93, 95, 96, 97, 100, 127, 128, 129, 130, 144, 157, 159, 160, 161, 162, 200, 255,
                      256, 257, 300, 511, 512, 513, 0]
