@@ -157,6 +157,11 @@ struct Context {
   std::recursive_mutex mutex;
   std::mutex small_mutex;                  // the free lists below (a Storage may die on a thread that holds another device's lock)
   std::vector<void *> small_free[24];      // [log2 size]: recycled device blocks of 256 B .. 4 MB (Storage)
+  // page-locked, device-addressable staging of imp_coo_create_from_csr_pattern: the expand kernel reads it in place; the event
+  // marks that kernel's end (the next call waits for it before overwriting the buffer)
+  void *pin_stage = nullptr;
+  size_t pin_stage_bytes = 0;
+  hipEvent_t pin_stage_ev = nullptr;
   DeviceArray<float> gram_ws;     // split-K partial gramians (gramian.hip)
   DeviceArray<float> long_ws;     // partial vectors / CG state of the long rows (als_cg.hip)
   DeviceArray<float> pad_x, pad_y, pad_gram;  // zero-padded copies for factor counts that ride the f = 64 / 128 / 256 kernels (als_cg.hip)

@@ -1007,6 +1007,64 @@ int imp_coo_create(int32_t rows, int32_t cols, int64_t nnz, const int32_t *row, 
   });
 }
 
+// (row, col) pattern of a host CSR matrix -> device COO.  One wavefront per row writes the row ids, every thread copies its
+// share of the column ids; both inputs are read from page-locked host memory in place (coalesced, once)
+__global__ void coo_from_csr_kernel(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, int rows, int64_t nnz,
+                                    int32_t *__restrict__ row_out, int32_t *__restrict__ col_out) {
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x, n = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = t; i < (size_t)nnz; i += n) col_out[i] = indices[i];
+  const int lane = threadIdx.x & 63;
+  for (size_t r = t >> 6; r < (size_t)rows; r += n >> 6) {
+    const int b = indptr[r], e = indptr[r + 1];
+    for (int j = b + lane; j < e; j += 64) row_out[j] = (int32_t)r;
+  }
+}
+
+int imp_coo_create_from_csr_pattern(int32_t rows, int32_t cols, const void *indptr, int indptr_is_64, const int32_t *indices,
+                                    imp_coo **out) {
+  return guarded([&] {
+    if (rows < 0 || cols < 0) throw std::invalid_argument("negative dimension for COOMatrix");
+    if (!indptr) throw std::invalid_argument("COOMatrix.from_csr_pattern: indptr is required");
+    const int64_t *p64 = indptr_is_64 ? static_cast<const int64_t *>(indptr) : nullptr;
+    const int32_t *p32 = indptr_is_64 ? nullptr : static_cast<const int32_t *>(indptr);
+    auto at = [&](int64_t i) -> int64_t { return p64 ? p64[i] : (int64_t)p32[i]; };
+    const int64_t base = at(0), nnz = at(rows) - base;
+    if (nnz < 0 || nnz > INT32_MAX) throw std::invalid_argument("COOMatrix.from_csr_pattern: nonzero count out of range");
+    if (nnz && !indices) throw std::invalid_argument("COOMatrix.from_csr_pattern: indices are required");
+    auto m = std::make_unique<imp_coo>();
+    m->rows = rows, m->cols = cols, m->nnz = nnz;
+    m->row.alloc((size_t)nnz);
+    m->col.alloc((size_t)nnz);
+    if (nnz) {
+      Context &c = ctx();
+      const size_t words = (size_t)rows + 1 + (size_t)nnz;
+      if (!c.pin_stage_ev) IMP_CHECK_HIP(hipEventCreateWithFlags(&c.pin_stage_ev, hipEventDisableTiming));
+      else IMP_CHECK_HIP(hipEventSynchronize(c.pin_stage_ev));  // the previous expand kernel is done with the buffer
+      if (c.pin_stage_bytes < words * 4) {
+        if (c.pin_stage) (void)hipHostFree(c.pin_stage);
+        c.pin_stage = nullptr, c.pin_stage_bytes = 0;
+        const size_t want = std::max(words * 4 * 2, (size_t)1 << 20);
+        IMP_CHECK_HIP(hipHostMalloc(&c.pin_stage, want, hipHostMallocDefault));
+        c.pin_stage_bytes = want;
+      }
+      int32_t *sp = static_cast<int32_t *>(c.pin_stage), *si = sp + rows + 1;
+      int64_t prev = 0;
+      for (int64_t r = 0; r <= rows; ++r) {
+        const int64_t v = at(r) - base;
+        if (v < prev || v > nnz) throw std::invalid_argument("COOMatrix.from_csr_pattern: indptr must be non-decreasing");
+        sp[r] = (int32_t)v, prev = v;
+      }
+      std::memcpy(si, indices + base, (size_t)nnz * 4);
+      const int grid = (int)std::min<size_t>(((size_t)std::max<int64_t>(nnz, (int64_t)rows * 64) + 255) / 256, (size_t)c.num_cus * 8);
+      coo_from_csr_kernel<<<grid, 256, 0, stream()>>>(sp, si, rows, nnz, m->row.data(), m->col.data());
+      IMP_CHECK_HIP(hipGetLastError());
+      IMP_CHECK_HIP(hipEventRecord(c.pin_stage_ev, stream()));
+      // no host wait: the caller's arrays have been copied, and whatever reads the matrix is queued behind the kernel
+    }
+    *out = m.release();
+  });
+}
+
 int imp_coo_destroy(imp_coo *m) {
   return guarded([&] { delete m; });
 }

@@ -310,12 +310,15 @@ class COOMatrix:
         """NEW: the (row, col) pattern of a scipy CSR matrix as a device COO without its values -- all the top-k filters read
         (knn.cu:197-214 reads row / col only).  Skips scipy's tocoo() and the value upload: recommend() builds one per batch."""
         self = cls.__new__(cls)
-        indptr = np.asarray(X.indptr)
+        indptr = np.ascontiguousarray(X.indptr)
+        if indptr.dtype not in (np.int32, np.int64):
+            indptr = indptr.astype(np.int64)
         col = np.ascontiguousarray(X.indices, dtype=np.int32)
-        row = np.repeat(np.arange(X.shape[0], dtype=np.int32), np.diff(indptr))
         self._h = ctypes.c_void_p()
         self.shape = X.shape
-        check(lib().imp_coo_create(X.shape[0], X.shape[1], len(col), _vp(row), _vp(col), None, ctypes.byref(self._h)))
+        # indptr + indices go to page-locked staging and a kernel expands the row ids: no np.repeat, no blocking uploads
+        check(lib().imp_coo_create_from_csr_pattern(X.shape[0], X.shape[1], _vp(indptr), int(indptr.dtype == np.int64), _vp(col),
+                                                    ctypes.byref(self._h)))
         return self
 
     def __del__(self):

@@ -60,6 +60,8 @@ _SIGNATURES = {
     "imp_csr_destroy": [ctypes.c_void_p],
     "imp_coo_create": [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                        ctypes.c_void_p, c_void_pp],
+    "imp_coo_create_from_csr_pattern": [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                        ctypes.POINTER(ctypes.c_void_p)],
     "imp_coo_destroy": [ctypes.c_void_p],
     "imp_solver_create": [c_void_pp],
     "imp_solver_destroy": [ctypes.c_void_p],

@@ -139,6 +139,13 @@ int imp_csr_shape(const imp_csr *m, int32_t *rows, int32_t *cols, int64_t *nonze
 int imp_csr_destroy(imp_csr *m);
 int imp_coo_create(int32_t rows, int32_t cols, int64_t nonzeros, const int32_t *row,
                    const int32_t *col, const float *data, imp_coo **out);
+/* NEW: the (row, col) pattern of a HOST CSR matrix as a device COO without values -- all the top-k filters read
+ * (knn.cu:197-214 reads row / col only).  `indptr`: rows + 1 offsets, int32 or int64 (`indptr_is_64`); `indices`: int32.
+ * Both are copied to page-locked staging and expanded by a kernel: no blocking upload, no host-side row expansion.
+ * recommend() builds one per batch (the reference: scipy tocoo() + three Vector uploads, matrix_factorization_base.py:109-112,
+ * matrix.cu:253-262). */
+int imp_coo_create_from_csr_pattern(int32_t rows, int32_t cols, const void *indptr, int indptr_is_64,
+                                    const int32_t *indices, imp_coo **out);
 int imp_coo_destroy(imp_coo *m);
 
 /* ---- LeastSquaresSolver (als.h:11-24, als.cu:118-281) ---------------------------------------- */

@@ -409,3 +409,36 @@ def test_device_output_pointers(gpu, shape):
         if flt is not None:  # nothing a user already liked comes back
             hit = [np.intersect1d(want_ids[r], liked.indices[liked.indptr[r]:liked.indptr[r + 1]]).size for r in range(nq)]
             assert not any(hit)
+
+
+def test_coo_filter_from_a_csr_pattern(gpu):
+    """COOMatrix.from_csr_pattern (what recommend() builds per batch: indptr + indices through page-locked staging, row ids expanded
+    on the device) filters exactly like the COO built from scipy's tocoo() (knn.cu:197-214 reads row / col only) -- 32- and
+    64-bit offsets, empty rows, one long row, an empty matrix; a decreasing indptr is a ValueError."""
+    rng = np.random.default_rng(5)
+    ni, f, nq, k = 30_000, 32, 300, 10
+    items = (rng.standard_normal((ni, f)) * 0.1).astype(np.float32)
+    queries = (rng.standard_normal((nq, f)) * 0.1).astype(np.float32)
+    liked = sp.random(nq, ni, density=0.003, format="lil", dtype=np.float32, random_state=9)
+    liked[7] = 0                                     # an empty row
+    liked[11, : ni // 3] = 1.0                       # a long one: 10 000 liked items
+    liked = liked.tocsr()
+    liked.eliminate_zeros()
+    I, Q, knn = gpu.Matrix(items), gpu.Matrix(queries), gpu.KnnQuery()
+    want_ids, want_d = knn.topk(I, Q, k, query_filter=gpu.COOMatrix(liked.tocoo()))
+    for dtype in (np.int32, np.int64):
+        L = liked.copy()
+        L.indptr = L.indptr.astype(dtype)
+        for _ in range(2):                           # the second call re-uses the staging buffer
+            ids, d = knn.topk(I, Q, k, query_filter=gpu.COOMatrix.from_csr_pattern(L))
+            assert_array_equal(ids, want_ids)
+            assert_array_equal(d, want_d)
+    assert not np.isin(want_ids[11], np.arange(ni // 3)).any()
+    empty = sp.csr_matrix((nq, ni), dtype=np.float32)
+    ids, _ = knn.topk(I, Q, k, query_filter=gpu.COOMatrix.from_csr_pattern(empty))
+    assert_array_equal(ids, knn.topk(I, Q, k)[0])
+    bad = liked.copy()
+    bad.indptr = bad.indptr.copy()
+    bad.indptr[5] = bad.indptr[6] + 3
+    with pytest.raises(ValueError):
+        gpu.COOMatrix.from_csr_pattern(bad)
