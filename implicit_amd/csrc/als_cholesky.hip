@@ -35,8 +35,13 @@ __device__ __forceinline__ float bcast_lane(float v, int lane) {
 //     of 16 bytes per 128 FMAs) -- two barriers per PANEL;
 //   * the augmented row f (b^T -> z^T) rides along as before, the back substitution is unchanged.
 // Arithmetic: the same products, panel by panel instead of column by column (association of the trailing sums differs).
+// f > 256 (round 6; the CPU reference takes any f, _als.pyx:75-142): GLOBAL = true keeps the augmented triangle in a per-workgroup
+// slice of a device workspace instead of the LDS (square layout; L2 / infinity-cache resident: 0.4 MB at f = 320, 4.2 MB at
+// f = 1024) -- every phase that passes data between threads through it is already separated by a workgroup barrier, which orders
+// global memory inside a workgroup as well.  ROWS = rows of the panel a lane holds (64 ROWS >= f + 1), MAXV = f / 64 rounded up.
+// A coverage path: correct, an order of magnitude off the LDS kernels' rate per flop.
 constexpr int kCholPanel = 8;
-template <bool PACKED>
+template <bool PACKED, bool GLOBAL = false, int ROWS = 5, int MAXV_ = 4>
 __global__ __launch_bounds__(256) void als_cholesky_blocked_kernel(const int32_t *__restrict__ order, int first, int count,
                                                                    const int32_t *__restrict__ indptr,
                                                                    const int32_t *__restrict__ indices,
@@ -44,16 +49,18 @@ __global__ __launch_bounds__(256) void als_cholesky_blocked_kernel(const int32_t
                                                                    const float *__restrict__ Y, const float *__restrict__ YtY,
                                                                    int f, float reg, int lda, unsigned long long *failed_row,
                                                                    int ko,  // ko: timing-only knock-out mask (IMP_CHOL_KO), 0 in production
-                                                                   const unsigned *__restrict__ dev_count = nullptr) {  // rows of `order` to take, if fewer than `count`
+                                                                   const unsigned *__restrict__ dev_count = nullptr,  // rows of `order` to take, if fewer than `count`
+                                                                   float *__restrict__ global_ws = nullptr) {
+  static_assert(!(PACKED && GLOBAL), "the workspace form uses the square layout");
   if (dev_count) count = min(count, (int)*dev_count);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int m = f + 1;                         // rows of the augmented triangle (row f = b^T -> z^T), f columns
   const int nbr = (m + 3) >> 2, nbc = (f + 3) >> 2;  // 4 x 4 blocks
   const int FS = 4 * nbc, US = 4 * nbr;        // padded strides of the staged tile
-  float *A = smem;
-  auto at = [&](int i, int j) { return PACKED ? i * (i + 1) / 2 + j : i * lda + j; };  // j <= i
   const size_t a_words = PACKED ? (size_t)m * (m + 1) / 2 : (size_t)m * lda;
-  float *yt = A + ((a_words + 3) & ~(size_t)3);  // [TILE][FS]  gathered rows, zero beyond f
+  float *A = GLOBAL ? global_ws + (size_t)blockIdx.x * ((a_words + 3) & ~(size_t)3) : smem;
+  auto at = [&](int i, int j) { return PACKED ? i * (i + 1) / 2 + j : i * lda + j; };  // j <= i
+  float *yt = GLOBAL ? smem : A + ((a_words + 3) & ~(size_t)3);  // [TILE][FS]  gathered rows, zero beyond f
   float *ut = yt + (size_t)kCholTile * FS;       // [TILE][US]  (|c|-1) y, c+ at index f, zero beyond
   float *panel = ut + (size_t)kCholTile * US;    // [m][8]      L[i][k0 .. k0+7] of the current panel
   int *flag = reinterpret_cast<int *>(panel + (size_t)m * kCholPanel);
@@ -149,7 +156,7 @@ __global__ __launch_bounds__(256) void als_cholesky_blocked_kernel(const int32_t
         // k0 + l + 64 r.  Row k0 + c is lane c's first row, so the pivot and the sub-diagonal entries a column step needs travel
         // by v_readlane; nothing touches the LDS between the load and the store of the panel (a first version walked the
         // panel through the LDS column by column: ~70 dependent LDS round trips per column, 640 K cycles per row).
-        constexpr int R = 5;  // 64 R >= 257 rows (f <= 256)
+        constexpr int R = ROWS;  // 64 R >= f + 1 rows (5: f <= 256)
         float pr[R][kCholPanel];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -245,7 +252,7 @@ __global__ __launch_bounds__(256) void als_cholesky_blocked_kernel(const int32_t
     }
     // back substitution L^T x = z with one wavefront; lane l owns z[l + 64 m]
     if (tid < 64 && !(ko & 8)) {
-      constexpr int MAXV = 4;  // f <= 256
+      constexpr int MAXV = MAXV_;  // 64 MAXV >= f (4: f <= 256)
       float z[MAXV];
 #pragma unroll
       for (int mm = 0; mm < MAXV; ++mm) {
@@ -712,7 +719,7 @@ void zero_rows(const int32_t *order, int first, int count, float *X, int f);  //
 // returns -1, or the smallest failing row
 int64_t least_squares_cholesky(const imp_csr *C, imp_matrix *X, const imp_matrix *YtY, const imp_matrix *Y, double reg) {
   const int f = (int)X->cols;
-  if (f > 256) throw std::invalid_argument("least_squares_cholesky: factors must be <= 256 in this build");
+  if (f > 1024) throw std::invalid_argument("least_squares_cholesky: factors must be <= 1024 (as the reference's GPU kernels, als.cu:177-182)");
   // 64 < f < 128 (the reference's CPU default is 100): zero-padded onto the f = 128 path below -- Y and the gramian padded, the gramian
   // with a unit diagonal block: the padded system is block diagonal and its solution the original one followed by zeros (its 4 x 4
   // blocks factorise in the same order; the padded block rows never touch the others).  125 -> about 62 ms per configs[2]-shaped
@@ -810,20 +817,36 @@ int64_t least_squares_cholesky(const imp_csr *C, imp_matrix *X, const imp_matrix
       const size_t a_words = packed ? (size_t)m * (m + 1) / 2 : (size_t)m * lda;
       lds = (((a_words + 3) & ~(size_t)3) + (size_t)kCholTile * 4 * (nbc + nbr) + (size_t)m * kCholPanel + 4) * sizeof(float);
     }
-    int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
-    int grid = std::min(n_block, ctx().num_cus * per_cu * 4);  // smaller fixed shares of the length-sorted schedule
-    IMP_PROF("als_cholesky_rows");
-    constexpr int ko = 0;  // (timing-only knock-outs of the phases: 1 A-build, 2 panel, 4 trailing update, 8 back substitution)
-    auto kern = packed ? als_cholesky_blocked_kernel<true> : als_cholesky_blocked_kernel<false>;
-    IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (use_nm)  // the listed rows only (the list stands in for the schedule; a zero count makes every workgroup return at once)
-      kern<<<std::min(nm_list.capacity, ctx().num_cus * per_cu), 256, lds, stream()>>>(
-          reinterpret_cast<const int32_t *>(nm_list.rows), 0, nm_list.capacity, C->indptr.data(), C->indices.data(), C->data.data(),
-          X->f32(), Y->f32(), YtY->f32(), f, (float)reg, lda, g_failed, ko, nm_list.count);
-    else
+    if (f > 256) {
+      // the triangle in a device workspace (als_cholesky_blocked_kernel<.., GLOBAL>): two workgroups per CU, a slice each
+      const int m = f + 1, nbr = (m + 3) / 4, nbc = (f + 3) / 4;
+      const size_t a_words = ((size_t)m * lda + 3) & ~(size_t)3;
+      lds = ((size_t)kCholTile * 4 * (nbc + nbr) + (size_t)m * kCholPanel + 4) * sizeof(float);
+      const int grid = std::min(n_block, ctx().num_cus * 2);
+      auto &ws = ctx().long_ws;
+      if (ws.size < a_words * (size_t)grid) ws.alloc(a_words * (size_t)grid);
+      IMP_PROF("als_cholesky_rows");
+      auto kern = als_cholesky_blocked_kernel<false, true, 17, 16>;
+      IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       kern<<<grid, 256, lds, stream()>>>(C->order.data(), 0, n_block, C->indptr.data(), C->indices.data(), C->data.data(), X->f32(),
-                                         Y->f32(), YtY->f32(), f, (float)reg, lda, g_failed, ko, nullptr);
-    IMP_CHECK_HIP(hipGetLastError());
+                                         Y->f32(), YtY->f32(), f, (float)reg, lda, g_failed, 0, nullptr, ws.data());
+      IMP_CHECK_HIP(hipGetLastError());
+    } else {
+    int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
+      int grid = std::min(n_block, ctx().num_cus * per_cu * 4);  // smaller fixed shares of the length-sorted schedule
+      IMP_PROF("als_cholesky_rows");
+      constexpr int ko = 0;  // (timing-only knock-outs of the phases: 1 A-build, 2 panel, 4 trailing update, 8 back substitution)
+      auto kern = packed ? als_cholesky_blocked_kernel<true> : als_cholesky_blocked_kernel<false>;
+      IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      if (use_nm)  // the listed rows only (the list stands in for the schedule; a zero count makes every workgroup return at once)
+        kern<<<std::min(nm_list.capacity, ctx().num_cus * per_cu), 256, lds, stream()>>>(
+            reinterpret_cast<const int32_t *>(nm_list.rows), 0, nm_list.capacity, C->indptr.data(), C->indices.data(), C->data.data(),
+            X->f32(), Y->f32(), YtY->f32(), f, (float)reg, lda, g_failed, ko, nm_list.count, nullptr);
+      else
+        kern<<<grid, 256, lds, stream()>>>(C->order.data(), 0, n_block, C->indptr.data(), C->indices.data(), C->data.data(), X->f32(),
+                                           Y->f32(), YtY->f32(), f, (float)reg, lda, g_failed, ko, nullptr, nullptr);
+      IMP_CHECK_HIP(hipGetLastError());
+    }
   }
   zero_rows(C->order.data(), C->first_empty(), C->n_empty(), X->f32(), f);
   unsigned long long failed = 0;

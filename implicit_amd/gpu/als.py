@@ -11,8 +11,7 @@ numerics of the reference's *CPU* path, which is the parity oracle (implicit/cpu
     reference-GPU style U(-0.5/f, 0.5/f) drawn on the device (gpu/als.py:129-139);
   * `use_cg=False` selects the Cholesky solver (cpu/als.py:418-423), which the reference GPU path
     does not have; recalculate_user/item use Cholesky as the CPU path does (cpu/als.py:221-241)
-    when factors <= 256, else CG run to `factors` steps as the reference GPU path does
-    (gpu/als.py:188-195);
+    (any factors <= 1024; the reference GPU path runs CG to `factors` steps there, gpu/als.py:188-195);
   * NaN factors after fit raise ModelFitError (cpu/als.py:202).
 
 Multi-GPU: `AlternatingLeastSquares(..., comm=implicit_amd.gpu.Comm(...))`, one process per GPU, every rank calling
@@ -35,7 +34,7 @@ from .matrix_factorization_base import MatrixFactorizationBase
 
 log = logging.getLogger("implicit_amd")
 
-_CHOLESKY_MAX_FACTORS = 256
+_CHOLESKY_MAX_FACTORS = 1024  # what the library's Cholesky takes (beyond 256: the triangle in a device workspace)
 
 
 class AlternatingLeastSquares(MatrixFactorizationBase):

@@ -196,6 +196,31 @@ def test_cholesky_sweep(gpu, oracle, f):
     assert err < TOL
 
 
+@pytest.mark.parametrize("f", [260, 320, 640, 1024])  # beyond the LDS: the triangle in a device workspace (the CPU reference takes any f)
+def test_cholesky_sweep_beyond_256_factors(gpu, oracle, f):
+    C, X0, Y0 = _problem(300, 400, 9_000, f)
+    C = C.tolil()
+    C[5] = 0                                          # an empty row: zeroed (_als.pyx:95-97)
+    C = C.tocsr()
+    C.eliminate_zeros()
+    want = X0.copy()
+    oracle.least_squares(C, want, Y0, 0.01)
+    solver = gpu.LeastSquaresSolver()
+    Xd, Yd = gpu.Matrix(X0), gpu.Matrix(Y0)
+    gram = gpu.Matrix.zeros(f, f)
+    solver.calculate_yty(Yd, gram, 0.0)
+    solver.least_squares_cholesky(gpu.CSRMatrix(C), Xd, gram, Yd, 0.01)
+    got = Xd.to_numpy()
+    err = rel(got, want)
+    print(f"f={f} cholesky (workspace kernel) rel={err:.2e}")
+    assert err < TOL
+    assert not got[5].any()
+    if f == 320:                                      # not positive definite -> ValueError naming the row, as below
+        with pytest.raises(ValueError):
+            solver.least_squares_cholesky(gpu.CSRMatrix(C), gpu.Matrix(X0), gpu.Matrix.zeros(f, f),
+                                          gpu.Matrix(np.zeros_like(Y0)), 0.0)
+
+
 def test_cholesky_not_positive_definite_raises(gpu):
     # zero factors + zero regularisation: the oracle raises ValueError (_als.pyx:136-138)
     C = sp.csr_matrix(np.ones((3, 4), dtype=np.float32))
