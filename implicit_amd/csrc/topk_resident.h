@@ -27,6 +27,23 @@ template <int N, int I = 0, typename Fn> __device__ __forceinline__ void rq_stat
     rq_static_for<N, I + 1>(fn);
   }
 }
+
+// A 16-byte LDS read the compiler does not track, and the counted wait that goes with it.  hipcc waits for its own LDS reads
+// with lgkmcnt(0) wherever the three-set fragment prefetch below needs one of them -- i.e. also for the reads it has JUST
+// issued for two k-steps ahead: a full LDS round trip exposed in front of the matrix pipe three times per item tile
+// (profiles/r06_topk_resident_knockouts.txt).  LDS operations of a wavefront return in order, so "all but the N newest" is exact.
+template <int OFFSET> __device__ __forceinline__ void rq_lds_read16(rq_f16x8 &dst, unsigned lds_addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "n"(OFFSET));
+}
+template <int N> __device__ __forceinline__ void rq_lds_wait(rq_f16x8 &x, rq_f16x8 &y) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x), "+v"(y) : "n"(N));
+}
+#ifndef RQ_AHEAD
+#define RQ_AHEAD 2  // k-steps of item fragments in flight ahead of the products (emit pass); 1 .. 4 measure the same (r06 knock-outs file)
+#endif
+#ifdef RQ_CLOCK  // variant builds: shader cycles and 100 MHz wall ticks one wavefront of the emit pass spends in its item loop
+__device__ unsigned long long rq_clock_dbg[4];
+#endif
 #ifndef RQ_KO
 #define RQ_KO 0  // timing-only knock-outs (build variants, wrong results): 1 no MFMAs, 2 no item DMA in the loop, 4 no epilogue, 8 no barrier, 16 tests but no survivor work
 #endif
@@ -285,6 +302,9 @@ __global__ __launch_bounds__(256, 2) void score_resident_kernel(ResidentArgs a) 
     // d + tau, an ulp or two off the threshold pass's value of the same dot product: a row whose k best all sit in the sampled
     // subset then finds k - 1 candidates -- measured: 6-13 rows per 1000 sent to the exact path.)  With item norms (cosine
     // scores) the finished score is what has to be compared: that form converts first and tests second.
+#ifdef RQ_CLOCK
+    const long long rq_c0 = __builtin_readcyclecounter(), rq_w0 = wall_clock64();
+#endif
     for (int s = 0; s < steps; ++s) {
       if (!(RQ_KO & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * PER_WAVE) : "memory");
       if (!(RQ_KO & 8)) __builtin_amdgcn_s_barrier();
@@ -298,28 +318,40 @@ __global__ __launch_bounds__(256, 2) void score_resident_kernel(ResidentArgs a) 
       // item fragments TWO k-steps ahead of the MFMAs that use them (three register sets): with the reads of k-step ks + 1 issued
       // only after the MFMAs of ks, an LDS round trip under load (eight wavefronts reading, the DMA writing) outlasted the 192
       // cycles those MFMAs cover, and the matrix pipe idled a third of the loop (SQ_VALU_MFMA_BUSY: 0.50 of the launch)
-      rq_f16x8 bh[3], bl[3];
-      auto ldb = [&](int ks, int set) {
-        bh[set] = *reinterpret_cast<const rq_f16x8 *>(slot + (ks * 2) * 1024 + lane * 16);
-        bl[set] = *reinterpret_cast<const rq_f16x8 *>(slot + (ks * 2 + 1) * 1024 + lane * 16);
+      constexpr int AHEAD = RQ_AHEAD, SETS = AHEAD + 1;  // fragment sets: k-steps in flight ahead of the products
+      rq_f16x8 bh[SETS], bl[SETS];
+      const unsigned slot_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char *)(slot + lane * 16);
+      auto ldb = [&](auto ks_c, auto set_c) {
+        constexpr int ks = decltype(ks_c)::value, set = decltype(set_c)::value;
+        if (RQ_KO & 32) {  // (timing only: no fragment reads)
+          asm volatile("" : "=v"(bh[set]), "=v"(bl[set]));
+          return;
+        }
+        rq_lds_read16<(ks * 2) * 1024>(bh[set], slot_lds);
+        rq_lds_read16<(ks * 2 + 1) * 1024>(bl[set], slot_lds);
       };
-      ldb(0, 0);
-      if constexpr (KS > 1) ldb(1, 1);
+      using std::integral_constant;
+      rq_static_for<(AHEAD < KS ? AHEAD : KS)>([&](auto Pc) {
+        constexpr int p = decltype(Pc)::value;
+        ldb(integral_constant<int, p>{}, integral_constant<int, p % SETS>{});
+      });
       __builtin_amdgcn_sched_barrier(0);
       rq_static_for<KS>([&](auto Kc) {
         constexpr int ks = decltype(Kc)::value;
-        if constexpr (ks + 2 < KS) ldb(ks + 2, (ks + 2) % 3);
+        if constexpr (ks + AHEAD < KS) ldb(integral_constant<int, ks + AHEAD>{}, integral_constant<int, (ks + AHEAD) % SETS>{});
+        // the reads of k-step ks have returned when at most those of the (up to AHEAD) later k-steps are outstanding
+        rq_lds_wait<2 * (KS - 1 - ks < AHEAD ? KS - 1 - ks : AHEAD)>(bh[ks % SETS], bl[ks % SETS]);
         __builtin_amdgcn_sched_barrier(0);  // (left alone, the scheduler sinks every read to just before its first use)
         if (RQ_KO & 1) {
 #pragma unroll
-          for (int tq = 0; tq < TQ; ++tq) asm volatile("" ::"v"(bh[ks % 3]), "v"(bl[ks % 3]), "v"(ah[tq][ks]), "v"(al[tq][ks]));
+          for (int tq = 0; tq < TQ; ++tq) asm volatile("" ::"v"(bh[ks % SETS]), "v"(bl[ks % SETS]), "v"(ah[tq][ks]), "v"(al[tq][ks]));
         } else {  // the query tiles' chains in turn: a dependent MFMA directly behind its predecessor waits for the result
 #pragma unroll
-          for (int tq = 0; tq < TQ; ++tq) acc[tq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tq][ks], bh[ks % 3], acc[tq], 0, 0, 0);
+          for (int tq = 0; tq < TQ; ++tq) acc[tq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tq][ks], bh[ks % SETS], acc[tq], 0, 0, 0);
 #pragma unroll
-          for (int tq = 0; tq < TQ; ++tq) acc[tq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tq][ks], bl[ks % 3], acc[tq], 0, 0, 0);
+          for (int tq = 0; tq < TQ; ++tq) acc[tq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tq][ks], bl[ks % SETS], acc[tq], 0, 0, 0);
 #pragma unroll
-          for (int tq = 0; tq < TQ; ++tq) acc[tq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tq][ks], bh[ks % 3], acc[tq], 0, 0, 0);
+          for (int tq = 0; tq < TQ; ++tq) acc[tq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tq][ks], bh[ks % SETS], acc[tq], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       });
@@ -376,6 +408,12 @@ __global__ __launch_bounds__(256, 2) void score_resident_kernel(ResidentArgs a) 
         }
       }
     }
+#ifdef RQ_CLOCK
+    if (blockIdx.x == 17 && threadIdx.x == 0) {
+      rq_clock_dbg[0] = (unsigned long long)(__builtin_readcyclecounter() - rq_c0), rq_clock_dbg[1] = (unsigned long long)(wall_clock64() - rq_w0);
+      rq_clock_dbg[2] = (unsigned long long)steps;
+    }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stagings past the end
     __syncthreads();
     const unsigned n_all = st_n, n_st = min(n_all, (unsigned)kRqStageCap);
@@ -518,6 +556,15 @@ template <int MODE> static void launch_score_resident(int KS, ResidentArgs a, in
     IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     kern<<<a.chunks * a.n_qb, 256, lds, stream()>>>(a);
     IMP_CHECK_HIP(hipGetLastError());
+#ifdef RQ_CLOCK
+    if (MODE == 2) {
+      unsigned long long h[4] = {0, 0, 0, 0};
+      IMP_CHECK_HIP(hipStreamSynchronize(stream()));
+      IMP_CHECK_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(rq_clock_dbg), sizeof(h)));
+      if (h[1]) fprintf(stderr, "[rq-clock] item loop of one wavefront: %llu shader cycles in %.2f us = %.0f MHz, %llu steps, %.0f cycles per step\n",
+                        h[0], h[1] / 100.0, h[0] / (h[1] / 100.0), h[2], (double)h[0] / (double)std::max<unsigned long long>(1, h[2]));
+    }
+#endif
   };
   using std::integral_constant;
   constexpr int TQ12 = MODE == 0 ? 1 : 2;
