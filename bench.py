@@ -345,6 +345,14 @@ def main():
     for _ in range(3):
         raw_step()
         clock_mhz.append(round(gpu.core_clock_mhz(50), 1))
+    # ... and the clock DURING the steps: the probe on a side stream beside six queued steps (still deferred mode)
+    clock_beside = []
+    for _ in range(3):
+        for _ in range(6):
+            raw_step()
+        time.sleep(0.004)
+        clock_beside.append(round(gpu.core_clock_mhz(-1500), 1))
+        gpu.synchronize()
     gpu.set_deferred_sync(False)
 
     # ---- roofline: the WHOLE step (every row class of both half sweeps), per-class table as an extra ---------------
@@ -421,7 +429,7 @@ def main():
         "kernels_ms_per_step": {k: v["total_ms"] / detail_steps for k, v in kernels.items()},
         "kernels_note": f"per-kernel HIP-event times from {detail_steps} extra iterations after the timed region",
         "setup_s": {"generate": t_gen, "upload": t_upload},
-        "core_clock_mhz": {"behind_a_step": clock_mhz, "before_warmup": clock_idle,
+        "core_clock_mhz": {"behind_a_step": clock_mhz, "beside_queued_steps": clock_beside, "before_warmup": clock_idle,
                            "note": "imp_debug_core_clock: core cycles over 50 us of the constant-rate wall clock, one wavefront "
                                    "queued behind the work named"},
     }

@@ -381,12 +381,18 @@ int imp_debug_core_clock(int microseconds, double *mhz) {
     int rate_khz = 100000;
     IMP_CHECK_HIP(hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, c.device));
     DeviceArray<unsigned long long> out;
-    out.alloc(2, true);
-    core_clock_kernel<<<1, 64, 0, stream()>>>((long long)std::max(1, microseconds) * rate_khz / 1000, out.data());
+    out.alloc(2, microseconds >= 0);  // (beside: no fill -- it would be queued BEHIND the work on the library stream; the probe writes both words)
+    // microseconds < 0: the probe runs on the side stream BESIDE whatever is queued on the library stream (deferred mode: the
+    // clock the kernels of a queued step run at, not the clock the chip recovers to behind them)
+    const bool beside = microseconds < 0;
+    if (beside && !c.occupy_stream) IMP_CHECK_HIP(hipStreamCreateWithFlags(&c.occupy_stream, hipStreamNonBlocking));
+    hipStream_t st = beside ? c.occupy_stream : stream();
+    core_clock_kernel<<<1, 64, 0, st>>>((long long)std::max(1, std::abs(microseconds)) * rate_khz / 1000, out.data());
     IMP_CHECK_HIP(hipGetLastError());
     unsigned long long h[2] = {0, 0};
-    IMP_CHECK_HIP(hipMemcpyAsync(h, out.data(), sizeof(h), hipMemcpyDeviceToHost, stream()));
-    sync();
+    IMP_CHECK_HIP(hipMemcpyAsync(h, out.data(), sizeof(h), hipMemcpyDeviceToHost, st));
+    if (beside) IMP_CHECK_HIP(hipStreamSynchronize(st));
+    else sync();
     *mhz = h[1] ? (double)h[0] / ((double)h[1] / rate_khz * 1e3) : 0.0;  // cycles per microsecond
   });
 }

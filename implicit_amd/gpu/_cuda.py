@@ -477,7 +477,8 @@ def debug_occupy(workgroups, microseconds):
 
 
 def core_clock_mhz(microseconds=50):
-    """Measurement aid: the shader core clock (MHz) seen by a probe kernel queued behind the work already on the stream."""
+    """Measurement aid: the shader core clock (MHz) seen by a probe kernel queued behind the work already on the stream;
+    microseconds < 0: by a probe running BESIDE the work queued in deferred mode (the clock those kernels run at)."""
     mhz = ctypes.c_double(0.0)
     check(lib().imp_debug_core_clock(int(microseconds), ctypes.byref(mhz)))
     return mhz.value

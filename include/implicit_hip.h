@@ -67,7 +67,9 @@ int imp_set_deferred_sync(int on);
 /* Measurement aid: occupies `workgroups` x (256 threads, 32 KB LDS) for about `microseconds` on a stream of its own. */
 int imp_debug_occupy(int workgroups, int microseconds);
 /* Measurement aid: the shader core clock right now, in MHz -- a one-wavefront kernel queued on the library stream counts core
- * cycles over `microseconds` of the constant-rate wall clock (behind whatever is queued: the clock the preceding work ran at). */
+ * cycles over `microseconds` of the constant-rate wall clock (behind whatever is queued: the clock the chip has recovered to).
+ * microseconds < 0: the probe runs on a side stream BESIDE the work queued on the library stream (deferred mode) -- the clock
+ * the queued kernels themselves run at (a power-limited chip clocks an MFMA-heavy kernel well below its idle clock). */
 int imp_debug_core_clock(int microseconds, double *mhz);
 int imp_device_synchronize(void);
 /* NEW.  Rows of CG sweeps on the CURRENT device that a fast kernel declined to store and the fp32 one-wavefront-per-row fix-up
