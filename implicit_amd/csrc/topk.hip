@@ -282,6 +282,7 @@ struct EmitArgs {
   unsigned int *count;        // [nq]
   int cap;
   float *row_unscale;         // [nq] resident form: the keys carry raw accumulators; factor that turns a row's into scores (else null)
+  float *row_eps;             // [nq] screened emit pass (MODE 3): the error bound of the row's one-product accumulators (else null)
 };
 
 // TQ / TI: storage type of the query / item factors (float or __half).  fp16 factors are read as they are stored and
@@ -1045,6 +1046,117 @@ __global__ __launch_bounds__(BLOCK) void select_candidates_kernel(const uint64_t
   write_best_k<BLOCK>(cand, n_c, k, q, out_ids, out_dist, out_stride, fallback, unscale_q);
 }
 
+// Candidates of the SCREENED emit pass (topk_resident.h MODE 3): the keys carry one-product accumulators, each within eps_q of the
+// row's scaled exact score.  Sort by them; with A_k the k-th largest, every entry whose exact score reaches the k-th EXACT score
+// has an accumulator >= A_k - 2 eps_q (k entries have exact scores >= A_k - eps_q, so the k-th exact score is at least that; an
+// entry that reaches it lies at most eps_q below in the approximate order).  Those R entries -- k plus a handful -- are re-scored
+// from the stored factors in fp32 (one wavefront per entry, the reference's own arithmetic: an fp32 dot product of the row and
+// the item, implicit/gpu/knn.cu:131-147 / cpu/topk.pyx:45-47), ordered by (score desc, column desc) and written with the heap's
+// tie rule.  More than kScreenCap of them (eps_q is a worst-case bound: tiny queries against a catalogue with huge outliers) or a
+// non-finite score: the row goes to the exact path.
+constexpr int kScreenCap = 1024;
+#ifdef RQ_SCREEN_STATS  // variant builds: rows, candidates, re-scored entries of the screened select
+__device__ unsigned long long rq_screen_stats[4];
+#endif
+template <int BLOCK, typename TQs, typename TIs>
+__global__ __launch_bounds__(BLOCK) void select_screened_kernel(const uint64_t *__restrict__ gcand, const unsigned int *__restrict__ count,
+                                                                int cap, int k, int32_t *__restrict__ out_ids, float *__restrict__ out_dist,
+                                                                int out_stride, int *__restrict__ fallback, const float *__restrict__ row_eps,
+                                                                const TQs *__restrict__ Q, const TIs *__restrict__ I, int f) {
+  __shared__ uint64_t cand[kEmitCap];
+  __shared__ unsigned int sh_r;
+  const int tid = threadIdx.x, q = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned int n_c = count[q];
+  if (n_c > (unsigned)cap || n_c < (unsigned)k) {  // uniform
+    if (tid == 0) fallback[q] = 1;
+    return;
+  }
+  int npad = 2;
+  while (npad < (int)n_c) npad <<= 1;
+  for (int i = tid; i < npad; i += BLOCK) cand[i] = i < (int)n_c ? gcand[(size_t)q * cap + i] : 0;  // pads sort last
+  if (tid == 0) sh_r = 0;
+  __syncthreads();
+  auto sort_desc = [&](int n2) {
+    for (int size = 2; size <= n2; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int t = tid; t < (n2 >> 1); t += BLOCK) {
+          int lo = 2 * t - (t & (stride - 1));
+          int hi = lo + stride;
+          bool desc = ((lo & size) == 0);
+          uint64_t a = cand[lo], b = cand[hi];
+          if ((a < b) == desc) {
+            cand[lo] = b;
+            cand[hi] = a;
+          }
+        }
+        __syncthreads();
+      }
+    }
+  };
+  sort_desc(npad);
+  const float eps = row_eps[q];
+  const float a_k = unordered((uint32_t)(cand[k - 1] >> 32));
+  const float cut = a_k - 2.f * eps;
+  if (!(eps >= 0.f) || !(eps <= FLT_MAX) || !(a_k == a_k) || (uint32_t)(cand[0] >> 32) >= 0xFF800000u) {  // (uniform) NaN / inf somewhere
+    if (tid == 0) fallback[q] = 1;
+    return;
+  }
+  // R = entries with an accumulator >= cut: a prefix of the sorted list
+  for (int i = tid; i < (int)n_c; i += BLOCK)
+    if (unordered((uint32_t)(cand[i] >> 32)) >= cut) atomicMax(&sh_r, (unsigned)i + 1u);
+  __syncthreads();
+  const int n_r = (int)sh_r;
+#ifdef RQ_SCREEN_STATS
+  if (tid == 0) atomicAdd(&rq_screen_stats[0], 1ull), atomicAdd(&rq_screen_stats[1], (unsigned long long)n_c), atomicAdd(&rq_screen_stats[2], (unsigned long long)n_r);
+#endif
+  if (n_r > kScreenCap) {  // uniform
+    if (tid == 0) fallback[q] = 1;
+    return;
+  }
+  // exact scores of the R entries: sixteen lanes per entry (32 entries of a row in flight: a few rows re-score a hundred), four
+  // consecutive factors per lane and trip, fixed-order sum over the group
+  const TQs *qrow = Q + (size_t)q * f;
+  bool bad = false;
+#ifdef RQ_SCREEN_KO
+  if (RQ_SCREEN_KO & 1) goto skip_rescoring;  // (timing only)
+#endif
+  {
+    const int g = tid & 15;
+    for (int i = tid >> 4; i < n_r; i += BLOCK / 16) {
+      const int item = (int)(uint32_t)cand[i];
+      const TIs *irow = I + (size_t)item * f;
+      float sum = 0.f;
+      for (int c = 4 * g; c < f; c += 64) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (c + e < f) sum = fmaf((float)qrow[c + e], (float)irow[c + e], sum);
+      }
+      sum += __shfl_xor(sum, 8, 64), sum += __shfl_xor(sum, 4, 64), sum += __shfl_xor(sum, 2, 64), sum += __shfl_xor(sum, 1, 64);
+      if (!(fabsf(sum) <= FLT_MAX)) bad = true;
+      if (g == 0) cand[i] = make_key(sum, item);
+    }
+  }
+#ifdef RQ_SCREEN_KO
+skip_rescoring:
+#endif
+  if (__syncthreads_or(bad)) {
+    if (tid == 0) fallback[q] = 1;
+    return;
+  }
+#ifdef RQ_SCREEN_KO
+  if (RQ_SCREEN_KO & 2) {  // (timing only: no second sort / write)
+    if (tid == 0) fallback[q] = 0;
+    return;
+  }
+#endif
+  int rpad = 2;
+  while (rpad < n_r) rpad <<= 1;
+  for (int i = n_r + tid; i < rpad; i += BLOCK) cand[i] = 0;  // (the slots behind R: no longer needed)
+  __syncthreads();
+  sort_desc(rpad);
+  write_best_k<BLOCK>(cand, (unsigned)n_r, k, q, out_ids, out_dist, out_stride, fallback, 1.f);
+}
+
 // factor counts that are not a multiple of 16 (the reference's CPU default is 100): rows zero-padded to the next multiple, fp16
 // converted on the way -- extra zero factors change no dot product, and the scores come from the direct-operand kernels
 template <typename T>
@@ -1139,6 +1251,7 @@ struct imp_knn {
     DeviceArray<_Float16> planes;
     DeviceArray<int> exp;          // scale exponent of the item matrix (from its exact maximum)
     DeviceArray<unsigned> maxbits;
+    DeviceArray<unsigned> ne;      // bits of max || y 2^e ||_2 and max || y 2^e - high plane ||_2 (screened emit pass)
     size_t rows = 0, cols = 0, itemsize = 0;
     int KS = 0;
     ItemPlanes() { register_derived_cache(&key); }
@@ -1146,6 +1259,8 @@ struct imp_knn {
   } item_planes;
   DeviceArray<_Float16> query_planes;
   DeviceArray<int> query_exp;
+  DeviceArray<float> query_err;    // [2][rows]: || q 2^e - high plane ||, || high plane || per query row of the call
+  DeviceArray<float> row_eps;
   DeviceArray<float> row_unscale;  // per row of an emit batch: what turns the raw accumulators its candidate keys carry into scores
   DeviceArray<uint32_t> tau, row_bits, item_bits;
   DeviceArray<unsigned int> cand_count;
@@ -1324,6 +1439,8 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
       constexpr bool BF3 = decltype(Bf3c)::value;
     // fp16 two-term planes for the resident-query kernels (topk_resident.h): the item matrix once per catalogue version (cached in
     // the handle), the query rows of this call with one scale per row
+    const float *q_err_a = nullptr, *q_err_b = nullptr;
+    const unsigned *item_ne = nullptr;
     auto prepare_planes = [&](int KS, const _Float16 *&iplanes, const int *&iexp, const _Float16 *&qplanes, const int *&qexp) {
         IMP_PROF("split_query_rows");
         auto &ip = knn->item_planes;
@@ -1332,13 +1449,16 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
         if (!same) {
           ip.key.src = nullptr;
           if (ip.planes.size < ni_pad * F * 2) ip.planes.alloc(ni_pad * F * 2);
-          if (ip.exp.size < 1) ip.exp.alloc(1), ip.maxbits.alloc(1);
+          if (ip.exp.size < 1) ip.exp.alloc(1), ip.maxbits.alloc(1), ip.ne.alloc(2);
           IMP_CHECK_HIP(hipMemsetAsync(ip.maxbits.data(), 0, sizeof(unsigned), stream()));
+          IMP_CHECK_HIP(hipMemsetAsync(ip.ne.data(), 0, 2 * sizeof(unsigned), stream()));
           const int g1 = (int)std::max<size_t>(1, std::min<size_t>((ni * (size_t)f + 255) / 256, (size_t)ctx().num_cus * 8));
           rq_absmax_kernel<TI><<<g1, 256, 0, stream()>>>(Ib, ni * (size_t)f, ip.maxbits.data());
           rq_item_exp_kernel<<<1, 1, 0, stream()>>>(ip.maxbits.data(), ip.exp.data());
           const int g2 = (int)std::max<size_t>(1, std::min<size_t>((ni_pad * (F / 8) + 255) / 256, (size_t)ctx().num_cus * 16));
           rq_split_items_kernel<TI><<<g2, 256, 0, stream()>>>(Ib, ip.planes.data(), ni, ni_pad, f, KS, ip.exp.data());
+          rq_item_err_kernel<TI><<<(int)std::min<size_t>((ni + 3) / 4, (size_t)ctx().num_cus * 16), 256, 0, stream()>>>(Ib, ni, f, ip.exp.data(),
+                                                                                                                    ip.ne.data());
           ip.rows = ni, ip.cols = (size_t)f_in, ip.itemsize = items_in->itemsize, ip.KS = KS;
           const bool trusted = items_in->storage && items_in->storage->owned && !items_in->storage->exposed;
           if (trusted) ip.key.src = items_in->data, ip.key.bytes = items_in->bytes();
@@ -1347,9 +1467,12 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
         const size_t nq_pad = rq_query_pad(nq);
         _Float16 *qp = imp_knn::ensure(knn->query_planes, nq_pad * F * 2);
         int *qe = imp_knn::ensure(knn->query_exp, nq_pad);
-        rq_split_queries_kernel<TQ><<<(int)std::min<size_t>((nq_pad + 3) / 4, (size_t)ctx().num_cus * 8), 256, 0, stream()>>>(Qb, qp, qe, nq, nq_pad, f, KS);
+        float *qerr = imp_knn::ensure(knn->query_err, 2 * nq_pad);
+        rq_split_queries_kernel<TQ><<<(int)std::min<size_t>((nq_pad + 3) / 4, (size_t)ctx().num_cus * 8), 256, 0, stream()>>>(Qb, qp, qe, nq, nq_pad, f, KS,
+                                                                                                                             qerr, qerr + nq_pad);
         IMP_CHECK_HIP(hipGetLastError());
         qplanes = qp, qexp = qe;
+        q_err_a = qerr, q_err_b = qerr + nq_pad, item_ne = ip.ne.data();
     };
     static const bool resident_env = !(getenv("IMP_TOPK_RESIDENT") && atoi(getenv("IMP_TOPK_RESIDENT")) == 0);
     constexpr bool bf16x3 = false;
@@ -1408,20 +1531,30 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
             ra.nq = rows, ra.ni = (int)ni, ra.norms = norms_p;
             ra.n_blocks = (int)grid.x, ra.block_stride = bstride;
             ra.S = S_out, ra.sub_cols = (int)grid.x * 128, ra.emit = ea;
+            ra.qa = q_err_a ? q_err_a + start : nullptr, ra.qb = q_err_b ? q_err_b + start : nullptr, ra.ine = item_ne;
             launch_score_resident<M>(KS, ra, rows);
             return;
           }
         }
-        if constexpr (kCanSplit) {
-          if (qsplit) {
-            score_gemm_direct_kernel<M, split_bf16, TI, true><<<grid, 256, 0, stream()>>>(qs + start * 3 * (size_t)f, rows, Ib, (int)ni, f, norms_p,
-                                                                                    S_out, nullptr, 0, bstride, ea);
-            return;
+        if constexpr (M == 3) {
+          throw std::logic_error("the screened emit pass exists in the resident form only");
+        } else {
+          if constexpr (kCanSplit) {
+            if (qsplit) {
+              score_gemm_direct_kernel<M, split_bf16, TI, true><<<grid, 256, 0, stream()>>>(qs + start * 3 * (size_t)f, rows, Ib, (int)ni, f, norms_p,
+                                                                                      S_out, nullptr, 0, bstride, ea);
+              return;
+            }
           }
+          score_gemm_direct_kernel<M, TQ, TI, BF3><<<grid, 256, 0, stream()>>>(Qb + start * f, rows, Ib, (int)ni, f, norms_p, S_out, nullptr, 0,
+                                                                              bstride, ea);
         }
-        score_gemm_direct_kernel<M, TQ, TI, BF3><<<grid, 256, 0, stream()>>>(Qb + start * f, rows, Ib, (int)ni, f, norms_p, S_out, nullptr, 0,
-                                                                            bstride, ea);
       };
+      // screened emit pass (topk_resident.h MODE 3): one-product scores against tau - eps, the few candidates that can still be among
+      // the best k re-scored in fp32 by the select kernel.  Dot-product scores only (no item norms); IMP_TOPK_SCREEN=0: three products
+      static const bool screen_env = !(getenv("IMP_TOPK_SCREEN") && atoi(getenv("IMP_TOPK_SCREEN")) == 0);
+      const bool screen = resident && screen_env && !item_norms;
+      float *row_eps = screen ? imp_knn::ensure(knn->row_eps, rq_query_pad(ebatch)) : nullptr;
       for (size_t start = 0; start < nq; start += ebatch) {
         const size_t end = std::min(nq, start + ebatch), rows = end - start;
         const auto *qptr = Qb + start * f;
@@ -1456,15 +1589,29 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
         }
         {
           IMP_PROF("score_gemm");
-          EmitArgs ea{tau, row_bits, item_bits, words, cand, cnt, kEmitCap, resident ? row_unscale : nullptr};
-          gemm(std::integral_constant<int, 2>{}, start, dim3((unsigned)n_blocks, qblocks), (int)rows, nullptr, 1, ea);
+          EmitArgs ea{tau, row_bits, item_bits, words, cand, cnt, kEmitCap, resident ? row_unscale : nullptr, row_eps};
+          if (screen) gemm(std::integral_constant<int, 3>{}, start, dim3((unsigned)n_blocks, qblocks), (int)rows, nullptr, 1, ea);
+          else gemm(std::integral_constant<int, 2>{}, start, dim3((unsigned)n_blocks, qblocks), (int)rows, nullptr, 1, ea);
           IMP_CHECK_HIP(hipGetLastError());
         }
         {
           IMP_PROF("topk_select_candidates");
-          select_candidates_kernel<512><<<(unsigned)rows, 512, 0, stream()>>>(cand, cnt, kEmitCap, k_eff, d_ids + start * k,
-                                                                             d_dist + start * k, k, fallback_e, resident ? row_unscale : nullptr);
+          if (screen)
+            select_screened_kernel<512, TQ, TI><<<(unsigned)rows, 512, 0, stream()>>>(cand, cnt, kEmitCap, k_eff, d_ids + start * k, d_dist + start * k, k,
+                                                                                     fallback_e, row_eps, Qb + start * f, Ib, f);
+          else
+            select_candidates_kernel<512><<<(unsigned)rows, 512, 0, stream()>>>(cand, cnt, kEmitCap, k_eff, d_ids + start * k,
+                                                                               d_dist + start * k, k, fallback_e, resident ? row_unscale : nullptr);
           IMP_CHECK_HIP(hipGetLastError());
+#ifdef RQ_SCREEN_STATS
+          if (screen) {
+            unsigned long long h[4];
+            IMP_CHECK_HIP(hipStreamSynchronize(stream()));
+            IMP_CHECK_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(rq_screen_stats), sizeof(h)));
+            fprintf(stderr, "[screen-stats] rows %llu, candidates per row %.1f, re-scored per row %.1f\n", h[0], (double)h[1] / std::max(1ull, h[0]),
+                    (double)h[2] / std::max(1ull, h[0]));
+          }
+#endif
         }
         sync();
         fb_list.clear();

@@ -64,6 +64,31 @@ template <typename T> __global__ __launch_bounds__(256) void rq_absmax_kernel(co
 // exp_out[0] = the scale exponent of the item matrix, from its exact maximum
 __global__ void rq_item_exp_kernel(const unsigned *__restrict__ maxbits, int *__restrict__ exp_out) { exp_out[0] = rq_scale_exp(maxbits[0]); }
 
+// ne[0] / ne[1] = bits of max_i || y_i 2^e ||_2 and of max_i || y_i 2^e - its high plane ||_2 (non-negative floats: unsigned order);
+// one wavefront per item row; zeroed by the caller.  Once per catalogue version, with the planes.
+template <typename T>
+__global__ __launch_bounds__(256) void rq_item_err_kernel(const T *__restrict__ I, size_t rows, int f, const int *__restrict__ exp_in,
+                                                          unsigned *__restrict__ ne) {
+  const float s = rq_pow2(exp_in[0]);
+  const int lane = threadIdx.x & 63;
+  float mn = 0.f, me = 0.f;
+  for (size_t row = blockIdx.x * (size_t)(blockDim.x >> 6) + (threadIdx.x >> 6); row < rows; row += (size_t)gridDim.x * (blockDim.x >> 6)) {
+    float n2 = 0.f, e2 = 0.f;
+    for (int c = lane; c < f; c += 64) {
+      const float x = (float)I[row * (size_t)f + c] * s;
+      const float d = x - (float)(_Float16)x;
+      n2 = fmaf(x, x, n2), e2 = fmaf(d, d, e2);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) n2 += __shfl_xor(n2, off, 64), e2 += __shfl_xor(e2, off, 64);
+    mn = fmaxf(mn, n2), me = fmaxf(me, e2);
+  }
+  if (lane == 0) {
+    atomicMax(&ne[0], __float_as_uint(sqrtf(mn)));
+    atomicMax(&ne[1], __float_as_uint(sqrtf(me)));
+  }
+}
+
 // Fragment order (A and B operand of v_mfma_f32_32x32x16_f16 alike): element (row, c) of a 32-row tile goes to
 //   ((tile KS + c / 16) 2 + term) 512 + lane 8 + (c & 7),   lane = (row & 31) + 32 ((c >> 3) & 1)
 // -- lane (r, kh) of k-step s holds factors 16 s + 8 kh .. + 7 of row r.  Rows / factors past the matrix are zero.
@@ -92,9 +117,12 @@ __global__ __launch_bounds__(256) void rq_split_items_kernel(const T *__restrict
 }
 
 // Query rows: ONE wavefront per row -- row maximum, its own scale exponent (qexp[row]), the two planes in fragment order.
+// qa / qb (may be null): || q 2^e - high plane ||_2 and || high plane ||_2 of the row -- what the screened emit pass (MODE 3) bounds
+// the error of its one-product scores with.
 template <typename T>
 __global__ __launch_bounds__(256) void rq_split_queries_kernel(const T *__restrict__ Q, _Float16 *__restrict__ out, int *__restrict__ qexp,
-                                                               size_t rows, size_t rows_pad, int f, int KS) {
+                                                               size_t rows, size_t rows_pad, int f, int KS, float *__restrict__ qa,
+                                                               float *__restrict__ qb) {
   const int lane = threadIdx.x & 63;
   const int F = KS * 16;
   for (size_t row = blockIdx.x * (size_t)(blockDim.x >> 6) + (threadIdx.x >> 6); row < rows_pad; row += (size_t)gridDim.x * (blockDim.x >> 6)) {
@@ -106,14 +134,28 @@ __global__ __launch_bounds__(256) void rq_split_queries_kernel(const T *__restri
     const int e = rq_scale_exp(__float_as_uint(m));  // (a NaN / inf row: clamped; its scores come out NaN and the row goes to the exact path)
     if (lane == 0) qexp[row] = e;
     const float s = rq_pow2(e);
+    float ea = 0.f, eb = 0.f;
     for (int c = lane; c < F; c += 64) {
       const float x = (row < rows && c < f) ? (float)Q[row * (size_t)f + c] * s : 0.f;
       const _Float16 hi = (_Float16)x;
       const int ln = (int)(row & 31) + 32 * ((c >> 3) & 1);
       _Float16 *o = out + ((((row >> 5) * KS + (c >> 4)) * 2) * 64 + ln) * 8 + (c & 7);
       o[0] = hi, o[512] = (_Float16)(x - (float)hi);
+      const float d = x - (float)hi;
+      ea = fmaf(d, d, ea), eb = fmaf((float)hi, (float)hi, eb);
+    }
+    if (qa) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) ea += __shfl_xor(ea, off, 64), eb += __shfl_xor(eb, off, 64);
+      if (lane == 0) qa[row] = sqrtf(ea), qb[row] = sqrtf(eb);
     }
   }
+}
+
+// MODE 3: bound of |q.y - q_h.y_h| in the scaled domain (see the kernel's header), with slack for the fp32 accumulation of the
+// products (exact themselves: 11 x 11 bits), for the rounding of the four norms and for the threshold's own arithmetic
+__device__ __forceinline__ float rq_screen_eps(float qa, float qb, float N, float E) {
+  return (qa * N + qb * E) * 1.00390625f + qb * N * 3.814697265625e-6f;  // (1 + 2^-8), 2^-18
 }
 
 // a candidate that passed its threshold: filter bitmaps (the batch's item filter, the query's liked items), then the query's list
@@ -141,20 +183,30 @@ struct ResidentArgs {
   int sub_cols;
   float *tile_max;         // MODE 0: [nq][n_tiles64]
   int n_tiles64;
-  EmitArgs emit;           // MODE 2
+  EmitArgs emit;           // MODE 2 / 3
+  const float *qa, *qb;    // MODE 3: per query row || q 2^e - high plane ||, || high plane ||
+  const unsigned *ine;     // MODE 3: bits of max || y 2^e ||, max || y 2^e - high plane || over the catalogue
 };
 
 // LDS slots of the item ring: as many as leave room for two workgroups per CU (the emit pass also stages its candidates in LDS)
 template <int KS, int MODE> constexpr int rq_stages() {
   constexpr int NI = 1;
   constexpr int SLOT = NI * KS * 2048 + 4 * 256 * NI;
-  constexpr int budget = MODE == 2 ? 56 * 1024 : 72 * 1024;
+  constexpr int budget = MODE >= 2 ? 56 * 1024 : 72 * 1024;
   return 4 * SLOT <= budget ? 4 : (3 * SLOT <= budget ? 3 : 2);
 }
 constexpr int kRqStageCap = 1536;  // candidates a workgroup of the emit pass stages in LDS before its one flush
 
 // MODE 0: scores + per-(query, 64-item) maxima (materialising path)   TQ = 1
 // MODE 1: compact subset scores (threshold pre-pass)                  MODE 2: candidates >= tau appended (emit pass)
+// MODE 3: the SCREENED emit pass (no item norms).  The emit pass only has to FIND the entries that may reach the threshold, so it
+// scores with ONE product -- high plane x high plane, a third of the matrix work and half the LDS / DMA bytes -- and tests against
+// tau - eps_q, eps_q = a_q N + b_q E a rigorous bound of |q.y - q_h.y_h| (Cauchy-Schwarz: a_q = ||q - q_h||, b_q = ||q_h||,
+// N = max ||y||, E = max ||y - y_h||; + slack for the fp32 accumulation and for tau's own rounding).  Candidates carry the
+// APPROXIMATE accumulator; select_screened_kernel re-scores the few that can still be among the best k from the stored factors
+// in fp32 (entries within 2 eps_q of the k-th approximate score -- every entry whose exact score reaches the k-th exact score is
+// among them) and orders those.  The matrix pipe was 84 % busy at a power-limited 1.67 GHz with three products
+// (profiles/r06_topk_resident_knockouts.txt): fewer products is the lever that is left.
 template <int KS, int TQ, int MODE>
 __global__ __launch_bounds__(256, 2) void score_resident_kernel(ResidentArgs a) {
   constexpr int NI = 1;                                    // 32-item tiles per pipeline step
@@ -166,7 +218,9 @@ __global__ __launch_bounds__(256, 2) void score_resident_kernel(ResidentArgs a) 
   constexpr int NSTAGE = rq_stages<KS, MODE>();
   constexpr int PIECES = STEP_BYTES / 1024;                // 1 KB DMA instructions per step
   static_assert(PIECES % 4 == 0 || PIECES == 2, "pieces are dealt to the four wavefronts");
-  constexpr int PER_WAVE_DATA = PIECES >= 4 ? PIECES / 4 : 1;  // (KS = 1 is not instantiated; PIECES = 2 x KS x NI >= 4)
+  // (KS = 1 is not instantiated; PIECES = 2 x KS x NI >= 4.)  MODE 3 stages the high-plane pieces only (the even ones); with fewer
+  // of them than wavefronts (KS = 2) the spare wavefronts repeat a piece, so every wavefront issues the same number of loads
+  constexpr int PER_WAVE_DATA = (MODE == 3) ? (PIECES / 2 >= 4 ? PIECES / 8 : 1) : (PIECES >= 4 ? PIECES / 4 : 1);
   constexpr int PER_WAVE = PER_WAVE_DATA + NI;             // + the norms piece(s)
   constexpr int QROWS = 128 * TQ;
   extern __shared__ __attribute__((aligned(1024))) unsigned char rq_smem[];
@@ -179,10 +233,11 @@ __global__ __launch_bounds__(256, 2) void score_resident_kernel(ResidentArgs a) 
   // round trip -- the filter bitmaps, the atomic on the query's list, the store -- happens once, at the end, for all staged
   // entries in parallel.  About stride x k entries per query survive the threshold, i.e. two per wavefront and step: inline, the
   // three dependent round trips (~4 us) behind every one of them were six times the step's matrix time (0.64 us).
-  __shared__ unsigned long long st_key[MODE == 2 ? kRqStageCap : 1];
-  __shared__ unsigned short st_row[MODE == 2 ? kRqStageCap : 1];
+  constexpr bool EMIT = MODE >= 2, ONE = MODE == 3;  // ONE: one product (high planes only)
+  __shared__ unsigned long long st_key[EMIT ? kRqStageCap : 1];
+  __shared__ unsigned short st_row[EMIT ? kRqStageCap : 1];
   __shared__ unsigned st_n;
-  if (MODE == 2 && threadIdx.x == 0) st_n = 0u;
+  if (EMIT && threadIdx.x == 0) st_n = 0u;
 
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c31 = lane & 31, kh = lane >> 5;
@@ -194,11 +249,11 @@ __global__ __launch_bounds__(256, 2) void score_resident_kernel(ResidentArgs a) 
   // (measured on the bench's trained factors: its LDS staging overflowed and every row of its query block went to the exact path)
   // The emit pass deals single 32-item TILES (t = c, c + chunks, ...): what it stages before filtering includes the users' liked
   // items, and on such a catalogue a tenth of all interactions sit in the first two 128-item blocks.
-  constexpr int GRAIN = MODE == 2 ? 1 : 4;  // tiles per dealt unit
+  constexpr int GRAIN = EMIT ? 1 : 4;  // tiles per dealt unit
   const int n_units = a.n_blocks * (4 / GRAIN);
   const int my_units = chunk < n_units ? (n_units - chunk + a.chunks - 1) / a.chunks : 0;
   const int steps = my_units * GRAIN;
-  if constexpr (MODE == 2) {
+  if constexpr (EMIT) {
     // candidates travel with their RAW accumulator as the key's score (one scale per query row: the order is the scores'); the
     // select kernel scales the k winners out.  The first workgroup of a query block leaves the factors for it (even when its own
     // item range is empty: more chunks than item blocks)
@@ -207,6 +262,15 @@ __global__ __launch_bounds__(256, 2) void score_resident_kernel(ResidentArgs a) 
       for (int r = threadIdx.x; r < 128 * TQ; r += 256) {
         const int q = qb * 128 * TQ + r;
         a.emit.row_unscale[q] = a.norms ? 1.f : rq_pow2(-(a.qexp[q] + ie));
+      }
+    }
+    if constexpr (ONE) {
+      if (chunk == 0) {
+        const float N = __uint_as_float(a.ine[0]), E = __uint_as_float(a.ine[1]);
+        for (int r = threadIdx.x; r < 128 * TQ; r += 256) {
+          const int q = qb * 128 * TQ + r;
+          a.emit.row_eps[q] = rq_screen_eps(a.qa[q], a.qb[q], N, E);
+        }
       }
     }
   }
@@ -220,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void score_resident_kernel(ResidentArgs a) 
     const int q = qb * QROWS + r;
     const int e = a.qexp[q] + iexp;                        // (qexp is padded to whole query blocks)
     unscale[r] = rq_pow2(-e);
-    if constexpr (MODE == 2) {
+    if constexpr (EMIT) {
       const float t = q < a.nq ? unordered(a.emit.tau[q]) : INFINITY;
       // without norms the test runs on the raw accumulators: tau 2^e (exact unless it leaves the range, where it saturates the
       // safe way: -inf / the largest finite value let more through, never less)
@@ -238,17 +302,20 @@ __global__ __launch_bounds__(256, 2) void score_resident_kernel(ResidentArgs a) 
         }
         if (q >= a.nq) ts = INFINITY;
       }
+      // screened pass: everything whose exact score can reach tau (a NaN / inf bound lets everything through: the row overflows
+      // and goes to the exact path)
+      if constexpr (ONE) ts -= rq_screen_eps(a.qa[q], a.qb[q], __uint_as_float(a.ine[0]), __uint_as_float(a.ine[1]));
       tau_s[r] = ts;
     }
   }
-  rq_f16x8 ah[TQ][KS], al[TQ][KS];
+  rq_f16x8 ah[TQ][KS], al[ONE ? 1 : TQ][ONE ? 1 : KS];
 #pragma unroll
   for (int tq = 0; tq < TQ; ++tq) {
     const _Float16 *src = a.qsplit + ((size_t)(q_wave / 32 + tq) * KS * 2) * 512 + lane * 8;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       ah[tq][ks] = *reinterpret_cast<const rq_f16x8 *>(src + (size_t)(ks * 2) * 512);
-      al[tq][ks] = *reinterpret_cast<const rq_f16x8 *>(src + (size_t)(ks * 2 + 1) * 512);
+      if constexpr (!ONE) al[tq][ks] = *reinterpret_cast<const rq_f16x8 *>(src + (size_t)(ks * 2 + 1) * 512);
     }
   }
 
@@ -258,14 +325,17 @@ __global__ __launch_bounds__(256, 2) void score_resident_kernel(ResidentArgs a) 
 #pragma unroll
   for (int tq = 0; tq < TQ; ++tq)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(ah[tq][ks]), "+v"(al[tq][ks]));
+    for (int ks = 0; ks < KS; ++ks) {
+      asm volatile("" : "+v"(ah[tq][ks]));
+      if constexpr (!ONE) asm volatile("" : "+v"(al[tq][ks]));
+    }
   __syncthreads();  // tau_s / unscale are in place (nothing LDS-bound is in flight yet: a plain barrier)
 
   // ---- item stream -----------------------------------------------------------------------------------------------------
   // step s of the workgroup = item tiles tile_of(s) .. + NI - 1; past the end the last tile is staged again (results unused)
   auto block_of = [&](int s) { return chunk + (s >> 2) * a.chunks; };  // (MODE 0 / 1)
   auto first_tile = [&](int s) {
-    if constexpr (MODE == 2) return chunk + s * a.chunks;
+    if constexpr (EMIT) return chunk + s * a.chunks;
     const int blk = block_of(s), sub = s & 3;
     return (MODE == 1 ? blk * a.block_stride : blk) * 4 + sub;
   };
@@ -275,7 +345,8 @@ __global__ __launch_bounds__(256, 2) void score_resident_kernel(ResidentArgs a) 
     const int t0 = first_tile(min(s, steps - 1));
 #pragma unroll
     for (int p = 0; p < PER_WAVE_DATA; ++p) {
-      const int piece = wave * PER_WAVE_DATA + p;          // 0 .. PIECES - 1 over the NI tiles of the step
+      int piece = wave * PER_WAVE_DATA + p;                // 0 .. PIECES - 1 over the NI tiles of the step
+      if constexpr (MODE == 3) piece = 2 * (piece % (PIECES / 2));  // high planes: pieces 0, 2, 4, ...
       const int tile = min(t0 + piece / (TILE_BYTES / 1024), last_tile), within = piece % (TILE_BYTES / 1024);
       const unsigned char *src = ibase + (size_t)tile * TILE_BYTES + within * 1024 + lane * 16;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
@@ -293,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void score_resident_kernel(ResidentArgs a) 
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s) dma(s);
 
-  if constexpr (MODE == 2) {
+  if constexpr (EMIT) {
     // ---- emit pass.  d = acc - tau_s (the row thresholds in the scaled domain, four rows per LDS read), "does anything in this lane
     // pass" five v_max3 and one compare per query tile, and the per-element work (which element, the exact test on the ordered key, the LDS staging) is left to the
     // lanes that have a survivor.  A compare per accumulator element against thresholds read from LDS cost ~1.4 K vector cycles per
@@ -328,7 +399,8 @@ __global__ __launch_bounds__(256, 2) void score_resident_kernel(ResidentArgs a) 
           return;
         }
         rq_lds_read16<(ks * 2) * 1024>(bh[set], slot_lds);
-        rq_lds_read16<(ks * 2 + 1) * 1024>(bl[set], slot_lds);
+        if constexpr (ONE) asm volatile("" : "=v"(bl[set]));  // (never read)
+        else rq_lds_read16<(ks * 2 + 1) * 1024>(bl[set], slot_lds);
       };
       using std::integral_constant;
       rq_static_for<(AHEAD < KS ? AHEAD : KS)>([&](auto Pc) {
@@ -340,16 +412,18 @@ __global__ __launch_bounds__(256, 2) void score_resident_kernel(ResidentArgs a) 
         constexpr int ks = decltype(Kc)::value;
         if constexpr (ks + AHEAD < KS) ldb(integral_constant<int, ks + AHEAD>{}, integral_constant<int, (ks + AHEAD) % SETS>{});
         // the reads of k-step ks have returned when at most those of the (up to AHEAD) later k-steps are outstanding
-        rq_lds_wait<2 * (KS - 1 - ks < AHEAD ? KS - 1 - ks : AHEAD)>(bh[ks % SETS], bl[ks % SETS]);
+        rq_lds_wait<(ONE ? 1 : 2) * (KS - 1 - ks < AHEAD ? KS - 1 - ks : AHEAD)>(bh[ks % SETS], bl[ks % SETS]);
         __builtin_amdgcn_sched_barrier(0);  // (left alone, the scheduler sinks every read to just before its first use)
         if (RQ_KO & 1) {
 #pragma unroll
-          for (int tq = 0; tq < TQ; ++tq) asm volatile("" ::"v"(bh[ks % SETS]), "v"(bl[ks % SETS]), "v"(ah[tq][ks]), "v"(al[tq][ks]));
+          for (int tq = 0; tq < TQ; ++tq) asm volatile("" ::"v"(bh[ks % SETS]), "v"(bl[ks % SETS]), "v"(ah[tq][ks]));
         } else {  // the query tiles' chains in turn: a dependent MFMA directly behind its predecessor waits for the result
+          if constexpr (!ONE) {
 #pragma unroll
-          for (int tq = 0; tq < TQ; ++tq) acc[tq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tq][ks], bh[ks % SETS], acc[tq], 0, 0, 0);
+            for (int tq = 0; tq < TQ; ++tq) acc[tq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tq][ks], bh[ks % SETS], acc[tq], 0, 0, 0);
 #pragma unroll
-          for (int tq = 0; tq < TQ; ++tq) acc[tq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tq][ks], bl[ks % SETS], acc[tq], 0, 0, 0);
+            for (int tq = 0; tq < TQ; ++tq) acc[tq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tq][ks], bl[ks % SETS], acc[tq], 0, 0, 0);
+          }
 #pragma unroll
           for (int tq = 0; tq < TQ; ++tq) acc[tq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tq][ks], bh[ks % SETS], acc[tq], 0, 0, 0);
         }
@@ -557,7 +631,7 @@ template <int MODE> static void launch_score_resident(int KS, ResidentArgs a, in
     kern<<<a.chunks * a.n_qb, 256, lds, stream()>>>(a);
     IMP_CHECK_HIP(hipGetLastError());
 #ifdef RQ_CLOCK
-    if (MODE == 2) {
+    if (MODE >= 2) {
       unsigned long long h[4] = {0, 0, 0, 0};
       IMP_CHECK_HIP(hipStreamSynchronize(stream()));
       IMP_CHECK_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(rq_clock_dbg), sizeof(h)));
@@ -568,6 +642,12 @@ template <int MODE> static void launch_score_resident(int KS, ResidentArgs a, in
   };
   using std::integral_constant;
   constexpr int TQ12 = MODE == 0 ? 1 : 2;
+  if constexpr (MODE == 3) {  // one plane of query fragments: twice the query rows per wavefront fit
+    if (KS == 16) {
+      go(integral_constant<int, 16>{}, integral_constant<int, 2>{});
+      return;
+    }
+  }
   if (KS == 2) go(integral_constant<int, 2>{}, integral_constant<int, TQ12>{});
   else if (KS == 4) go(integral_constant<int, 4>{}, integral_constant<int, TQ12>{});
   else if (KS == 8) go(integral_constant<int, 8>{}, integral_constant<int, TQ12>{});

@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r6f; mkdir -p $O
 cd $R
 B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras"
 IMP_BENCH_DETAIL=$O/base.json $B > /dev/null 2>$O/base.err
-for k in 4 6 36 38; do
+for k in ; do
   IMP_LIB_PATH=$R/build/variants/libimplicit_hip_rqko$k.so IMP_BENCH_DETAIL=$O/ko$k.json $B > /dev/null 2>$O/ko$k.err
 done
 python - <<'PY'
