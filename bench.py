@@ -1051,9 +1051,10 @@ def bench_topk(gpu, Cui, X, Y, k=10, queries=20_000, batch=1000):
         tf = per_batch_flops / (gemm_ms * 1e-3) / 1e12
         exact = os.environ.get("IMP_TOPK_FP32_MFMA") is not None
         resident = os.environ.get("IMP_TOPK_RESIDENT", "1") != "0" and not exact and Y.shape[1] <= 256
-        products = 3.0 if resident else 6.0
+        screen = resident and os.environ.get("IMP_TOPK_SCREEN", "1") != "0"
+        products = 1.0 if screen else (3.0 if resident else 6.0)
         peak = FP32_PEAK_TFLOPS if exact else BF16_PEAK_TFLOPS / products
-        kernel = "score_resident_kernel<8, 2, 2>" if resident else "score_gemm_direct_kernel<2"
+        kernel = ("score_resident_kernel<8, 2, 3>" if screen else "score_resident_kernel<8, 2, 2>") if resident else "score_gemm_direct_kernel<2"
         roofline = {"bound": "mfma", "kernel": kernel + " (emit pass)", "achieved": tf, "peak": peak,
                     "unit": "TFLOP/s", "frac": tf / peak, "avg_launch_ms": gemm_ms,
                     "flops_per_launch": per_batch_flops, "traffic": _pmc_kernel_traffic(kernel),
@@ -1062,8 +1063,10 @@ def bench_topk(gpu, Cui, X, Y, k=10, queries=20_000, batch=1000):
                     "note": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32); 2 x batch x items x f flops per launch" if exact else
                             ("fp32-equivalent flops (2 x batch x items x f per launch); the product runs as %d partial products of %s on "
                              "the fp16 / bf16 matrix cores with fp32 accumulation: peak = 2500 TFLOP/s dense / %d" %
-                             (int(products), "two-term fp16 operands (l h, h l, h h; per-row query scales, exact item maximum)" if resident
-                              else "three-term bf16 operands", int(products)))}
+                             (int(products), ("the high fp16 planes only: a SCREENING pass against tau - eps (rigorous error bound); the select kernel "
+                                              "re-scores the few entries that can still be among the best k in fp32 from the stored factors") if screen
+                              else ("two-term fp16 operands (l h, h l, h h; per-row query scales, exact item maximum)" if resident
+                                    else "three-term bf16 operands"), int(products)))}
     # the model-level call a user makes (recommend(): host COO build of the liked items + upload + KnnQuery.topk per batch)
     rec, rec_presliced = None, None
     try:

@@ -1065,96 +1065,134 @@ __global__ __launch_bounds__(BLOCK) void select_screened_kernel(const uint64_t *
                                                                 const TQs *__restrict__ Q, const TIs *__restrict__ I, int f) {
   __shared__ uint64_t cand[kEmitCap];
   __shared__ unsigned int sh_r;
-  const int tid = threadIdx.x, q = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, q = blockIdx.x;
   const unsigned int n_c = count[q];
   if (n_c > (unsigned)cap || n_c < (unsigned)k) {  // uniform
     if (tid == 0) fallback[q] = 1;
     return;
+  }
+  // the query row's share of this lane (EIGHT lanes per re-scored entry, four consecutive factors per lane and trip; f <= 256:
+  // the resident form's limit), requested before anything else: its latency runs under the sort
+  const int g = tid & 7;
+  float4 qv[8];  // (f is a multiple of 8 on this path: whole 4-factor pieces, one vector load each)
+  {
+    const TQs *qrow = Q + (size_t)q * f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = 4 * g + 32 * j;
+      qv[j] = c < f ? load4(qrow + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
   int npad = 2;
   while (npad < (int)n_c) npad <<= 1;
   for (int i = tid; i < npad; i += BLOCK) cand[i] = i < (int)n_c ? gcand[(size_t)q * cap + i] : 0;  // pads sort last
   if (tid == 0) sh_r = 0;
   __syncthreads();
-  auto sort_desc = [&](int n2) {
+  auto sort_desc = [&](uint64_t *v, int n2) {
     for (int size = 2; size <= n2; size <<= 1) {
       for (int stride = size >> 1; stride > 0; stride >>= 1) {
         for (int t = tid; t < (n2 >> 1); t += BLOCK) {
           int lo = 2 * t - (t & (stride - 1));
           int hi = lo + stride;
           bool desc = ((lo & size) == 0);
-          uint64_t a = cand[lo], b = cand[hi];
+          uint64_t a = v[lo], b = v[hi];
           if ((a < b) == desc) {
-            cand[lo] = b;
-            cand[hi] = a;
+            v[lo] = b;
+            v[hi] = a;
           }
         }
         __syncthreads();
       }
     }
   };
-  sort_desc(npad);
+  // short lists (the usual case: a few dozen entries) are ordered by counting -- entry i goes to the position "entries greater
+  // than it" (keys are distinct: the column is part of them) -- one barrier instead of the bitonic network's log^2 n; beyond
+  // kRankSort entries the quadratic count loses to the network
+  auto rank_sort = [&](const uint64_t *in, uint64_t *out, int n) {
+    for (int i = tid; i < n; i += BLOCK) {
+      const uint64_t key = in[i];
+      int rank = 0;
+      for (int j = 0; j < n; ++j) rank += in[j] > key;
+      out[rank] = key;
+    }
+    __syncthreads();
+  };
+  constexpr int kRankSort = 128;
+  uint64_t *lst = cand;
+  if (n_c <= (unsigned)kRankSort) {
+    lst = cand + 2048;
+    rank_sort(cand, lst, (int)n_c);
+  } else {
+    sort_desc(cand, npad);
+  }
   const float eps = row_eps[q];
-  const float a_k = unordered((uint32_t)(cand[k - 1] >> 32));
+  const float a_k = unordered((uint32_t)(lst[k - 1] >> 32));
   const float cut = a_k - 2.f * eps;
-  if (!(eps >= 0.f) || !(eps <= FLT_MAX) || !(a_k == a_k) || (uint32_t)(cand[0] >> 32) >= 0xFF800000u) {  // (uniform) NaN / inf somewhere
+  if (!(eps >= 0.f) || !(eps <= FLT_MAX) || !(a_k == a_k) || (uint32_t)(lst[0] >> 32) >= 0xFF800000u) {  // (uniform) NaN / inf somewhere
     if (tid == 0) fallback[q] = 1;
     return;
   }
   // R = entries with an accumulator >= cut: a prefix of the sorted list
   for (int i = tid; i < (int)n_c; i += BLOCK)
-    if (unordered((uint32_t)(cand[i] >> 32)) >= cut) atomicMax(&sh_r, (unsigned)i + 1u);
+    if (unordered((uint32_t)(lst[i] >> 32)) >= cut) atomicMax(&sh_r, (unsigned)i + 1u);
   __syncthreads();
   const int n_r = (int)sh_r;
 #ifdef RQ_SCREEN_STATS
-  if (tid == 0) atomicAdd(&rq_screen_stats[0], 1ull), atomicAdd(&rq_screen_stats[1], (unsigned long long)n_c), atomicAdd(&rq_screen_stats[2], (unsigned long long)n_r);
+  if (tid == 0) atomicAdd(&rq_screen_stats[0], 1ull), atomicAdd(&rq_screen_stats[1], (unsigned long long)n_c), atomicAdd(&rq_screen_stats[2], (unsigned long long)n_r), atomicMax(&rq_screen_stats[3], (unsigned long long)n_r);
 #endif
   if (n_r > kScreenCap) {  // uniform
     if (tid == 0) fallback[q] = 1;
     return;
   }
-  // exact scores of the R entries: sixteen lanes per entry (32 entries of a row in flight: a few rows re-score a hundred), four
-  // consecutive factors per lane and trip, fixed-order sum over the group
-  const TQs *qrow = Q + (size_t)q * f;
+  // exact scores of the R entries.  Nearly every row re-scores k plus one or two, but a row whose scores are all small against its
+  // bound re-scores hundreds (624 seen on the bench's trained factors) and the launch lasts as long as its slowest row: eight
+  // lanes per entry and two entries per group and trip = 128 gathers of a row in flight; fixed-order sum over the group
   bool bad = false;
-#ifdef RQ_SCREEN_KO
-  if (RQ_SCREEN_KO & 1) goto skip_rescoring;  // (timing only)
+  constexpr int PER = BLOCK / 8;
+  for (int i0 = tid >> 3; i0 < n_r; i0 += 2 * PER) {
+    const int i1 = i0 + PER;
+    const bool two = i1 < n_r;
+    const int item0 = (int)(uint32_t)lst[i0], item1 = two ? (int)(uint32_t)lst[i1] : item0;
+#ifdef RQ_SCREEN_KO  // (timing only) 1: no gathers -- every entry reads item row 0;  2: no re-scoring at all
+    const TIs *r0 = I + (size_t)((RQ_SCREEN_KO & 1) ? 0 : item0) * f, *r1 = I + (size_t)((RQ_SCREEN_KO & 1) ? 0 : item1) * f;
+    if (RQ_SCREEN_KO & 2) break;
+#else
+    const TIs *r0 = I + (size_t)item0 * f, *r1 = I + (size_t)item1 * f;
 #endif
-  {
-    const int g = tid & 15;
-    for (int i = tid >> 4; i < n_r; i += BLOCK / 16) {
-      const int item = (int)(uint32_t)cand[i];
-      const TIs *irow = I + (size_t)item * f;
-      float sum = 0.f;
-      for (int c = 4 * g; c < f; c += 64) {
+    float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (c + e < f) sum = fmaf((float)qrow[c + e], (float)irow[c + e], sum);
+    for (int j = 0; j < 8; ++j) {
+      const int c = 4 * g + 32 * j;
+      if (c < f) {
+        const float4 y0 = load4(r0 + c), y1 = load4(r1 + c);
+        s0 = fmaf(qv[j].x, y0.x, s0), s0 = fmaf(qv[j].y, y0.y, s0), s0 = fmaf(qv[j].z, y0.z, s0), s0 = fmaf(qv[j].w, y0.w, s0);
+        s1 = fmaf(qv[j].x, y1.x, s1), s1 = fmaf(qv[j].y, y1.y, s1), s1 = fmaf(qv[j].z, y1.z, s1), s1 = fmaf(qv[j].w, y1.w, s1);
       }
-      sum += __shfl_xor(sum, 8, 64), sum += __shfl_xor(sum, 4, 64), sum += __shfl_xor(sum, 2, 64), sum += __shfl_xor(sum, 1, 64);
-      if (!(fabsf(sum) <= FLT_MAX)) bad = true;
-      if (g == 0) cand[i] = make_key(sum, item);
+    }
+    s0 += __shfl_xor(s0, 4, 64), s0 += __shfl_xor(s0, 2, 64), s0 += __shfl_xor(s0, 1, 64);
+    s1 += __shfl_xor(s1, 4, 64), s1 += __shfl_xor(s1, 2, 64), s1 += __shfl_xor(s1, 1, 64);
+    if (!(fabsf(s0) <= FLT_MAX) || !(fabsf(s1) <= FLT_MAX)) bad = true;
+    if (g == 0) {
+      lst[i0] = make_key(s0, item0);
+      if (two) lst[i1] = make_key(s1, item1);
     }
   }
-#ifdef RQ_SCREEN_KO
-skip_rescoring:
-#endif
   if (__syncthreads_or(bad)) {
     if (tid == 0) fallback[q] = 1;
     return;
   }
-#ifdef RQ_SCREEN_KO
-  if (RQ_SCREEN_KO & 2) {  // (timing only: no second sort / write)
-    if (tid == 0) fallback[q] = 0;
-    return;
+  uint64_t *fin = lst;
+  if (n_r <= kRankSort) {
+    fin = lst == cand ? cand + 2048 : cand;  // (the two regions do not overlap)
+    rank_sort(lst, fin, n_r);
+  } else {  // (n_r <= kScreenCap = 1024: the pads stay inside the list's 2048-entry region)
+    int rpad = 2;
+    while (rpad < n_r) rpad <<= 1;
+    for (int i = n_r + tid; i < rpad; i += BLOCK) lst[i] = 0;
+    __syncthreads();
+    sort_desc(lst, rpad);
   }
-#endif
-  int rpad = 2;
-  while (rpad < n_r) rpad <<= 1;
-  for (int i = n_r + tid; i < rpad; i += BLOCK) cand[i] = 0;  // (the slots behind R: no longer needed)
-  __syncthreads();
-  sort_desc(rpad);
-  write_best_k<BLOCK>(cand, (unsigned)n_r, k, q, out_ids, out_dist, out_stride, fallback, 1.f);
+  write_best_k<BLOCK>(fin, (unsigned)n_r, k, q, out_ids, out_dist, out_stride, fallback, 1.f);
 }
 
 // factor counts that are not a multiple of 16 (the reference's CPU default is 100): rows zero-padded to the next multiple, fp16
@@ -1608,8 +1646,8 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
             unsigned long long h[4];
             IMP_CHECK_HIP(hipStreamSynchronize(stream()));
             IMP_CHECK_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(rq_screen_stats), sizeof(h)));
-            fprintf(stderr, "[screen-stats] rows %llu, candidates per row %.1f, re-scored per row %.1f\n", h[0], (double)h[1] / std::max(1ull, h[0]),
-                    (double)h[2] / std::max(1ull, h[0]));
+            fprintf(stderr, "[screen-stats] rows %llu, candidates per row %.1f, re-scored per row %.1f (largest so far: %llu)\n", h[0],
+                    (double)h[1] / std::max(1ull, h[0]), (double)h[2] / std::max(1ull, h[0]), h[3]);
           }
 #endif
         }
