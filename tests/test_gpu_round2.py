@@ -221,7 +221,7 @@ print("switch ok")
 
 
 @pytest.mark.parametrize("switch", ["IMP_STRIPE=0", "IMP_SEGMENT=128", "IMP_TOPK_NO_FAST=1", "IMP_TOPK_NO_EMIT=1", "IMP_TOPK_RESIDENT=0",
-                                    "IMP_TOPK_FP32_MFMA=1", "IMP_OVERSUB=3", "IMP_NO_PAD=1", "IMP_NM=0", "IMP_NM_SEGMENT=128", "IMP_F256_OLD=1",
+                                    "IMP_TOPK_SCREEN=0", "IMP_TOPK_FP32_MFMA=1", "IMP_OVERSUB=3", "IMP_NO_PAD=1", "IMP_NM=0", "IMP_NM_SEGMENT=128", "IMP_F256_OLD=1",
                                     "IMP_CHOL_NM=0", "IMP_CHOL_PAD=0"])
 def test_ab_switch_paths_keep_parity(gpu, switch):
     """Every debug / A-B environment switch selects kernels the default run does not take (they are read once per

@@ -442,3 +442,45 @@ def test_coo_filter_from_a_csr_pattern(gpu):
     bad.indptr[5] = bad.indptr[6] + 3
     with pytest.raises(ValueError):
         gpu.COOMatrix.from_csr_pattern(bad)
+
+
+def test_screened_emit_pass_bounds_hold_on_awkward_rows(gpu, oracle):
+    """The emit pass scores with ONE fp16 product and keeps everything within a rigorous error bound of the threshold; the
+    select kernel re-scores what can still be among the best k in fp32 (topk_resident.h MODE 3).  Rows that stress the bound:
+    queries of very different magnitude in one batch, a query that is tiny against its own rounding (all scores within the
+    bound: hundreds of entries re-scored, or the row handed to the exact path), items with outlier norms that inflate the
+    catalogue-wide bound, duplicated items (exact ties after re-scoring), fp16-stored factors.  Ids must be the oracle's outside
+    fp32 near-ties, distances within the reference's own tolerance, tie rows bit for bit."""
+    rng = np.random.default_rng(12)
+    ni, f, nq, k = 40_000, 128, 256, 10
+    items = (rng.standard_normal((ni, f)) * 0.05).astype(np.float32)
+    items[::997] *= 40.0                               # outlier norms: N_max is 40 x the typical norm
+    items[1::2000] = items[3]                          # duplicated rows: exact ties
+    queries = (rng.standard_normal((nq, f)) * 0.1).astype(np.float32)
+    queries[::5] *= 1e-4
+    queries[1::5] *= 300.0
+    queries[7] = 1e-30                                 # scores far below the bound's absolute terms
+    queries[9] = items[3] * 2                          # the duplicated item wins: ties at the top
+    queries[11] = 0.0                                  # all scores tie at zero
+    want_ids, want_d = oracle.topk(items, queries, k + 1)
+    knn = gpu.KnnQuery()
+    ids, d = knn.topk(gpu.Matrix(items), gpu.Matrix(queries), k)
+    audit = _near_tie_rows(want_d, f)
+    ties = [9, 11]                                     # exact ties: the heap's rule depends on k -- compared with the oracle at k
+    audit[ties] = True
+    ok = ~audit
+    assert_array_equal(ids[ok], want_ids[ok, :k])
+    assert_allclose(d[ok], want_d[ok, :k], rtol=3e-5, atol=1e-30)
+    tie_ids, tie_d = oracle.topk(items, queries[ties], k)
+    assert_array_equal(ids[ties], tie_ids)
+    assert_allclose(d[ties], tie_d, rtol=3e-5)
+    for r in np.nonzero(audit)[0]:
+        if r not in ties:
+            assert len(set(ids[r]) ^ set(want_ids[r, :k])) <= 2
+    # fp16-stored factors are re-scored as stored
+    ih, qh = items.astype(np.float16), (queries[:64] * 0 + rng.standard_normal((64, f)) * 0.1).astype(np.float16)
+    want_ids, want_d = oracle.topk(ih.astype(np.float32), qh.astype(np.float32), k + 1)
+    ids, d = knn.topk(gpu.Matrix(ih), gpu.Matrix(qh), k)
+    ok = ~_near_tie_rows(want_d, f)
+    assert_array_equal(ids[ok], want_ids[ok, :k])
+    assert_allclose(d[ok], want_d[ok, :k], rtol=2e-3)
