@@ -154,7 +154,8 @@ def fmt(v):
     return "—" if v is None else f"{v:.1e}"
 
 
-TOPK_FORMS = (("fp16 x 2, three products (default, topk_resident.h)", {}),
+TOPK_FORMS = (("default: one-product screening pass + fp32 re-scoring of the candidates (emit path, no norms); fp16 x 2, three products elsewhere", {}),
+              ("fp16 x 2, three products everywhere (IMP_TOPK_SCREEN=0)", {"IMP_TOPK_SCREEN": "0"}),
               ("bf16 x 3, six products (IMP_TOPK_RESIDENT=0)", {"IMP_TOPK_RESIDENT": "0"}),
               ("exact fp32 MFMA (IMP_TOPK_FP32_MFMA=1)", {"IMP_TOPK_FP32_MFMA": "1", "IMP_TOPK_RESIDENT": "0"}))
 
