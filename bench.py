@@ -505,6 +505,7 @@ def compact_line(full, args):
         line["topk"] = {"k": topk.get("k"), "via": "model.recommend()", "knn_topk_recs_per_s": _r(topk.get("knn_topk_recs_per_s")),
                         "presliced_recs_per_s": _r(topk.get("model_recommend_presliced_recs_per_s")),
                         "gemm_ms": _r(tr.get("avg_launch_ms"), 4), "gemm_frac_of_mfma_peak": _r(tr.get("frac"), 3),
+                        "gemm_peak_TFLOPs": _r(tr.get("peak")),  # 2500 / partial products: 1 (screening pass), 3 or 6
                         "gemm_traffic": _r(tr.get("traffic"))}
     extras = {}
     for key, v in full.items():
