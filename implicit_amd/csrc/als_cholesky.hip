@@ -17,6 +17,7 @@
 namespace imp {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kCholTile = 8;
 
@@ -605,13 +606,51 @@ __global__ __launch_bounds__(256, 3) void als_cholesky_f64_kernel(const int32_t 
     // sub-diagonal entries a pivot step needs travel by v_readlane, not through the image -- and the four new columns go to
     // the image in ONE ds_write_b128 per lane.  16 LDS round trips per row instead of 64; the forward substitution rides
     // along as before.
+    // Round 6: the bulk of those sums on the matrix cores.  At the start of every 16-column PANEL P >= 1 the contributions of
+    // all earlier panels to its columns, T[i][c] = sum_{j < 16 P} L[i][j] L[16 P + c][j], come from v_mfma_f32_16x16x4_f32 --
+    // operands read straight from the image (columns < 16 P of every row are final), one 16 x 16 tile per row block >= P, 40
+    // MFMAs per row in all -- go through the image's not-yet-written positions (row, 16 P + c) to the row-per-lane layout and
+    // are subtracted from the lane's A values; the four-column steps then only sum over the columns of their own panel.  It
+    // replaces ~1150 of a row's ~6 K vector instructions (packed FMAs + broadcast LDS reads): the kernel is vector-issue bound.
+#ifndef IMP_CHOL_NO_PANEL_MFMA
+    constexpr bool kPanelMfma = true;
+#else
+    constexpr bool kPanelMfma = false;
+#endif
     static_for<F / 4>([&](auto bc) {
       constexpr int k0 = 4 * decltype(bc)::value;
+      constexpr int j_first = kPanelMfma ? 16 * (k0 / 16) : 0;  // first column the four-column step still sums over
+      if constexpr (kPanelMfma && k0 % 16 == 0 && k0 > 0) {
+        constexpr int P = k0 / 16;
+        const int l16 = lane_v & 15, lq = lane_v >> 4;
+        const int off_b = chol_rowoff(16 * P + l16) + lq;  // B[k = lq][c = l16] = L[16 P + l16][4 ks + lq]
+        static_for<4 - P>([&](auto rbc) {
+          constexpr int rb = P + decltype(rbc)::value;
+          const int off_a = chol_rowoff(16 * rb + l16) + lq;  // A[i = l16][k = lq] = L[16 rb + l16][4 ks + lq]
+          f32x4 d = {0.f, 0.f, 0.f, 0.f};
+          static_for<4 * P>([&](auto ksc) {
+            constexpr int ks = decltype(ksc)::value;
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(As[off_a + 4 * ks], As[off_b + 4 * ks], d, 0, 0, 0);
+          });
+          // D[i = 4 lq + r][c = l16] -> image position (row 16 rb + 4 lq + r, column k0 + l16) where the row has storage there
+          // (rows are padded to whole 4-float chunks: column <= row | 3); the positions above the diagonal are never read back
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * rb + 4 * lq + r;
+            if ((row | 3) >= k0 + l16) As[chol_rowoff(row) + k0 + l16] = d[r];
+          }
+        });
+#pragma unroll
+        for (int j = 0; j < 16; j += 4) {  // this lane's row (lanes above the panel read other rows' words into values never used)
+          const float4 t4 = *reinterpret_cast<const float4 *>(As + my_off + k0 + j);
+          A(k0 + j) -= t4.x, A(k0 + j + 1) -= t4.y, A(k0 + j + 2) -= t4.z, A(k0 + j + 3) -= t4.w;
+        }
+      }
       f32x2 acc[4][2];
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[c][0] = acc[c][1] = f32x2{0.f, 0.f};
-      static_for<k0 / 4>([&](auto cc) {
-        constexpr int j = 4 * decltype(cc)::value;
+      static_for<(k0 - j_first) / 4>([&](auto cc) {
+        constexpr int j = j_first + 4 * decltype(cc)::value;
         float4 l[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) l[c] = *reinterpret_cast<const float4 *>(As + chol_rowoff(k0 + c) + j);
