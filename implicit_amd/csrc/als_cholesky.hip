@@ -665,8 +665,7 @@ __global__ __launch_bounds__(256, 3) void als_cholesky_f64_kernel(const int32_t 
       for (int c = 0; c < 4; ++c) t[c] = A(k0 + c) - ((acc[c][0].x + acc[c][0].y) + (acc[c][1].x + acc[c][1].y));
       static_for<4>([&](auto cc) {
         constexpr int c = decltype(cc)::value, k = k0 + c;
-        const float d = bcast_lane(t[c], k);  // pivot
-        if (!(d > 0.f)) ok = false;
+        const float d = bcast_lane(t[c], k);  // pivot (a non-positive one turns the column, and L[k][k] with it, into NaNs: checked once, below)
         const float r0 = __builtin_amdgcn_rsqf(d);  // 1 / sqrt(d): v_rsq_f32 + one Newton step (see the column-wise form)
         const float inv = fmaf(r0, fmaf(-0.5f * d * r0, r0, 0.5f), r0);
         const float lik = t[c] * inv;  // L[i][k] for i >= k
@@ -675,13 +674,20 @@ __global__ __launch_bounds__(256, 3) void als_cholesky_f64_kernel(const int32_t 
         for (int c2 = c + 1; c2 < 4; ++c2) t[c2] = fmaf(-lik, bcast_lane(lik, k0 + c2), t[c2]);  // - L[i][k] L[k0+c2][k]
         const float zk = bcast_lane(b, k) * inv;  // z_k = b_k / L_kk; the forward substitution rides along
         b = lane_v == k ? zk : (lane_v > k ? fmaf(-lik, zk, b) : b);
-        dinv = lane_v == k ? inv : dinv;
-        asm volatile("" : "+v"(dinv));  // here and now (see the column-wise form)
       });
       // rows k0 and below get their four new columns; a row inside the block writes words beyond its diagonal into its own
       // padding (rows are padded to whole 4-float chunks), which nothing reads
       if (lane_v >= k0) *reinterpret_cast<float4 *>(As + my_off + k0) = make_float4(A(k0), A(k0 + 1), A(k0 + 2), A(k0 + 3));
     });
+    {
+      // 1 / L[k][k] for the back substitution and the positive-definiteness check, once per row instead of a compare and a
+      // select per column: lane k reads its diagonal from the image (d x rsq(d), a NaN or an infinity if any pivot up to k
+      // was not positive) -- v_rcp_f32 + one Newton step
+      const float ldiag = As[my_off + lane_v];
+      const float r0 = __builtin_amdgcn_rcpf(ldiag);
+      dinv = fmaf(r0, fmaf(-ldiag, r0, 1.f), r0);
+      ok = __ballot(ldiag > 0.f && ldiag <= 3.0e38f) == ~0ull;
+    }
 #else
     float4 lrow[F / 4];
     static_for<F>([&](auto kc) {
