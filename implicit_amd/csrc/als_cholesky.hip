@@ -596,8 +596,7 @@ __global__ __launch_bounds__(256, 3) void als_cholesky_f64_kernel(const int32_t 
     // pipeline: the chunks of row k+1 that do not contain column k are already final, so their reads are issued right
     // after step k's dot product and fly during its pivot chain (v_readlane -> v_rsq -> Newton -> column scale -> store);
     // only the chunk holding column k is read after the store.  lrow is free by then: no extra registers.
-#ifndef IMP_CHOL_COLUMNWISE
-    // Round 4: four columns per step.  Column by column (the form kept below for A/B builds) the row's critical path was 64
+    // Round 4: four columns per step.  Column by column (round 2's form, removed in round 6) the row's critical path was 64
     // times [dot product -> pivot chain -> LDS store of the column -> LDS read of the next row's last chunk]: an LDS round trip
     // per column that nothing covers at three waves per SIMD (IMP_CHOL_STATS: 34.8 K of a 50-nonzero row's 60 K cycles).  A
     // block of columns k0 .. k0 + 3 needs rows k0 .. k0 + 3 of L only in columns < k0, all final when the block starts: their
@@ -672,8 +671,10 @@ __global__ __launch_bounds__(256, 3) void als_cholesky_f64_kernel(const int32_t 
         A(k) = lik;
 #pragma unroll
         for (int c2 = c + 1; c2 < 4; ++c2) t[c2] = fmaf(-lik, bcast_lane(lik, k0 + c2), t[c2]);  // - L[i][k] L[k0+c2][k]
-        const float zk = bcast_lane(b, k) * inv;  // z_k = b_k / L_kk; the forward substitution rides along
-        b = lane_v == k ? zk : (lane_v > k ? fmaf(-lik, zk, b) : b);
+        // the forward substitution rides along: rows below k lose L[i][k] z_k, z_k = b_k / L_kk; lane k keeps its REDUCED
+        // right-hand side b_k (z_k = b_k / L_kk is taken for all lanes at once after the loop: one select less per column)
+        const float zk = bcast_lane(b, k) * inv;
+        b = lane_v > k ? fmaf(-lik, zk, b) : b;
       });
       // rows k0 and below get their four new columns; a row inside the block writes words beyond its diagonal into its own
       // padding (rows are padded to whole 4-float chunks), which nothing reads
@@ -688,49 +689,6 @@ __global__ __launch_bounds__(256, 3) void als_cholesky_f64_kernel(const int32_t 
       dinv = fmaf(r0, fmaf(-ldiag, r0, 1.f), r0);
       ok = __ballot(ldiag > 0.f && ldiag <= 3.0e38f) == ~0ull;
     }
-#else
-    float4 lrow[F / 4];
-    static_for<F>([&](auto kc) {
-      constexpr int k = decltype(kc)::value;
-      // s = A[lane][k] - sum_{j<k} L[lane][j] L[k][j], 4 independent accumulators in two packed pairs
-      f32x2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
-#pragma unroll
-      for (int j = 0; j < k; j += 4) {
-        const float4 l = lrow[j / 4];
-        // compile-time conditions: the last chunk of a row is partial
-        if (j + 1 < k) s01 = __builtin_elementwise_fma(A2[j / 2], (f32x2){l.x, l.y}, s01);
-        else s01.x = fmaf(A(j), l.x, s01.x);
-        if (j + 3 < k) s23 = __builtin_elementwise_fma(A2[j / 2 + 1], (f32x2){l.z, l.w}, s23);
-        else if (j + 2 < k) s23.x = fmaf(A(j + 2), l.z, s23.x);
-      }
-      const float s0 = s01.x, s1 = s01.y, s2 = s23.x, s3 = s23.y;
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (k + 1 < F) {  // row k+1, chunks below the one that holds column k
-#pragma unroll
-        for (int c = 0; c < k / 4; ++c) lrow[c] = *reinterpret_cast<const float4 *>(As + chol_rowoff(k + 1) + 4 * c);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      const float s = A(k) - ((s0 + s1) + (s2 + s3));
-      const float d = bcast_lane(s, k);  // pivot
-      if (!(d > 0.f)) ok = false;
-      // 1 / sqrt(d): v_rsq_f32 (1 ulp) + one Newton step -- as accurate as sqrt followed by a true division (two roundings)
-      // at a fifth of the instructions (reg = 0 systems are badly conditioned: no raw approximations).  The column and the
-      // forward substitution multiply by it; L[k][k] itself comes out as d * inv and is only used through `inv`.
-      const float r0 = __builtin_amdgcn_rsqf(d);
-      const float inv = fmaf(r0, fmaf(-0.5f * d * r0, r0, 0.5f), r0);  // r0 + r0 (1/2 - d r0^2 / 2)
-      const float lik = s * inv;  // L[i][k] for i >= k
-      A(k) = lik;
-      if (lane_v >= k) As[my_off + k] = lik;  // rows above k have no column k in the triangular image
-      if constexpr (k + 1 < F) lrow[k / 4] = *reinterpret_cast<const float4 *>(As + chol_rowoff(k + 1) + 4 * (k / 4));
-      const float zk = bcast_lane(b, k) * inv;  // z_k = b_k / L_kk; the forward substitution rides along
-      // rows above k are finished (z_i final) and their column-k value is not a matrix element in the triangular image
-      b = lane_v == k ? zk : (lane_v > k ? fmaf(-lik, zk, b) : b);
-      dinv = lane_v == k ? inv : dinv;
-      // here and now: left to the scheduler, the 64 selects sink below the loop and keep 64 `inv` values alive (231 registers
-      // instead of 172: the difference between two and three waves per SIMD)
-      asm volatile("" : "+v"(dinv));
-    });
-#endif
     tick(3);
     if (!ok) {
       if (lane == 0) atomicMin(failed_row, (unsigned long long)u);
@@ -742,7 +700,7 @@ __global__ __launch_bounds__(256, 3) void als_cholesky_f64_kernel(const int32_t 
 #pragma unroll
     for (int k = 0; k < F; ++k) A(k) = As[chol_rowoff(k) + lane];  // L[k][lane] (meaningful for lane < k; beyond: other rows' words)
     __builtin_amdgcn_sched_barrier(0);
-    b *= dinv;  // lane k now holds z_k / L[k][k]; the pending corrections are scaled the same way as they arrive
+    b *= dinv * dinv;  // lane k: reduced b_k -> z_k = b_k / L[k][k] -> z_k / L[k][k]; the pending corrections are scaled the same way as they arrive
     static_for<F>([&](auto kc) {
       constexpr int k = F - 1 - decltype(kc)::value;
       const float xk = bcast_lane(b, k);  // x_k: lane k's value is final once all x_j, j > k, have been applied
