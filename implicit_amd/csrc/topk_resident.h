@@ -330,6 +330,18 @@ __global__ __launch_bounds__(256, 2) void score_resident_kernel(ResidentArgs a) 
       if constexpr (!ONE) asm volatile("" : "+v"(al[tq][ks]));
     }
   __syncthreads();  // tau_s / unscale are in place (nothing LDS-bound is in flight yet: a plain barrier)
+  // MODE 3: the accumulators START at -(tau - eps) of their rows (the first MFMA's C operand), so the threshold test is a maximum
+  // and a sign -- no subtraction, no LDS read per step.  The three-product pass cannot do this (a survivor's score rebuilt as
+  // d + tau is an ulp or two off the threshold pass's value of the same dot product: rows then find k - 1 candidates); here the
+  // candidates are re-scored anyway, the keys only have to keep each row's ORDER (an offset per row does), and the rounding of the
+  // offset sum (2^-23 of |tau|) is inside the bound's slack term
+  [[maybe_unused]] float nts[ONE ? TQ : 1][16];
+  if constexpr (ONE) {
+#pragma unroll
+    for (int tq = 0; tq < TQ; ++tq)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) nts[tq][e] = -tau_s[wave * 32 * TQ + 32 * tq + 4 * kh + (e & 3) + 8 * (e >> 2)];
+  }
 
   // ---- item stream -----------------------------------------------------------------------------------------------------
   // step s of the workgroup = item tiles tile_of(s) .. + NI - 1; past the end the last tile is staged again (results unused)
@@ -385,7 +397,7 @@ __global__ __launch_bounds__(256, 2) void score_resident_kernel(ResidentArgs a) 
 #pragma unroll
       for (int tq = 0; tq < TQ; ++tq)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[tq][e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[tq][e] = ONE ? nts[tq][e] : 0.f;
       // item fragments TWO k-steps ahead of the MFMAs that use them (three register sets): with the reads of k-step ks + 1 issued
       // only after the MFMAs of ks, an LDS round trip under load (eight wavefronts reading, the DMA writing) outlasted the 192
       // cycles those MFMAs cover, and the matrix pipe idled a third of the loop (SQ_VALU_MFMA_BUSY: 0.50 of the launch)
@@ -455,10 +467,14 @@ __global__ __launch_bounds__(256, 2) void score_resident_kernel(ResidentArgs a) 
         // d = score - threshold: its sign is exact.  A NaN (a non-finite operand) is dropped by the maxima while a number stands
         // beside it: its row then collects fewer than k candidates and goes to the exact path, as it should
         f32x16 d;
+        if constexpr (ONE) {
+          d = c;  // (the accumulators started at minus their thresholds)
+        } else {
 #pragma unroll
-        for (int eg = 0; eg < 4; ++eg) {
-          const float4 ts = *reinterpret_cast<const float4 *>(tau_s + r_base + 8 * eg);
-          d[4 * eg] = c[4 * eg] - ts.x, d[4 * eg + 1] = c[4 * eg + 1] - ts.y, d[4 * eg + 2] = c[4 * eg + 2] - ts.z, d[4 * eg + 3] = c[4 * eg + 3] - ts.w;
+          for (int eg = 0; eg < 4; ++eg) {
+            const float4 ts = *reinterpret_cast<const float4 *>(tau_s + r_base + 8 * eg);
+            d[4 * eg] = c[4 * eg] - ts.x, d[4 * eg + 1] = c[4 * eg + 1] - ts.y, d[4 * eg + 2] = c[4 * eg + 2] - ts.z, d[4 * eg + 3] = c[4 * eg + 3] - ts.w;
+          }
         }
         const float m = fmaxf(fmaxf(fmaxf(fmaxf(d[0], d[1]), fmaxf(d[2], d[3])), fmaxf(fmaxf(d[4], d[5]), fmaxf(d[6], d[7]))),
                               fmaxf(fmaxf(fmaxf(d[8], d[9]), fmaxf(d[10], d[11])), fmaxf(fmaxf(d[12], d[13]), fmaxf(d[14], d[15]))));
