@@ -1362,7 +1362,8 @@ struct imp_knn {
     DeviceArray<_Float16> planes;
     DeviceArray<int> exp;          // scale exponent of the item matrix (from its exact maximum)
     DeviceArray<unsigned> maxbits;
-    DeviceArray<unsigned> ne;      // bits of max || y 2^e ||_2 and max || y 2^e - high plane ||_2 (screened emit pass)
+    DeviceArray<unsigned> ne;      // bits of max || y 2^e ||_2, max || y 2^e - high plane ||_2, max ratio of the two (screened emit pass)
+    DeviceArray<unsigned> tile_n;  // bits of max || y 2^e ||_2 per 32-item tile
     size_t rows = 0, cols = 0, itemsize = 0;
     int KS = 0;
     ItemPlanes() { register_derived_cache(&key); }
@@ -1552,6 +1553,7 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
     // the handle), the query rows of this call with one scale per row
     const float *q_err_a = nullptr, *q_err_b = nullptr;
     const unsigned *item_ne = nullptr;
+    const float *item_tile_n = nullptr;
     auto prepare_planes = [&](int KS, const _Float16 *&iplanes, const int *&iexp, const _Float16 *&qplanes, const int *&qexp) {
         IMP_PROF("split_query_rows");
         auto &ip = knn->item_planes;
@@ -1560,16 +1562,18 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
         if (!same) {
           ip.key.src = nullptr;
           if (ip.planes.size < ni_pad * F * 2) ip.planes.alloc(ni_pad * F * 2);
-          if (ip.exp.size < 1) ip.exp.alloc(1), ip.maxbits.alloc(1), ip.ne.alloc(2);
+          if (ip.exp.size < 1) ip.exp.alloc(1), ip.maxbits.alloc(1), ip.ne.alloc(4);
+          if (ip.tile_n.size < ni_pad / 32) ip.tile_n.alloc(ni_pad / 32);
           IMP_CHECK_HIP(hipMemsetAsync(ip.maxbits.data(), 0, sizeof(unsigned), stream()));
-          IMP_CHECK_HIP(hipMemsetAsync(ip.ne.data(), 0, 2 * sizeof(unsigned), stream()));
+          IMP_CHECK_HIP(hipMemsetAsync(ip.ne.data(), 0, 4 * sizeof(unsigned), stream()));
+          IMP_CHECK_HIP(hipMemsetAsync(ip.tile_n.data(), 0, (ni_pad / 32) * sizeof(unsigned), stream()));
           const int g1 = (int)std::max<size_t>(1, std::min<size_t>((ni * (size_t)f + 255) / 256, (size_t)ctx().num_cus * 8));
           rq_absmax_kernel<TI><<<g1, 256, 0, stream()>>>(Ib, ni * (size_t)f, ip.maxbits.data());
           rq_item_exp_kernel<<<1, 1, 0, stream()>>>(ip.maxbits.data(), ip.exp.data());
           const int g2 = (int)std::max<size_t>(1, std::min<size_t>((ni_pad * (F / 8) + 255) / 256, (size_t)ctx().num_cus * 16));
           rq_split_items_kernel<TI><<<g2, 256, 0, stream()>>>(Ib, ip.planes.data(), ni, ni_pad, f, KS, ip.exp.data());
           rq_item_err_kernel<TI><<<(int)std::min<size_t>((ni + 3) / 4, (size_t)ctx().num_cus * 16), 256, 0, stream()>>>(Ib, ni, f, ip.exp.data(),
-                                                                                                                    ip.ne.data());
+                                                                                                                    ip.ne.data(), ip.tile_n.data());
           ip.rows = ni, ip.cols = (size_t)f_in, ip.itemsize = items_in->itemsize, ip.KS = KS;
           const bool trusted = items_in->storage && items_in->storage->owned && !items_in->storage->exposed;
           if (trusted) ip.key.src = items_in->data, ip.key.bytes = items_in->bytes();
@@ -1583,7 +1587,7 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
                                                                                                                              qerr, qerr + nq_pad);
         IMP_CHECK_HIP(hipGetLastError());
         qplanes = qp, qexp = qe;
-        q_err_a = qerr, q_err_b = qerr + nq_pad, item_ne = ip.ne.data();
+        q_err_a = qerr, q_err_b = qerr + nq_pad, item_ne = ip.ne.data(), item_tile_n = reinterpret_cast<const float *>(ip.tile_n.data());
     };
     static const bool resident_env = !(getenv("IMP_TOPK_RESIDENT") && atoi(getenv("IMP_TOPK_RESIDENT")) == 0);
     constexpr bool bf16x3 = false;
@@ -1642,7 +1646,7 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
             ra.nq = rows, ra.ni = (int)ni, ra.norms = norms_p;
             ra.n_blocks = (int)grid.x, ra.block_stride = bstride;
             ra.S = S_out, ra.sub_cols = (int)grid.x * 128, ra.emit = ea;
-            ra.qa = q_err_a ? q_err_a + start : nullptr, ra.qb = q_err_b ? q_err_b + start : nullptr, ra.ine = item_ne;
+            ra.qa = q_err_a ? q_err_a + start : nullptr, ra.qb = q_err_b ? q_err_b + start : nullptr, ra.ine = item_ne, ra.tile_n = item_tile_n;
             launch_score_resident<M>(KS, ra, rows);
             return;
           }

@@ -66,9 +66,11 @@ __global__ void rq_item_exp_kernel(const unsigned *__restrict__ maxbits, int *__
 
 // ne[0] / ne[1] = bits of max_i || y_i 2^e ||_2 and of max_i || y_i 2^e - its high plane ||_2 (non-negative floats: unsigned order);
 // one wavefront per item row; zeroed by the caller.  Once per catalogue version, with the planes.
+// tile_n[t] = bits of max || y 2^e || over the 32 items of tile t (zeroed by the caller): the emit pass starts a tile's accumulators
+// at -(tau - c_q tile_n[t]) instead of using the catalogue-wide bound.
 template <typename T>
 __global__ __launch_bounds__(256) void rq_item_err_kernel(const T *__restrict__ I, size_t rows, int f, const int *__restrict__ exp_in,
-                                                          unsigned *__restrict__ ne) {
+                                                          unsigned *__restrict__ ne, unsigned *__restrict__ tile_n) {
   const float s = rq_pow2(exp_in[0]);
   const int lane = threadIdx.x & 63;
   float mn = 0.f, me = 0.f;
@@ -82,6 +84,11 @@ __global__ __launch_bounds__(256) void rq_item_err_kernel(const T *__restrict__ 
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) n2 += __shfl_xor(n2, off, 64), e2 += __shfl_xor(e2, off, 64);
     mn = fmaxf(mn, n2), me = fmaxf(me, e2);
+    if (lane == 0) {
+      atomicMax(&tile_n[row >> 5], __float_as_uint(sqrtf(n2) * 1.0000002f));
+      // ne[2]: the largest ratio || y - y_h || / || y || of any item (an all-zero row: 0) -- with it E_i <= ne[2] N_i for every item
+      if (n2 > 0.f) atomicMax(&ne[2], __float_as_uint(sqrtf(e2) / sqrtf(n2) * 1.000001f));
+    }
   }
   if (lane == 0) {
     atomicMax(&ne[0], __float_as_uint(sqrtf(mn)));
@@ -158,6 +165,11 @@ __device__ __forceinline__ float rq_screen_eps(float qa, float qb, float N, floa
   return (qa * N + qb * E) * 1.00390625f + qb * N * 3.814697265625e-6f;  // (1 + 2^-8), 2^-18
 }
 
+// the same bound for ONE item of norm N_i: E_i <= rho N_i (rho = ne[2]) gives eps_i <= rq_screen_coef(qa, qb, rho) N_i
+__device__ __forceinline__ float rq_screen_coef(float qa, float qb, float rho) {
+  return (qa + qb * rho) * 1.00390625f + qb * 3.814697265625e-6f;
+}
+
 // a candidate that passed its threshold: filter bitmaps (the batch's item filter, the query's liked items), then the query's list
 __device__ __forceinline__ void rq_append(const EmitArgs &e, int q, int item, unsigned long long key) {
   const uint32_t bit = 1u << (item & 31);
@@ -185,7 +197,8 @@ struct ResidentArgs {
   int n_tiles64;
   EmitArgs emit;           // MODE 2 / 3
   const float *qa, *qb;    // MODE 3: per query row || q 2^e - high plane ||, || high plane ||
-  const unsigned *ine;     // MODE 3: bits of max || y 2^e ||, max || y 2^e - high plane || over the catalogue
+  const unsigned *ine;     // MODE 3: bits of max || y 2^e ||, max || y 2^e - high plane || over the catalogue, max ratio of the two per item
+  const float *tile_n;     // MODE 3: max || y 2^e || per 32-item tile
 };
 
 // LDS slots of the item ring: as many as leave room for two workgroups per CU (the emit pass also stages its candidates in LDS)
@@ -237,6 +250,8 @@ __global__ __launch_bounds__(256, 2) void score_resident_kernel(ResidentArgs a) 
   __shared__ unsigned long long st_key[EMIT ? kRqStageCap : 1];
   __shared__ unsigned short st_row[EMIT ? kRqStageCap : 1];
   __shared__ unsigned st_n;
+  constexpr int kTileNormCap = 512;  // steps whose tile norms a workgroup keeps in LDS (beyond: the catalogue-wide maximum)
+  __shared__ float tn_s[ONE ? kTileNormCap : 1];
   if (EMIT && threadIdx.x == 0) st_n = 0u;
 
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -280,6 +295,9 @@ __global__ __launch_bounds__(256, 2) void score_resident_kernel(ResidentArgs a) 
 
   // ---- prologue: scales and thresholds of the workgroup's rows, the resident query fragments -----------------------------
   const int iexp = a.iexp[0];
+  if constexpr (ONE) {
+    for (int s = threadIdx.x; s < min(steps, kTileNormCap); s += 256) tn_s[s] = a.tile_n[min(chunk + s * a.chunks, last_tile)];
+  }
   for (int r = threadIdx.x; r < QROWS; r += 256) {
     const int q = qb * QROWS + r;
     const int e = a.qexp[q] + iexp;                        // (qexp is padded to whole query blocks)
@@ -304,7 +322,9 @@ __global__ __launch_bounds__(256, 2) void score_resident_kernel(ResidentArgs a) 
       }
       // screened pass: everything whose exact score can reach tau (a NaN / inf bound lets everything through: the row overflows
       // and goes to the exact path)
-      if constexpr (ONE) ts -= rq_screen_eps(a.qa[q], a.qb[q], __uint_as_float(a.ine[0]), __uint_as_float(a.ine[1]));
+      // screened pass: a tile's accumulators start at -(tau - c_q N_t), N_t = the tile's largest item norm (a NaN / inf coefficient
+      // lets everything through: the row overflows and goes to the exact path); c_q rides in `unscale` (not needed without norms)
+      if constexpr (ONE) unscale[r] = q < a.nq ? rq_screen_coef(a.qa[q], a.qb[q], __uint_as_float(a.ine[2])) : 0.f;
       tau_s[r] = ts;
     }
   }
@@ -335,12 +355,18 @@ __global__ __launch_bounds__(256, 2) void score_resident_kernel(ResidentArgs a) 
   // d + tau is an ulp or two off the threshold pass's value of the same dot product: rows then find k - 1 candidates); here the
   // candidates are re-scored anyway, the keys only have to keep each row's ORDER (an offset per row does), and the rounding of the
   // offset sum (2^-23 of |tau|) is inside the bound's slack term
-  [[maybe_unused]] float nts[ONE ? TQ : 1][16];
+  [[maybe_unused]] float nts[ONE ? TQ : 1][16], cqr[ONE ? TQ : 1][16];
+  [[maybe_unused]] float norm_max = 0.f;
   if constexpr (ONE) {
+    norm_max = __uint_as_float(a.ine[0]);
+    asm volatile("" : "+v"(norm_max));
 #pragma unroll
     for (int tq = 0; tq < TQ; ++tq)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) nts[tq][e] = -tau_s[wave * 32 * TQ + 32 * tq + 4 * kh + (e & 3) + 8 * (e >> 2)];
+      for (int e = 0; e < 16; ++e) {
+        const int r = wave * 32 * TQ + 32 * tq + 4 * kh + (e & 3) + 8 * (e >> 2);
+        nts[tq][e] = -tau_s[r], cqr[tq][e] = unscale[r];
+      }
   }
 
   // ---- item stream -----------------------------------------------------------------------------------------------------
@@ -388,16 +414,21 @@ __global__ __launch_bounds__(256, 2) void score_resident_kernel(ResidentArgs a) 
 #ifdef RQ_CLOCK
     const long long rq_c0 = __builtin_readcyclecounter(), rq_w0 = wall_clock64();
 #endif
+    [[maybe_unused]] float tile_norm_next = ONE ? tn_s[0] : 0.f;  // (norm_max: loaded in the prologue -- a global load in this loop would be waited for with vmcnt(0), draining the ring)
     for (int s = 0; s < steps; ++s) {
       if (!(RQ_KO & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * PER_WAVE) : "memory");
       if (!(RQ_KO & 8)) __builtin_amdgcn_s_barrier();
       if (!(RQ_KO & 2)) dma(s + NSTAGE - 1);
       const unsigned char *slot = ring + (s % NSTAGE) * SLOT;
+      // (read one step ahead: the accumulators' start values -- and with them the first product -- would otherwise wait for an LDS
+      // round trip at the top of every step)
+      [[maybe_unused]] const float tile_norm = tile_norm_next;
+      if constexpr (ONE) tile_norm_next = s + 1 < kTileNormCap ? tn_s[s + 1] : norm_max;
       f32x16 acc[TQ];
 #pragma unroll
       for (int tq = 0; tq < TQ; ++tq)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[tq][e] = ONE ? nts[tq][e] : 0.f;
+        for (int e = 0; e < 16; ++e) acc[tq][e] = ONE ? fmaf(cqr[tq][e], tile_norm, nts[tq][e]) : 0.f;
       // item fragments TWO k-steps ahead of the MFMAs that use them (three register sets): with the reads of k-step ks + 1 issued
       // only after the MFMAs of ks, an LDS round trip under load (eight wavefronts reading, the DMA writing) outlasted the 192
       // cycles those MFMAs cover, and the matrix pipe idled a third of the loop (SQ_VALU_MFMA_BUSY: 0.50 of the launch)
