@@ -1135,11 +1135,13 @@ template <int BLOCK, typename TQs, typename TIs>
 __global__ __launch_bounds__(BLOCK) void select_screened_kernel(const uint64_t *__restrict__ gcand, const unsigned int *__restrict__ count,
                                                                 int cap, int k, int32_t *__restrict__ out_ids, float *__restrict__ out_dist,
                                                                 int out_stride, int *__restrict__ fallback, const float *__restrict__ row_eps,
-                                                                const TQs *__restrict__ Q, const TIs *__restrict__ I, int f) {
+                                                                const TQs *__restrict__ Q, const TIs *__restrict__ I, int f,
+                                                                int *__restrict__ n_out) {
   __shared__ uint64_t cand[kEmitCap];
   __shared__ unsigned int sh_r;
   const int tid = threadIdx.x, q = blockIdx.x;
   const unsigned int n_c = count[q];
+  if (tid == 0) n_out[q] = (int)min(n_c, (unsigned)cap + 1u);
   if (n_c > (unsigned)cap || n_c < (unsigned)k) {  // uniform
     if (tid == 0) fallback[q] = 1;
     return;
@@ -1345,6 +1347,11 @@ extern "C" int imp_matrix_astype(const imp_matrix *src, size_t itemsize, imp_mat
 
 struct imp_knn {
   size_t max_temp_memory = 0;
+  // screened emit path: multiplier (1, 2, 4) of the threshold pre-pass's subset stride, steered by the candidate counts of the
+  // previous batch of the same (catalogue size, k) -- see the feedback rule in imp_knn_topk
+  int stride_boost = 1;
+  size_t boost_ni = 0;
+  int boost_k = 0;
   // persistent workspaces (grown on demand): no hipMalloc on the query path after the first call
   DeviceArray<float> scores, tile_max;
   DeviceArray<uint64_t> gcand;
@@ -1490,9 +1497,10 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
     constexpr size_t kFlagSlots = 2048;  // = the emit path's batch
     const size_t out_words = nq * (size_t)k;
     const bool stage_results = (host_ids || host_dist) && out_words <= ((size_t)16 << 20);
-    int *host_flags = static_cast<int *>(knn->host_stage.ensure((kFlagSlots + (stage_results ? 2 * out_words : 0)) * 4));
-    int32_t *stage_ids = reinterpret_cast<int32_t *>(host_flags + kFlagSlots);
-    float *stage_dist = reinterpret_cast<float *>(host_flags + kFlagSlots + out_words);
+    int *host_flags = static_cast<int *>(knn->host_stage.ensure((2 * kFlagSlots + (stage_results ? 2 * out_words : 0)) * 4));
+    int *host_counts = host_flags + kFlagSlots;  // screened select: the length of every row's candidate list (feeds the stride rule)
+    int32_t *stage_ids = reinterpret_cast<int32_t *>(host_flags + 2 * kFlagSlots);
+    float *stage_dist = reinterpret_cast<float *>(host_flags + 2 * kFlagSlots + out_words);
     if (host_ids) {
       if (stage_results) {
         d_ids = stage_ids;
@@ -1532,7 +1540,15 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
     // the query's counter and a scattered store (measured at configs[4]'s similar_items shape, 26 744 items, k = 100,
     // stride 20: 7.5 % of all scores survive and the emit GEMM runs at 10 TFLOP/s against 33 for the materialising path) --
     // and a stride below 8 (a pre-pass of more than an eighth of the GEMM) is not worth it either.
-    const int stride = (int)std::min<size_t>(std::min(kSubStride, kEmitCap / (2 * std::max(1, k_eff))), ni / ((size_t)64 * std::max(1, k_eff)));
+    // The stride is a trade between the pre-pass (scores of 1 / stride of the items materialised, filtered, selected from) and the
+    // candidate lists (about stride x k entries on unstructured data).  On TRAINED factors a row's best scores stand far above the
+    // bulk and the lists stay short (22 entries at stride 32 on the bench's factors), so the screened path lets the stride grow:
+    // after every batch the mean list length decides -- under 48: twice the stride next time (up to 4 x 32), over 400 or more than
+    // one row in a hundred sent to the exact path: half.  Results do not depend on the stride; random factors stay at 32
+    // (stride 128 there: 1280-entry lists and every row's staging overflowing -- measured, profiles/r06_topk_resident_knockouts.txt).
+    if (knn->boost_ni != ni || knn->boost_k != k_eff) knn->stride_boost = 1, knn->boost_ni = ni, knn->boost_k = k_eff;
+    const int stride_cap = item_norms ? kSubStride : kSubStride * knn->stride_boost;
+    const int stride = (int)std::min<size_t>(std::min(stride_cap, kEmitCap / (2 * std::max(1, k_eff))), ni / ((size_t)64 * std::max(1, k_eff)));
     const bool emit_shape = (f % 8 == 0) && k_eff == k && k_eff <= 256 && stride >= 8;
     const bool will_emit = !no_emit_alloc && getenv("IMP_TOPK_NO_FAST") == nullptr && emit_shape;
     float *scores = will_emit ? nullptr : imp_knn::ensure(knn->scores, batch * ni);  // the emit path materialises fallback rows only
@@ -1713,7 +1729,7 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
           IMP_PROF("topk_select_candidates");
           if (screen)
             select_screened_kernel<512, TQ, TI><<<(unsigned)rows, 512, 0, stream()>>>(cand, cnt, kEmitCap, k_eff, d_ids + start * k, d_dist + start * k, k,
-                                                                                     fallback_e, row_eps, Qb + start * f, Ib, f);
+                                                                                     fallback_e, row_eps, Qb + start * f, Ib, f, host_counts);
           else
             select_candidates_kernel<512><<<(unsigned)rows, 512, 0, stream()>>>(cand, cnt, kEmitCap, k_eff, d_ids + start * k,
                                                                                d_dist + start * k, k, fallback_e, resident ? row_unscale : nullptr);
@@ -1732,6 +1748,13 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
         fb_list.clear();
         for (size_t i = 0; i < rows; ++i)
           if (flags[i]) fb_list.push_back((int32_t)i);
+        if (screen && rows >= 64) {  // the stride rule (above): mean list length and exact-path rows of this batch
+          size_t total = 0;
+          for (size_t i = 0; i < rows; ++i) total += (size_t)host_counts[i];
+          const size_t mean = total / rows;
+          if (fb_list.size() * 100 > rows || mean > 400) knn->stride_boost = std::max(1, knn->stride_boost / 2);
+          else if (mean < 48 && knn->stride_boost < 4) knn->stride_boost *= 2;
+        }
         static const bool debug = getenv("IMP_TOPK_DEBUG") != nullptr;
         if (debug && !fb_list.empty()) {
           std::vector<unsigned int> hc(rows);

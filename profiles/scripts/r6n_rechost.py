@@ -1,6 +1,9 @@
 # where model.recommend()'s host time goes (per 1000-user batch, configs[2] shape, random factors)
 import sys, time, numpy as np
 sys.path.insert(0, '.')
+import os
+import implicit_amd._libpath as _lp
+if os.environ.get('IMP_LIB_PATH'): _lp.OVERRIDE = os.environ['IMP_LIB_PATH']
 import implicit_amd.gpu as gpu
 from implicit_amd.als import AlternatingLeastSquares
 from implicit_amd.synthetic import synthetic_csr
