@@ -484,3 +484,27 @@ def test_screened_emit_pass_bounds_hold_on_awkward_rows(gpu, oracle):
     ok = ~_near_tie_rows(want_d, f)
     assert_array_equal(ids[ok], want_ids[ok, :k])
     assert_allclose(d[ok], want_d[ok, :k], rtol=2e-3)
+
+
+def test_results_do_not_depend_on_the_adaptive_subset_stride(gpu, oracle):
+    """The screened path widens the threshold pre-pass's subset stride (32 -> 64 -> 128) when a handle's candidate lists come
+    out short -- heavy-tailed item norms, as trained factors have -- and narrows it again when they do not.  The ids and scores
+    of every call are the oracle's whatever the stride was; a different catalogue size starts over."""
+    rng = np.random.default_rng(21)
+    ni, f, nq, k = 150_000, 64, 512, 10
+    items = (rng.standard_normal((ni, f)) * 0.05).astype(np.float32) * rng.lognormal(0.0, 1.2, size=(ni, 1)).astype(np.float32)
+    queries = (rng.standard_normal((nq, f)) * 0.1).astype(np.float32)
+    want_ids, want_d = oracle.topk(items, queries, k + 1)
+    ok = ~_near_tie_rows(want_d, f)
+    knn, I, Q = gpu.KnnQuery(), gpu.Matrix(items), gpu.Matrix(queries)
+    for call in range(5):                               # stride 32, 64, 128, 128, 128 if the lists stay short
+        ids, d = knn.topk(I, Q, k)
+        assert_array_equal(ids[ok], want_ids[ok, :k], err_msg=f"call {call}")
+        assert_allclose(d[ok], want_d[ok, :k], rtol=3e-5)
+    flat = (rng.standard_normal((60_000, f)) * 0.1).astype(np.float32)   # unstructured: long lists, the stride goes back / stays
+    w_ids, w_d = oracle.topk(flat, queries, k + 1)
+    ok2 = ~_near_tie_rows(w_d, f)
+    F = gpu.Matrix(flat)
+    for call in range(3):
+        ids, d = knn.topk(F, Q, k)
+        assert_array_equal(ids[ok2], w_ids[ok2, :k], err_msg=f"flat call {call}")
