@@ -414,10 +414,27 @@ __global__ __launch_bounds__(256, 2) void score_resident_kernel(ResidentArgs a) 
 #ifdef RQ_CLOCK
     const long long rq_c0 = __builtin_readcyclecounter(), rq_w0 = wall_clock64();
 #endif
+    // candidates staged so far go to the lists EARLY when the staging buffer is nearly full: read right behind a step's barrier
+    // the count is the same in every wavefront (all of them are past the previous step's test), so the decision is uniform.
+    // Popularity-dominated scores (the same few hundred items best for every query) put 256 survivors per such item into ONE
+    // workgroup: without this its buffer overflowed and every row of its query block went to the exact path
+    constexpr unsigned kStageHead = 512;  // room a single step may need (beyond: the overflow rule at the end)
+    auto flush_staged = [&]() {
+      const unsigned n_st = min(st_n, (unsigned)kRqStageCap);
+      for (unsigned i = threadIdx.x; i < n_st; i += 256) {
+        const unsigned long long key = st_key[i];
+        rq_append(a.emit, qb * QROWS + (int)st_row[i], (int)(uint32_t)key, key);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the appends' memory operations share the counter of the counted DMA waits)
+      __syncthreads();
+      if (threadIdx.x == 0) st_n = 0u;
+      __syncthreads();
+    };
     [[maybe_unused]] float tile_norm_next = ONE ? tn_s[0] : 0.f;  // (norm_max: loaded in the prologue -- a global load in this loop would be waited for with vmcnt(0), draining the ring)
     for (int s = 0; s < steps; ++s) {
       if (!(RQ_KO & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * PER_WAVE) : "memory");
       if (!(RQ_KO & 8)) __builtin_amdgcn_s_barrier();
+      if (st_n > (unsigned)kRqStageCap - kStageHead) flush_staged();  // (uniform; rare)
       if (!(RQ_KO & 2)) dma(s + NSTAGE - 1);
       const unsigned char *slot = ring + (s % NSTAGE) * SLOT;
       // (read one step ahead: the accumulators' start values -- and with them the first product -- would otherwise wait for an LDS

@@ -508,3 +508,25 @@ def test_results_do_not_depend_on_the_adaptive_subset_stride(gpu, oracle):
     for call in range(3):
         ids, d = knn.topk(F, Q, k)
         assert_array_equal(ids[ok2], w_ids[ok2, :k], err_msg=f"flat call {call}")
+
+
+def test_concentrated_scores_defeat_the_screen_not_the_result(gpu):
+    """All-positive, nearly parallel factors (a model one sweep from the default start): every score within 1e-3 of the next, so
+    the one-product screen passes thousands of entries per row and the lists overflow.  The batch is then redone by the
+    three-product emit pass -- decided by the batch's own outcome, so the same call returns the same bits every time -- and the
+    answer is still the true top k (judged in float64: with scores this close, adjacent ranks are near-ties by construction)."""
+    rng = np.random.default_rng(2)
+    ni, f, nq, k = 120_000, 64, 300, 10
+    items = (rng.random((ni, f), dtype=np.float32) * 0.01 + 0.02).astype(np.float32)
+    queries = (rng.random((nq, f), dtype=np.float32) * 0.01 + 0.02).astype(np.float32)
+    knn, I, Q = gpu.KnnQuery(), gpu.Matrix(items), gpu.Matrix(queries)
+    ids, d = knn.topk(I, Q, k)
+    ids2, d2 = knn.topk(I, Q, k)
+    assert_array_equal(ids, ids2)
+    assert_array_equal(d, d2)
+    exact = queries.astype(np.float64) @ items.astype(np.float64).T
+    best = -np.sort(-exact, axis=1)[:, :k]
+    got = np.take_along_axis(exact, ids.astype(np.int64), axis=1)
+    assert_allclose(got, best, rtol=2e-6)               # the returned items ARE the best k up to fp32 near-ties
+    assert_allclose(d, got, rtol=3e-5)
+    assert (np.diff(d, axis=1) <= 0).all()
