@@ -962,6 +962,17 @@ __global__ void coo_bitmap_kernel(uint32_t *__restrict__ bits, int words, int st
   }
 }
 
+// the words coo_bitmap_kernel touched, back to zero: a batch leaves its per-query bitmap as it found it, so the next batch needs no
+// 36 MB memset (1000 queries x 292 385 items) -- this is 44 K stores, queued behind the batch where nobody waits for it
+__global__ void coo_bitmap_clear_kernel(uint32_t *__restrict__ bits, int words, int start, int end, int ni, const int32_t *__restrict__ row,
+                                        const int32_t *__restrict__ col, size_t nnz) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nnz; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = row[i], c = col[i];
+    if (r < start || r >= end || c < 0 || c >= ni) continue;
+    bits[(size_t)(r - start) * words + (c >> 5)] = 0u;
+  }
+}
+
 __global__ void item_bitmap_kernel(uint32_t *__restrict__ bits, int ni, const int32_t *__restrict__ items, int n_items,
                                    float *__restrict__ S_sub, int rows, int sub_cols, int sub_stride) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)n_items; i += (size_t)gridDim.x * blockDim.x) {
@@ -1352,6 +1363,9 @@ struct imp_knn {
   int stride_boost = 1;
   size_t boost_ni = 0;
   int boost_k = 0;
+  // the per-query filter bitmap is all zeros between batches (every batch clears the words it set); true: not known to be (fresh
+  // or regrown memory, a call that ended in an error) -- the next batch zeroes its part wholesale first
+  bool row_bits_dirty = true;
   // persistent workspaces (grown on demand): no hipMalloc on the query path after the first call
   DeviceArray<float> scores, tile_max;
   DeviceArray<uint64_t> gcand;
@@ -1623,7 +1637,15 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
       float *row_unscale = imp_knn::ensure(knn->row_unscale, rq_query_pad(ebatch));
       int *fallback_e = host_flags;  // one flag per row of the batch, read by the host after the batch's wait
       const bool have_coo = query_filter && query_filter->nnz, have_items = item_filter && item_filter->size;
+      if (have_coo && knn->row_bits.size < ebatch * (size_t)words) knn->row_bits_dirty = true;  // (regrown: fresh memory)
       uint32_t *row_bits = have_coo ? imp_knn::ensure(knn->row_bits, ebatch * (size_t)words) : nullptr;
+      auto clear_row_bits = [&](size_t start, size_t end) {  // behind a batch: the words it set, back to zero
+        int grid = (int)std::min<size_t>(((size_t)query_filter->nnz + 255) / 256, (size_t)ctx().num_cus * 8);
+        coo_bitmap_clear_kernel<<<grid, 256, 0, stream()>>>(row_bits, words, (int)start, (int)end, (int)ni, query_filter->row.data(),
+                                                            query_filter->col.data(), (size_t)query_filter->nnz);
+        IMP_CHECK_HIP(hipGetLastError());
+        knn->row_bits_dirty = false;
+      };
       uint32_t *item_bits = have_items ? imp_knn::ensure(knn->item_bits, (size_t)words) : nullptr;
       if (have_items) IMP_CHECK_HIP(hipMemsetAsync(item_bits, 0, (size_t)words * 4, stream()));
       static_assert(kFlagSlots >= 2048, "one flag per row of an emit batch");
@@ -1690,7 +1712,10 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
         const size_t end = std::min(nq, start + ebatch), rows = end - start;
         const auto *qptr = Qb + start * f;
         const unsigned qblocks = (unsigned)((rows + 127) / 128);
-        if (have_coo) IMP_CHECK_HIP(hipMemsetAsync(row_bits, 0, rows * (size_t)words * 4, stream()));
+        if (have_coo) {
+          if (knn->row_bits_dirty) IMP_CHECK_HIP(hipMemsetAsync(row_bits, 0, knn->row_bits.size * sizeof(uint32_t), stream()));
+          knn->row_bits_dirty = true;  // (until this batch's clear is queued)
+        }
         {
           IMP_PROF("score_gemm_subset");
           gemm(std::integral_constant<int, 1>{}, start, dim3((unsigned)n_sub, qblocks), (int)rows, sub, stride, EmitArgs{});
@@ -1813,8 +1838,10 @@ int imp_knn_topk(imp_knn *knn, const imp_matrix *items_in, const imp_matrix *que
             IMP_CHECK_HIP(hipGetLastError());
           }
         }
+        if (have_coo && end < nq) clear_row_bits(start, end);  // (the last batch's: behind the call's wait, below)
       }
       deliver();
+      if (have_coo && nq > 0) clear_row_bits((nq - 1) / ebatch * ebatch, nq);
       return;
     }
 

@@ -691,7 +691,12 @@ template <int MODE> static void launch_score_resident(int KS, ResidentArgs a, in
     a.chunks = 8 * m;
     auto kern = score_resident_kernel<K, T, MODE>;
     const size_t lds = rq_lds_bytes<K, T, MODE>();
-    IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static bool attr_done[64] = {};  // (per instantiation and device: the attribute call costs a microsecond or two of every launch)
+    const int dev = ctx().device;
+    if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+      IMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      if (dev >= 0 && dev < 64) attr_done[dev] = true;
+    }
     kern<<<a.chunks * a.n_qb, 256, lds, stream()>>>(a);
     IMP_CHECK_HIP(hipGetLastError());
 #ifdef RQ_CLOCK
