@@ -249,10 +249,10 @@ __global__ __launch_bounds__(256, 2) void score_resident_kernel(ResidentArgs a) 
   constexpr bool EMIT = MODE >= 2, ONE = MODE == 3;  // ONE: one product (high planes only)
   __shared__ unsigned long long st_key[EMIT ? kRqStageCap : 1];
   __shared__ unsigned short st_row[EMIT ? kRqStageCap : 1];
-  __shared__ unsigned st_n;
+  __shared__ unsigned st_n, st_over;  // staged entries; sticky: a step staged more than the buffer had room for (entries were dropped)
   constexpr int kTileNormCap = 512;  // steps whose tile norms a workgroup keeps in LDS (beyond: the catalogue-wide maximum)
   __shared__ float tn_s[ONE ? kTileNormCap : 1];
-  if (EMIT && threadIdx.x == 0) st_n = 0u;
+  if (EMIT && threadIdx.x == 0) st_n = 0u, st_over = 0u;
 
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c31 = lane & 31, kh = lane >> 5;
@@ -418,7 +418,10 @@ __global__ __launch_bounds__(256, 2) void score_resident_kernel(ResidentArgs a) 
     // the count is the same in every wavefront (all of them are past the previous step's test), so the decision is uniform.
     // Popularity-dominated scores (the same few hundred items best for every query) put 256 survivors per such item into ONE
     // workgroup: without this its buffer overflowed and every row of its query block went to the exact path
-    constexpr unsigned kStageHead = 512;  // room a single step may need (beyond: the overflow rule at the end)
+    // room a single step may need: three quarters of the buffer (an item that passes for every row of the block stages 256 entries
+    // by itself; a step that needs more drops entries -- remembered in st_over, and the rule at the end sends the block's rows to
+    // the exact path.  A fuzz run found the first form of this, which forgot the drop at the flush: profiles/scripts/r6F_fuzz.py)
+    constexpr unsigned kStageHead = kRqStageCap - kRqStageCap / 4;
     auto flush_staged = [&]() {
       const unsigned n_st = min(st_n, (unsigned)kRqStageCap);
       for (unsigned i = threadIdx.x; i < n_st; i += 256) {
@@ -427,12 +430,18 @@ __global__ __launch_bounds__(256, 2) void score_resident_kernel(ResidentArgs a) 
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the appends' memory operations share the counter of the counted DMA waits)
       __syncthreads();
-      if (threadIdx.x == 0) st_n = 0u;
+      if (threadIdx.x == 0) {
+        if (st_n > (unsigned)kRqStageCap) st_over = 1u;  // (a single step outran the headroom: remembered for the rule at the end)
+        st_n = 0u;
+      }
       __syncthreads();
     };
     [[maybe_unused]] float tile_norm_next = ONE ? tn_s[0] : 0.f;  // (norm_max: loaded in the prologue -- a global load in this loop would be waited for with vmcnt(0), draining the ring)
     for (int s = 0; s < steps; ++s) {
       if (!(RQ_KO & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * PER_WAVE) : "memory");
+      // (the raw barrier does not wait for LDS operations: a wavefront's staging stores of the previous step's test must have
+      // landed before another wavefront may flush them -- none of its fragment reads is in flight at this point, so the wait is free)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (!(RQ_KO & 8)) __builtin_amdgcn_s_barrier();
       if (st_n > (unsigned)kRqStageCap - kStageHead) flush_staged();  // (uniform; rare)
       if (!(RQ_KO & 2)) dma(s + NSTAGE - 1);
@@ -559,7 +568,7 @@ __global__ __launch_bounds__(256, 2) void score_resident_kernel(ResidentArgs a) 
       const unsigned long long key = st_key[i];
       rq_append(a.emit, qb * QROWS + (int)st_row[i], (int)(uint32_t)key, key);
     }
-    if (n_all > (unsigned)kRqStageCap) {
+    if (n_all > (unsigned)kRqStageCap || st_over) {
       // the staging buffer overflowed (a workgroup expects ~640 of its 1536 entries): candidates were dropped, WHOSE is not known --
       // every row of the query block is declared overflowed and re-done by the exact path (slow, correct, and not seen so far)
       for (int r = threadIdx.x; r < QROWS; r += 256)
